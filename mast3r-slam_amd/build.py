@@ -1,0 +1,70 @@
+"""Build libm3slam_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python mast3r-slam_amd/build.py [--force]
+
+One object per .hip source (compiled in parallel), linked into
+mast3r-slam_amd/lib/libm3slam_hip.so.  matching.hip is compiled with
+-ffp-contract=off: its results are bit-exact against the CPU oracle.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "lib")
+LIB = os.path.join(OUT, "libm3slam_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fhip-fp32-correctly-rounded-divide-sqrt",
+          "-Wall", "-Wno-unused-function"]
+PER_FILE = {
+    "matching.hip": ["-ffp-contract=off"],
+}
+
+
+def _sources():
+    return sorted(f for f in os.listdir(SRC) if f.endswith(".hip"))
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OUT, exist_ok=True)
+    headers = [os.path.join(SRC, f) for f in os.listdir(SRC) if f.endswith(".h")]
+    headers.append(os.path.join(HERE, "..", "include", "m3slam.h"))
+    headers += [os.path.join(HERE, "..", "include", f) for f in os.listdir(os.path.join(HERE, "..", "include"))]
+    jobs = []
+    objs = []
+    for s in _sources():
+        src = os.path.join(SRC, s)
+        obj = os.path.join(OUT, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + headers):
+            jobs.append([HIPCC, *COMMON, *PER_FILE.get(s, []), "-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr, flush=True)
+
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    if jobs or force or _stale(LIB, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,324 @@
+// Backend Gauss-Newton ("rays" = 3-D point alignment) for gfx950.
+//
+// Replaces kernels.gauss_newton_rays (backends/mpsgraph/kernels.py:262-322), numpy twin
+// gauss_newton.py:23-280, Metal gn_jacobian_kernel (gauss_newton.metal:66-252) and its HOST
+// reduction (gn_metal_runner.py:221-292) of /root/reference/src/mlx_mast3r_slam.
+//
+// The Metal path writes 119 floats PER POINT (476 B) and reduces them on the host; here
+// the per-point 7x7 contributions never leave registers: float32 per point, float64
+// accumulation, wave-shuffle + LDS reduction to 36 doubles per (edge, chunk), a second
+// fixed-order pass to 36 doubles per edge.  HBM bound: ~41 B per (edge, point).
+// With the reference's "simplified adjoint" Ji = -Jj (gauss_newton.py:189-213) the five
+// blocks of an edge are +-Hjj and +-gj, so only Hjj (28) and gj (7) are accumulated.
+#include "common.h"
+#include "sim3_dev.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kSums = 36;         // 28 Hjj upper + 7 gj + 1 count
+constexpr int kMaxChunks = 128;
+constexpr int kPtsPerChunk = 2048;
+constexpr int kSolveThreads = 1024;
+constexpr int kMaxDim = 448;      // 64 free keyframes in the single-workgroup Cholesky
+
+__host__ __device__ inline int gn_chunks(int P) {
+    int c = (P + kPtsPerChunk - 1) / kPtsPerChunk;
+    return c < 1 ? 1 : (c > kMaxChunks ? kMaxChunks : c);
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_gn_blocks(const float *__restrict__ Twc, const float *__restrict__ Xs, const float *__restrict__ Cs,
+            const int32_t *__restrict__ ii, const int32_t *__restrict__ jj, const int32_t *__restrict__ idx,
+            const uint8_t *__restrict__ valid, const float *__restrict__ Q, double *__restrict__ part,
+            const double *__restrict__ done, int K, int P, int chunks, float inv_sigma, float C_thresh,
+            float Q_thresh) {
+    if (done && done[0] != 0.0) return;
+    const int e = blockIdx.y, chunk = blockIdx.x;
+    const int ix = ii[e], jx = jj[e];
+    double acc[kSums];
+#pragma unroll
+    for (int i = 0; i < kSums; ++i) acc[i] = 0.0;
+    if (ix >= 0 && ix < K && jx >= 0 && jx < K) {
+        const Pose<double> Ti = load_pose<double>(Twc + 8 * ix), Tj = load_pose<double>(Twc + 8 * jx);
+        const Pose<double> Tij_d = rel_ops(Ti, Tj);
+        Pose<float> Tij;
+        Tij.t = {(float)Tij_d.t.x, (float)Tij_d.t.y, (float)Tij_d.t.z};
+        Tij.q = {(float)Tij_d.q.x, (float)Tij_d.q.y, (float)Tij_d.q.z, (float)Tij_d.q.w};
+        Tij.s = (float)Tij_d.s;
+        const Q4<float> qi_inv{-(float)Ti.q.x, -(float)Ti.q.y, -(float)Ti.q.z, (float)Ti.q.w};
+        const float s_inv = (float)(1.0 / Ti.s);
+        // translation columns of Jj are per-edge constants: R_i^T e_c / s_i
+        const V3<float> jt[3] = {s_inv * qrot(qi_inv, V3<float>{1.f, 0.f, 0.f}),
+                                 s_inv * qrot(qi_inv, V3<float>{0.f, 1.f, 0.f}),
+                                 s_inv * qrot(qi_inv, V3<float>{0.f, 0.f, 1.f})};
+        const float *Xi_base = Xs + (size_t)ix * P * 3, *Xj_base = Xs + (size_t)jx * P * 3;
+        const float *Ci = Cs + (size_t)ix * P, *Cj = Cs + (size_t)jx * P;
+        const size_t eo = (size_t)e * P;
+        for (int k = chunk * kThreads + threadIdx.x; k < P; k += chunks * kThreads) {
+            if (!valid[eo + k]) continue;
+            const float qc = Q[eo + k];
+            int id = idx[eo + k];
+            if (id < 0) id += P;
+            id = id < 0 ? 0 : (id >= P ? P - 1 : id);
+            if (!(qc > Q_thresh) || !(Ci[id] > C_thresh) || !(Cj[k] > C_thresh)) continue;
+            const V3<float> Xi{Xi_base[3 * id], Xi_base[3 * id + 1], Xi_base[3 * id + 2]};
+            const V3<float> Xj{Xj_base[3 * k], Xj_base[3 * k + 1], Xj_base[3 * k + 2]};
+            const V3<float> Y = act(Tij, Xj);
+            const float err[3] = {Y.x - Xi.x, Y.y - Xi.y, Y.z - Xi.z};
+            const float sqrt_w = inv_sigma * sqrtf(qc), w2 = sqrt_w * sqrt_w;
+            const V3<float> br[3] = {{0.f, Y.z, -Y.y}, {-Y.z, 0.f, Y.x}, {Y.y, -Y.x, 0.f}};
+            const float Yc[3] = {Y.x, Y.y, Y.z};
+            float h[35];
+#pragma unroll
+            for (int i = 0; i < 35; ++i) h[i] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float we = fabsf(sqrt_w * err[c]);
+                const float w = ((we < 1.345f) ? 1.0f : 1.345f / we) * w2;
+                const V3<float> jr = qrot(qi_inv, br[c]);
+                const float J[7] = {jt[c].x, jt[c].y, jt[c].z, jr.x, jr.y, jr.z, Yc[c]};
+                int m = 0;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    const float wj = w * J[i];
+#pragma unroll
+                    for (int j = i; j < 7; ++j) h[m++] += wj * J[j];
+                    h[28 + i] += wj * err[c];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 35; ++i) acc[i] += (double)h[i];
+            acc[35] += 1.0;
+        }
+    }
+    __shared__ double red[kThreads / 64][kSums];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < kSums; ++i) {
+        const double s = m3_wave_sum(acc[i]);
+        if (lane == 0) red[wv][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kSums) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) s += red[w][threadIdx.x];
+        part[((size_t)e * chunks + chunk) * kSums + threadIdx.x] = s;
+    }
+}
+
+// fixed-order reduction over the chunks of one edge
+__global__ void __launch_bounds__(64)
+k_gn_reduce(const double *__restrict__ part, double *__restrict__ blocks, const double *__restrict__ done,
+            int chunks) {
+    if (done && done[0] != 0.0) return;
+    const int e = blockIdx.x;
+    if (threadIdx.x >= kSums) return;
+    double s = 0.0;
+    for (int c = 0; c < chunks; ++c) s += part[((size_t)e * chunks + c) * kSums + threadIdx.x];
+    blocks[(size_t)e * kSums + threadIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_gn_zero(double *__restrict__ Hbuf, const double *__restrict__ done, int64_t count) {
+    if (done && done[0] != 0.0) return;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < count; i += (int64_t)gridDim.x * kThreads)
+        Hbuf[i] = 0.0;
+}
+
+// scatter one edge's +-Hjj / +-gj into the dense system (gauss_newton.py:220-251)
+__global__ void __launch_bounds__(64)
+k_gn_assemble(const double *__restrict__ blocks, const int32_t *__restrict__ ii, const int32_t *__restrict__ jj,
+              const int32_t *__restrict__ local, double *__restrict__ H, double *__restrict__ g,
+              const double *__restrict__ done, int K, int dim) {
+    if (done && done[0] != 0.0) return;
+    const int e = blockIdx.x, t = threadIdx.x;
+    const int ix = ii[e], jx = jj[e];
+    if (ix < 0 || ix >= K || jx < 0 || jx >= K) return;
+    const int il = local[ix], jl = local[jx];
+    const double *b = blocks + (size_t)e * kSums;
+    if (b[35] == 0.0 || (il < 0 && jl < 0)) return;
+    if (t < 49) {
+        const int r = t / 7, c = t % 7;
+        const int lo = r < c ? r : c, hi = r < c ? c : r;
+        const double v = b[lo * 7 - lo * (lo - 1) / 2 + (hi - lo)];
+        if (il >= 0) atomicAdd(&H[(size_t)(il * 7 + r) * dim + il * 7 + c], v);
+        if (jl >= 0) atomicAdd(&H[(size_t)(jl * 7 + r) * dim + jl * 7 + c], v);
+        if (il >= 0 && jl >= 0) {
+            atomicAdd(&H[(size_t)(il * 7 + r) * dim + jl * 7 + c], -v);
+            atomicAdd(&H[(size_t)(jl * 7 + r) * dim + il * 7 + c], -v);
+        }
+    } else if (t < 56) {
+        const int r = t - 49;
+        if (il >= 0) atomicAdd(&g[il * 7 + r], -b[28 + r]);
+        if (jl >= 0) atomicAdd(&g[jl * 7 + r], b[28 + r]);
+    }
+}
+
+// One workgroup: (H + 1e-6 I) dx = -g by in-place Cholesky (lower) + two triangular solves,
+// stop test, then T <- exp(dx) T for the free keyframes.  dx is left in x[0..dim).
+__global__ void __launch_bounds__(kSolveThreads)
+k_gn_step(double *__restrict__ H, double *__restrict__ g, double *__restrict__ x, float *__restrict__ Twc,
+          const int32_t *__restrict__ local, double *__restrict__ info, int K, int dim, float delta_thresh,
+          int apply) {
+    if (info[2] != 0.0) return;
+    const int t = threadIdx.x;
+    __shared__ double piv;
+    __shared__ int fail;
+    if (t == 0) fail = 0;
+    for (int i = t; i < dim; i += kSolveThreads) { H[(size_t)i * dim + i] += 1e-6; x[i] = -g[i]; }
+    __syncthreads();
+    for (int k = 0; k < dim; ++k) {
+        if (t == 0) {
+            const double d = H[(size_t)k * dim + k];
+            if (!(d > 0.0) || !isfinite(d)) fail = 1;
+            piv = sqrt(d);
+            H[(size_t)k * dim + k] = piv;
+        }
+        __syncthreads();
+        if (fail) break;
+        const double inv = 1.0 / piv;
+        for (int i = k + 1 + t; i < dim; i += kSolveThreads) H[(size_t)i * dim + k] *= inv;
+        __syncthreads();
+        // trailing update of the lower triangle, rows i > k, cols k < j <= i
+        const int m = dim - k - 1;
+        for (int idx = t; idx < m * m; idx += kSolveThreads) {
+            const int i = k + 1 + idx / m, j = k + 1 + idx % m;
+            if (j <= i) H[(size_t)i * dim + j] -= H[(size_t)i * dim + k] * H[(size_t)j * dim + k];
+        }
+        __syncthreads();
+    }
+    if (fail) {
+        if (t == 0) { info[2] = 1.0; info[3] = 1.0; }
+        return;
+    }
+    for (int k = 0; k < dim; ++k) {                         // L y = b
+        if (t == 0) x[k] = x[k] / H[(size_t)k * dim + k];
+        __syncthreads();
+        const double yk = x[k];
+        for (int i = k + 1 + t; i < dim; i += kSolveThreads) x[i] -= H[(size_t)i * dim + k] * yk;
+        __syncthreads();
+    }
+    for (int k = dim - 1; k >= 0; --k) {                    // L^T dx = y
+        if (t == 0) x[k] = x[k] / H[(size_t)k * dim + k];
+        __syncthreads();
+        const double xk = x[k];
+        for (int i = t; i < k; i += kSolveThreads) x[i] -= H[(size_t)k * dim + i] * xk;
+        __syncthreads();
+    }
+    __shared__ double nrm2;
+    if (t == 0) {
+        double s = 0.0;
+        for (int i = 0; i < dim; ++i) s += x[i] * x[i];
+        nrm2 = s;
+    }
+    __syncthreads();
+    const double dn = sqrt(nrm2);
+    if (t == 0) info[1] = dn;
+    if (dn < (double)delta_thresh) {                        // stop BEFORE the update (gauss_newton.py:262-265)
+        if (t == 0) info[2] = 1.0;
+        return;
+    }
+    if (!apply) return;
+    for (int kf = t; kf < K; kf += kSolveThreads) {
+        const int l = local[kf];
+        if (l < 0) continue;
+        store_pose(Twc + 8 * kf, retract_ops(x + 7 * l, load_pose<double>(Twc + 8 * kf)));
+    }
+    if (t == 0) info[0] += 1.0;
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_gn_retract(float *__restrict__ Twc, const double *__restrict__ dx, const int32_t *__restrict__ local, int K) {
+    const int kf = blockIdx.x * kThreads + threadIdx.x;
+    if (kf >= K) return;
+    const int l = local[kf];
+    if (l < 0) return;
+    store_pose(Twc + 8 * kf, retract_ops(dx + 7 * l, load_pose<double>(Twc + 8 * kf)));
+}
+
+__global__ void k_gn_info_init(double *info) {
+    if (threadIdx.x < 4) info[threadIdx.x] = 0.0;
+}
+
+int launch_blocks(const float *Twc, const float *Xs, const float *Cs, const int32_t *ii, const int32_t *jj,
+                  const int32_t *idx, const uint8_t *valid, const float *Q, double *blocks, double *ws,
+                  const double *done, int K, int P, int E, float sigma_ray, float C_thresh, float Q_thresh,
+                  hipStream_t st) {
+    const int chunks = gn_chunks(P);
+    const float inv_sigma = (float)(1.0 / (double)sigma_ray);
+    hipLaunchKernelGGL(k_gn_blocks, dim3(chunks, E), dim3(kThreads), 0, st, Twc, Xs, Cs, ii, jj, idx, valid, Q,
+                       ws, done, K, P, chunks, inv_sigma, C_thresh, Q_thresh);
+    hipLaunchKernelGGL(k_gn_reduce, dim3(E), dim3(64), 0, st, (const double *)ws, blocks, done, chunks);
+    M3_CHECK_LAUNCH("m3_gn_rays_blocks");
+    return M3_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int m3_gn_rays_chunks(int P) { return gn_chunks(P); }
+int m3_gn_rays_max_dim(void) { return kMaxDim; }
+
+int m3_gn_rays_blocks(const float *Twc, const float *Xs, const float *Cs, const int32_t *ii, const int32_t *jj,
+                      const int32_t *idx, const uint8_t *valid, const float *Q, double *blocks, double *ws,
+                      int K, int P, int E, float sigma_ray, float C_thresh, float Q_thresh, void *stream) {
+    M3_REQUIRE(Twc && Xs && Cs && ii && jj && idx && valid && Q && blocks && ws);
+    M3_REQUIRE(K > 0 && P > 0 && E > 0 && E <= 65535 && sigma_ray > 0.f);
+    return launch_blocks(Twc, Xs, Cs, ii, jj, idx, valid, Q, blocks, ws, nullptr, K, P, E, sigma_ray, C_thresh,
+                         Q_thresh, (hipStream_t)stream);
+}
+
+int m3_gn_rays_assemble(const double *blocks, const int32_t *ii, const int32_t *jj, const int32_t *local,
+                        double *H, double *g, int K, int E, int num_free, void *stream) {
+    M3_REQUIRE(blocks && ii && jj && local && H && g && K > 0 && E > 0 && num_free > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int dim = 7 * num_free;
+    M3_CHECK_HIP(hipMemsetAsync(H, 0, sizeof(double) * (size_t)dim * dim, st), "m3_gn_rays_assemble/memset");
+    M3_CHECK_HIP(hipMemsetAsync(g, 0, sizeof(double) * dim, st), "m3_gn_rays_assemble/memset");
+    hipLaunchKernelGGL(k_gn_assemble, dim3(E), dim3(64), 0, st, blocks, ii, jj, local, H, g,
+                       (const double *)nullptr, K, dim);
+    M3_CHECK_LAUNCH("m3_gn_rays_assemble");
+    return M3_OK;
+}
+
+int m3_gn_rays_retract(float *Twc, const double *dx, const int32_t *local, int K, void *stream) {
+    M3_REQUIRE(Twc && dx && local && K > 0);
+    hipLaunchKernelGGL(k_gn_retract, dim3(m3_cdiv(K, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, Twc, dx,
+                       local, K);
+    M3_CHECK_LAUNCH("m3_gn_rays_retract");
+    return M3_OK;
+}
+
+int m3_gn_rays_solve(float *Twc, const float *Xs, const float *Cs, const int32_t *ii, const int32_t *jj,
+                     const int32_t *idx, const uint8_t *valid, const float *Q, const int32_t *local,
+                     double *blocks, double *ws, double *Hbuf, double *info, int K, int P, int E, int num_free,
+                     float sigma_ray, float C_thresh, float Q_thresh, int max_iter, float delta_thresh,
+                     void *stream) {
+    M3_REQUIRE(Twc && Xs && Cs && ii && jj && idx && valid && Q && local && blocks && ws && Hbuf && info);
+    M3_REQUIRE(K > 0 && P > 0 && E > 0 && E <= 65535 && num_free > 0 && max_iter >= 0 && sigma_ray > 0.f);
+    const int dim = 7 * num_free;
+    if (dim > kMaxDim) return M3_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    double *H = Hbuf, *g = Hbuf + (size_t)dim * dim, *x = g + dim;
+    const double *done = info + 2;
+    hipLaunchKernelGGL(k_gn_info_init, dim3(1), dim3(64), 0, st, info);
+    const int64_t count = (int64_t)dim * dim + dim;
+    for (int it = 0; it < max_iter; ++it) {
+        int rc = launch_blocks(Twc, Xs, Cs, ii, jj, idx, valid, Q, blocks, ws, done, K, P, E, sigma_ray, C_thresh,
+                               Q_thresh, st);
+        if (rc != M3_OK) return rc;
+        hipLaunchKernelGGL(k_gn_zero, dim3(m3_cdiv(count, kThreads) > 1024 ? 1024 : m3_cdiv(count, kThreads)),
+                           dim3(kThreads), 0, st, Hbuf, done, count);
+        hipLaunchKernelGGL(k_gn_assemble, dim3(E), dim3(64), 0, st, (const double *)blocks, ii, jj, local, H, g,
+                           done, K, dim);
+        hipLaunchKernelGGL(k_gn_step, dim3(1), dim3(kSolveThreads), 0, st, H, g, x, Twc, local, info, K, dim,
+                           delta_thresh, 1);
+        M3_CHECK_LAUNCH("m3_gn_rays_solve/iter");
+    }
+    return M3_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,403 @@
+// Dense matching stage for gfx950: prep_for_iter_proj, iter_proj, refine_matches,
+// match epilogue, match_simple.   HBM/L2-gather bound integer+fp32 work: one
+// thread per point, coalesced streaming of the per-point arrays, gathers served
+// from L2 / Infinity Cache (the 9-channel ray image is 9.4 MB, the descriptor
+// image 25 MB at 512x512 - both far below the 256 MiB Infinity Cache).
+//
+// BUILD WITH -ffp-contract=off: the arithmetic below is written so that every
+// float32/float64 operation is individually rounded in exactly the order the
+// CPU oracle (oracle/matching.py) uses; parity on p / valid / idx is bit-exact.
+//
+// Reference semantics (paths under /root/reference/src/mlx_mast3r_slam):
+//   prep        matching.py:121-175, image.py:9-34
+//   iter_proj   backends/mpsgraph/kernels.py:151-254 (numpy twin)
+//   refine      backends/mpsgraph/kernels.py:496-537 (numpy twin)
+//   epilogue    matching.py:436-461 ; match_simple matching.py:41-90
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// ---------------------------------------------------------------- prep
+__device__ __forceinline__ void unit_ray(const float *__restrict__ X, float &rx, float &ry, float &rz) {
+    float x = X[0], y = X[1], z = X[2];
+    float n2 = (x * x + y * y) + z * z;
+    float nrm = sqrtf(n2 + 1e-10f);
+    rx = x / nrm; ry = y / nrm; rz = z / nrm;
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_prep(const float *__restrict__ X11, const float *__restrict__ X21, const int64_t *__restrict__ idx_init,
+       float *__restrict__ rwg, float *__restrict__ tgt, float *__restrict__ p_init, int H, int W) {
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * kThreads + threadIdx.x;
+    const int N = H * W;
+    if (n >= N) return;
+    const int y = n / W, x = n - y * W;
+    const size_t pix = (size_t)b * N + n;
+    const float *base = X11 + (size_t)b * N * 3;
+    float r0, r1, r2;
+    unit_ray(base + (size_t)n * 3, r0, r1, r2);
+    float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f, gy0 = 0.f, gy1 = 0.f, gy2 = 0.f;
+    if (x >= 1 && x <= W - 2) {
+        float a0, a1, a2, c0, c1, c2;
+        unit_ray(base + (size_t)(n + 1) * 3, a0, a1, a2);
+        unit_ray(base + (size_t)(n - 1) * 3, c0, c1, c2);
+        gx0 = (a0 - c0) / 2.0f; gx1 = (a1 - c1) / 2.0f; gx2 = (a2 - c2) / 2.0f;
+    }
+    if (y >= 1 && y <= H - 2) {
+        float a0, a1, a2, c0, c1, c2;
+        unit_ray(base + (size_t)(n + W) * 3, a0, a1, a2);
+        unit_ray(base + (size_t)(n - W) * 3, c0, c1, c2);
+        gy0 = (a0 - c0) / 2.0f; gy1 = (a1 - c1) / 2.0f; gy2 = (a2 - c2) / 2.0f;
+    }
+    float *o = rwg + pix * 9;
+    o[0] = r0; o[1] = r1; o[2] = r2;
+    o[3] = gx0; o[4] = gx1; o[5] = gx2;
+    o[6] = gy0; o[7] = gy1; o[8] = gy2;
+    float t0, t1, t2;
+    unit_ray(X21 + pix * 3, t0, t1, t2);
+    float *t = tgt + pix * 3;
+    t[0] = t0; t[1] = t1; t[2] = t2;
+    int64_t id = idx_init ? idx_init[pix] : (int64_t)n;
+    // python semantics of % and // for (possibly negative) indices
+    int64_t v = id / W, u = id - v * W;
+    if (u < 0) { u += W; v -= 1; }
+    p_init[pix * 2 + 0] = (float)u;
+    p_init[pix * 2 + 1] = (float)v;
+}
+
+// ---------------------------------------------------------------- iter_proj
+__device__ __forceinline__ float clipf(float v, float hi) {
+    v = (v < 0.0f) ? 0.0f : v;     // NaN stays NaN, like np.clip
+    v = (v > hi) ? hi : v;
+    return v;
+}
+__device__ __forceinline__ float dot3(float a0, float a1, float a2, float b0, float b1, float b2) {
+    return (a0 * b0 + a1 * b1) + a2 * b2;
+}
+
+// FIRST = true : run max_iter LM steps, record per-iteration max step norm (as uint bits).
+// FIRST = false: re-run with the per-batch iteration limit found by k_iter_limit; blocks
+//                whose limit == max_iter have nothing to redo and exit immediately.
+template <bool FIRST>
+__global__ void __launch_bounds__(kThreads)
+k_iter_proj(const float *__restrict__ rwg, const float *__restrict__ tgt, const float *__restrict__ p_init,
+            float *__restrict__ p_out, uint8_t *__restrict__ valid_out, uint32_t *__restrict__ stepmax,
+            const uint32_t *__restrict__ limit, int H, int W, int N, int max_iter, float lam,
+            float xhi, float yhi) {
+    const int b = blockIdx.y;
+    int n_iter = max_iter;
+    if (!FIRST) {
+        n_iter = (int)limit[b];
+        if (n_iter >= max_iter) return;
+    }
+    const int n = blockIdx.x * kThreads + threadIdx.x;
+    const bool live = n < N;
+    const size_t pt = (size_t)b * N + (live ? n : 0);
+    const float *img = rwg + (size_t)b * H * W * 9;
+    float px = p_init[pt * 2 + 0], py = p_init[pt * 2 + 1];
+    const float t0 = tgt[pt * 3 + 0], t1 = tgt[pt * 3 + 1], t2 = tgt[pt * 3 + 2];
+
+    for (int it = 0; it < n_iter; ++it) {
+        const float cx = clipf(px, xhi), cy = clipf(py, yhi);
+        int x0 = (int)floorf(cx), y0 = (int)floorf(cy);
+        x0 = min(max(x0, 0), W - 1); y0 = min(max(y0, 0), H - 1);   // only matters for NaN input
+        const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+        const double fx = (double)cx - (double)x0, fy = (double)cy - (double)y0;
+        const double w00 = (1.0 - fx) * (1.0 - fy), w01 = (1.0 - fx) * fy;
+        const double w10 = fx * (1.0 - fy), w11 = fx * fy;
+        const float *q00 = img + ((size_t)y0 * W + x0) * 9;
+        const float *q01 = img + ((size_t)y1 * W + x0) * 9;
+        const float *q10 = img + ((size_t)y0 * W + x1) * 9;
+        const float *q11 = img + ((size_t)y1 * W + x1) * 9;
+        float s[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            double v = ((w00 * (double)q00[c] + w01 * (double)q01[c]) + w10 * (double)q10[c])
+                       + w11 * (double)q11[c];
+            s[c] = (float)v;
+        }
+        const float r0 = s[0] - t0, r1 = s[1] - t1, r2 = s[2] - t2;
+        const float a = dot3(s[3], s[4], s[5], s[3], s[4], s[5]) + lam;
+        const float bb = dot3(s[3], s[4], s[5], s[6], s[7], s[8]);
+        const float c = dot3(s[6], s[7], s[8], s[3], s[4], s[5]);
+        const float d = dot3(s[6], s[7], s[8], s[6], s[7], s[8]) + lam;
+        const float j0 = dot3(s[3], s[4], s[5], r0, r1, r2);
+        const float j1 = dot3(s[6], s[7], s[8], r0, r1, r2);
+        float det = a * d - bb * c;
+        det = (det < 1e-10f) ? 1e-10f : det;
+        const float inv_det = 1.0f / det;
+        const float dx = -(d * j0 - bb * j1) * inv_det;
+        const float dy = -((-c) * j0 + a * j1) * inv_det;
+        px = px + dx;
+        py = py + dy;
+        if (FIRST) {
+            const float dn = sqrtf(dx * dx + dy * dy);
+            unsigned bits = live ? (__float_as_uint(dn) & 0x7fffffffu) : 0u;
+            bits = m3_wave_max(bits);
+            if ((threadIdx.x & 63) == 0) atomicMax(&stepmax[b * max_iter + it], bits);
+        }
+    }
+    if (live) {
+        p_out[pt * 2 + 0] = clipf(px, (float)(W - 1));
+        p_out[pt * 2 + 1] = clipf(py, (float)(H - 1));
+        valid_out[pt] = (px >= 0.0f) && (px < (float)W) && (py >= 0.0f) && (py < (float)H);
+    }
+}
+
+// one thread: first LM iteration whose max step norm is < thresh -> iterations to run
+__global__ void k_iter_limit(const uint32_t *__restrict__ stepmax, uint32_t *__restrict__ limit, int B,
+                             int max_iter, float thresh, int per_batch) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (per_batch) {
+        for (int b = 0; b < B; ++b) {
+            int lim = max_iter;
+            for (int it = 0; it < max_iter; ++it)
+                if (__uint_as_float(stepmax[b * max_iter + it]) < thresh) { lim = it + 1; break; }
+            limit[b] = (uint32_t)lim;
+        }
+    } else {
+        int lim = max_iter;
+        for (int it = 0; it < max_iter; ++it) {
+            unsigned m = 0;
+            for (int b = 0; b < B; ++b) m = max(m, stepmax[b * max_iter + it]);
+            if (__uint_as_float(m) < thresh) { lim = it + 1; break; }
+        }
+        for (int b = 0; b < B; ++b) limit[b] = (uint32_t)lim;
+    }
+}
+
+// ---------------------------------------------------------------- refine_matches
+// score = sequential sum_d (q[d]*r[d]) (mul, then add; contraction is off), strict '>' in
+// (dy outer, dx inner) raster order, out-of-bounds candidates skipped.
+template <int D>
+__device__ __forceinline__ void refine_pass(const float *__restrict__ img, const float *q, int H, int W,
+                                            int radius, int dil, int cx, int cy, int &bx, int &by) {
+    float best = -INFINITY;
+    bx = cx; by = cy;
+    for (int dy = -radius; dy <= radius; ++dy) {
+        const int ny = cy + dy * dil;
+        if (ny < 0 || ny >= H) continue;
+        for (int dx = -radius; dx <= radius; ++dx) {
+            const int nx = cx + dx * dil;
+            if (nx < 0 || nx >= W) continue;
+            const float4 *r4 = reinterpret_cast<const float4 *>(img + ((size_t)ny * W + nx) * D);
+            float score = 0.0f;
+#pragma unroll
+            for (int k = 0; k < D / 4; ++k) {
+                const float4 v = r4[k];
+                score = score + q[4 * k + 0] * v.x;
+                score = score + q[4 * k + 1] * v.y;
+                score = score + q[4 * k + 2] * v.z;
+                score = score + q[4 * k + 3] * v.w;
+            }
+            if (score > best) { best = score; bx = nx; by = ny; }
+        }
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(kThreads)
+k_refine(const float *__restrict__ D11, const float *__restrict__ D21, const int32_t *__restrict__ p_in,
+         int32_t *__restrict__ p_out, int H, int W, int N, int radius, int dil_max, int chained) {
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * kThreads + threadIdx.x;
+    if (n >= N) return;
+    const size_t pt = (size_t)b * N + n;
+    const float *img = D11 + (size_t)b * H * W * D;
+    float q[D];
+    const float4 *q4 = reinterpret_cast<const float4 *>(D21 + pt * D);
+#pragma unroll
+    for (int k = 0; k < D / 4; ++k) {
+        const float4 v = q4[k];
+        q[4 * k] = v.x; q[4 * k + 1] = v.y; q[4 * k + 2] = v.z; q[4 * k + 3] = v.w;
+    }
+    int cx = p_in[pt * 2 + 0], cy = p_in[pt * 2 + 1];
+    int bx = cx, by = cy;
+    if (chained) {
+        for (int dil = dil_max; dil >= 1; --dil) {
+            refine_pass<D>(img, q, H, W, radius, dil, cx, cy, bx, by);
+            cx = bx; cy = by;
+        }
+    } else {
+        refine_pass<D>(img, q, H, W, radius, 1, cx, cy, bx, by);
+    }
+    p_out[pt * 2 + 0] = bx;
+    p_out[pt * 2 + 1] = by;
+}
+
+// generic descriptor length (any D >= 1): query re-read from global (L1-resident)
+__global__ void __launch_bounds__(kThreads)
+k_refine_generic(const float *__restrict__ D11, const float *__restrict__ D21,
+                 const int32_t *__restrict__ p_in, int32_t *__restrict__ p_out, int H, int W, int D, int N,
+                 int radius, int dil_max, int chained) {
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * kThreads + threadIdx.x;
+    if (n >= N) return;
+    const size_t pt = (size_t)b * N + n;
+    const float *img = D11 + (size_t)b * H * W * D;
+    const float *q = D21 + pt * D;
+    int cx = p_in[pt * 2 + 0], cy = p_in[pt * 2 + 1];
+    int bx = cx, by = cy;
+    const int first = chained ? dil_max : 1;
+    for (int dil = first; dil >= 1; --dil) {
+        float best = -INFINITY;
+        bx = cx; by = cy;
+        for (int dy = -radius; dy <= radius; ++dy) {
+            const int ny = cy + dy * dil;
+            if (ny < 0 || ny >= H) continue;
+            for (int dx = -radius; dx <= radius; ++dx) {
+                const int nx = cx + dx * dil;
+                if (nx < 0 || nx >= W) continue;
+                const float *r = img + ((size_t)ny * W + nx) * D;
+                float score = 0.0f;
+                for (int k = 0; k < D; ++k) score = score + q[k] * r[k];
+                if (score > best) { best = score; bx = nx; by = ny; }
+            }
+        }
+        cx = bx; cy = by;
+    }
+    p_out[pt * 2 + 0] = bx;
+    p_out[pt * 2 + 1] = by;
+}
+
+// ---------------------------------------------------------------- epilogue / simple
+__global__ void __launch_bounds__(kThreads)
+k_epilogue(const float *__restrict__ X11, const float *__restrict__ X21, const int32_t *__restrict__ p_i32,
+           const float *__restrict__ p_f32, const uint8_t *__restrict__ valid_proj,
+           int64_t *__restrict__ idx_out, uint8_t *__restrict__ valid_out, int H, int W, float thresh) {
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * kThreads + threadIdx.x;
+    const int N = H * W;
+    if (n >= N) return;
+    const size_t pt = (size_t)b * N + n;
+    int u, v;
+    if (p_i32) { u = p_i32[pt * 2]; v = p_i32[pt * 2 + 1]; }
+    else { u = (int)p_f32[pt * 2]; v = (int)p_f32[pt * 2 + 1]; }
+    const int xc = min(max(u, 0), W - 1), yc = min(max(v, 0), H - 1);
+    const float *a = X11 + ((size_t)b * N + (size_t)yc * W + xc) * 3;
+    const float *c = X21 + pt * 3;
+    const float d0 = a[0] - c[0], d1 = a[1] - c[1], d2 = a[2] - c[2];
+    const float dist = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
+    valid_out[pt] = (valid_proj[pt] != 0) && (dist < thresh);
+    idx_out[pt] = (int64_t)u + (int64_t)W * (int64_t)v;
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_match_simple(const float *__restrict__ X11, const float *__restrict__ X21,
+               const int64_t *__restrict__ idx_init, int64_t *__restrict__ idx_out,
+               uint8_t *__restrict__ valid_out, int N, float thresh) {
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * kThreads + threadIdx.x;
+    if (n >= N) return;
+    const size_t pt = (size_t)b * N + n;
+    int64_t id = idx_init ? idx_init[pt] : (int64_t)n;
+    idx_out[pt] = id;
+    if (id < 0) id += N;                       // numpy/mlx negative indexing
+    id = id < 0 ? 0 : (id >= N ? N - 1 : id);  // never fault on bad input
+    const float *a = X11 + ((size_t)b * N + (size_t)id) * 3;
+    const float *c = X21 + pt * 3;
+    const float d0 = a[0] - c[0], d1 = a[1] - c[1], d2 = a[2] - c[2];
+    valid_out[pt] = sqrtf((d0 * d0 + d1 * d1) + d2 * d2) < thresh;
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_trunc(const float *__restrict__ p, int32_t *__restrict__ out, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i < count) out[i] = (int32_t)p[i];
+}
+
+}  // namespace
+
+// ================================================================== C ABI
+extern "C" {
+
+int m3_prep_iter_proj(const float *X11, const float *X21, const int64_t *idx_init, float *rwg,
+                      float *tgt, float *p_init, int B, int H, int W, void *stream) {
+    M3_REQUIRE(X11 && X21 && rwg && tgt && p_init);
+    M3_REQUIRE(B > 0 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 31) && B <= 65535);
+    dim3 grid(m3_cdiv((int64_t)H * W, kThreads), B);
+    hipLaunchKernelGGL(k_prep, grid, dim3(kThreads), 0, (hipStream_t)stream, X11, X21, idx_init, rwg, tgt,
+                       p_init, H, W);
+    M3_CHECK_LAUNCH("m3_prep_iter_proj");
+    return M3_OK;
+}
+
+int m3_iter_proj(const float *rwg, const float *tgt, const float *p_init, float *p_out,
+                 uint8_t *valid_out, uint32_t *ws, int B, int H, int W, int N, int max_iter,
+                 float lambda_init, float convergence_thresh, int stop_scope, void *stream) {
+    M3_REQUIRE(rwg && tgt && p_init && p_out && valid_out && ws);
+    M3_REQUIRE(B > 0 && H > 0 && W > 0 && N > 0 && max_iter >= 0 && B <= 65535);
+    M3_REQUIRE((int64_t)H * W < (1ll << 31) && (stop_scope == 0 || stop_scope == 1));
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t *stepmax = ws, *limit = ws + (size_t)B * max_iter;
+    M3_CHECK_HIP(hipMemsetAsync(ws, 0, sizeof(uint32_t) * ((size_t)B * max_iter + B), st), "m3_iter_proj/memset");
+    const float xhi = (float)((double)W - 1.001), yhi = (float)((double)H - 1.001);
+    dim3 grid(m3_cdiv(N, kThreads), B);
+    hipLaunchKernelGGL(k_iter_proj<true>, grid, dim3(kThreads), 0, st, rwg, tgt, p_init, p_out, valid_out,
+                       stepmax, (const uint32_t *)limit, H, W, N, max_iter, lambda_init, xhi, yhi);
+    M3_CHECK_LAUNCH("m3_iter_proj/pass1");
+    if (max_iter > 1) {
+        hipLaunchKernelGGL(k_iter_limit, dim3(1), dim3(64), 0, st, (const uint32_t *)stepmax, limit, B,
+                           max_iter, convergence_thresh, stop_scope);
+        M3_CHECK_LAUNCH("m3_iter_proj/limit");
+        hipLaunchKernelGGL(k_iter_proj<false>, grid, dim3(kThreads), 0, st, rwg, tgt, p_init, p_out,
+                           valid_out, stepmax, (const uint32_t *)limit, H, W, N, max_iter, lambda_init, xhi, yhi);
+        M3_CHECK_LAUNCH("m3_iter_proj/pass2");
+    }
+    return M3_OK;
+}
+
+int m3_refine_matches(const float *D11, const float *D21, const int32_t *p_in, int32_t *p_out, int B,
+                      int H, int W, int D, int N, int radius, int dilation_max, int chained, void *stream) {
+    M3_REQUIRE(D11 && D21 && p_in && p_out && p_in != p_out);
+    M3_REQUIRE(B > 0 && H > 0 && W > 0 && D > 0 && N > 0 && radius >= 0 && B <= 65535);
+    M3_REQUIRE((int64_t)H * W < (1ll << 31));
+    hipStream_t st = (hipStream_t)stream;
+    const int dmax = dilation_max < 1 ? 1 : dilation_max;
+    dim3 grid(m3_cdiv(N, kThreads), B), blk(kThreads);
+    const bool aligned = (((uintptr_t)D11 | (uintptr_t)D21) & 15) == 0;
+#define M3_REFINE(DD) hipLaunchKernelGGL(k_refine<DD>, grid, blk, 0, st, D11, D21, p_in, p_out, H, W, N, radius, dmax, chained)
+    if (aligned && D == 24) M3_REFINE(24);
+    else if (aligned && D == 16) M3_REFINE(16);
+    else if (aligned && D == 32) M3_REFINE(32);
+    else if (aligned && D == 64) M3_REFINE(64);
+    else hipLaunchKernelGGL(k_refine_generic, grid, blk, 0, st, D11, D21, p_in, p_out, H, W, D, N, radius, dmax, chained);
+#undef M3_REFINE
+    M3_CHECK_LAUNCH("m3_refine_matches");
+    return M3_OK;
+}
+
+int m3_match_epilogue(const float *X11, const float *X21, const int32_t *p_i32, const float *p_f32,
+                      const uint8_t *valid_proj, int64_t *idx_out, uint8_t *valid_out, int B, int H, int W,
+                      float dist_thresh, void *stream) {
+    M3_REQUIRE(X11 && X21 && (p_i32 || p_f32) && valid_proj && idx_out && valid_out);
+    M3_REQUIRE(B > 0 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 31) && B <= 65535);
+    dim3 grid(m3_cdiv((int64_t)H * W, kThreads), B);
+    hipLaunchKernelGGL(k_epilogue, grid, dim3(kThreads), 0, (hipStream_t)stream, X11, X21, p_i32, p_f32,
+                       valid_proj, idx_out, valid_out, H, W, dist_thresh);
+    M3_CHECK_LAUNCH("m3_match_epilogue");
+    return M3_OK;
+}
+
+int m3_match_simple(const float *X11, const float *X21, const int64_t *idx_init, int64_t *idx_out,
+                    uint8_t *valid_out, int B, int H, int W, float dist_thresh, void *stream) {
+    M3_REQUIRE(X11 && X21 && idx_out && valid_out);
+    M3_REQUIRE(B > 0 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 31) && B <= 65535);
+    dim3 grid(m3_cdiv((int64_t)H * W, kThreads), B);
+    hipLaunchKernelGGL(k_match_simple, grid, dim3(kThreads), 0, (hipStream_t)stream, X11, X21, idx_init,
+                       idx_out, valid_out, H * W, dist_thresh);
+    M3_CHECK_LAUNCH("m3_match_simple");
+    return M3_OK;
+}
+
+int m3_trunc_i32(const float *p, int32_t *out, int64_t count, void *stream) {
+    M3_REQUIRE(p && out && count > 0);
+    hipLaunchKernelGGL(k_trunc, dim3(m3_cdiv(count, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, p, out, count);
+    M3_CHECK_LAUNCH("m3_trunc_i32");
+    return M3_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+"""ctypes binding of libm3slam_hip.so (the C ABI declared in include/m3slam.h).
+
+The library is the product: there is NO fallback.  If it is missing or a call
+returns a non-zero status a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libm3slam_hip.so")
+HEADERS = [os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", h)
+           for h in ("m3slam.h", "m3slam_model.h")]
+
+_lib = None
+
+_CT = {
+    "int": C.c_int, "float": C.c_float, "int64_t": C.c_int64, "double": C.c_double,
+    "void": None,
+}
+
+
+def declared_symbols() -> list[str]:
+    """Every function name declared in include/*.h (used by the CPU export test)."""
+    names = []
+    for h in HEADERS:
+        if not os.path.exists(h):
+            continue
+        txt = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names += re.findall(r"\b(m3_[a-z0-9_]+)\s*\(", txt)
+    return sorted(set(names))
+
+
+def _parse_prototypes():
+    protos = {}
+    for h in HEADERS:
+        if not os.path.exists(h):
+            continue
+        txt = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        for m in re.finditer(r"(const char \*|int64_t|int|void)\s*(m3_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", txt):
+            ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+            argt = []
+            if args and args != "void":
+                for a in args.split(","):
+                    a = a.strip()
+                    if "*" in a:
+                        argt.append(C.c_void_p)
+                    else:
+                        base = a.replace("const ", "").split()[0]
+                        argt.append(_CT[base])
+            rt = C.c_char_p if ret.startswith("const char") else _CT[ret]
+            protos[name] = (rt, argt)
+    return protos
+
+
+def lib():
+    """Load (once) and return the shared library; raise if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python mast3r-slam_amd/build.py` "
+                "(the HIP library is the product path; there is no fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (rt, argt) in _parse_prototypes().items():
+            fn = getattr(L, name)
+            fn.restype = rt
+            fn.argtypes = argt
+        _lib = L
+    return _lib
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def check(t: torch.Tensor, dtype, name: str, shape=None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: must live on the ROCm device (got {t.device}); no CPU path exists")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if shape is not None:
+        if len(shape) != t.dim() or any(s is not None and s != d for s, d in zip(shape, t.shape)):
+            raise ValueError(f"{name}: expected shape {shape}, got {tuple(t.shape)}")
+    return t.contiguous()
+
+
+def call(name: str, *args):
+    """Call an int-returning entry point; non-zero status -> RuntimeError."""
+    L = lib()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        msg = L.m3_status_string(rc).decode()
+        herr = L.m3_last_hip_error().decode()
+        raise RuntimeError(f"{name} failed with status {rc}: {msg}" + (f" [{herr}]" if herr else ""))

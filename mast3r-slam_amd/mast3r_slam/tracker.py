@@ -1,0 +1,153 @@
+"""Frame-to-keyframe tracking on the MI355X.
+
+Mirror of /root/reference/src/mlx_mast3r_slam/tracker.py: FrameTracker.track :51-175,
+_get_points_poses :177-214, _solve :216-256, _opt_pose_ray_dist_sim3 :258-324.  The
+Gauss-Newton loop (residuals, Huber, J^T J / J^T r reduction, 7x7 solve, Sim3 retraction,
+stop test) runs entirely on the device through m3_track_gn_ray_dist; the host sees one
+stream-ordered call and no per-iteration sync.
+
+Poses are torch float32 tensors [8] or [1,8] = [t, q(xyzw), s] (Sim3.data layout,
+liegroups/sim3.py:13).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _ffi
+from .config import get_config
+
+
+def _pose(T, name):
+    T = _ffi.check(T.reshape(-1), torch.float32, name, (8,))
+    return T
+
+
+def track_gather(Xf_canon, Cf_avg, Ck_avg, Qff, Qkf, idx_f2k, valid_match, C_conf=0.0, Q_conf=1.5):
+    """tracker.py:88-113 + :214 fused: returns (Xf[idx] [N,3], Qk [N], valid_opt [N] u8,
+    valid_kf [N] u8, counts int32[2] = (#valid_opt, #valid_kf))."""
+    n = idx_f2k.numel()
+    Xf_canon = _ffi.check(Xf_canon.reshape(-1, 3), torch.float32, "Xf_canon", (n, 3))
+    Cf_avg = _ffi.check(Cf_avg.reshape(-1), torch.float32, "Cf", (n,))
+    Ck_avg = _ffi.check(Ck_avg.reshape(-1), torch.float32, "Ck", (n,))
+    Qff = _ffi.check(Qff.reshape(-1), torch.float32, "Qff", (n,))
+    Qkf = _ffi.check(Qkf.reshape(-1), torch.float32, "Qkf", (n,))
+    idx = _ffi.check(idx_f2k.reshape(-1).to(torch.int64), torch.int64, "idx_f2k", (n,))
+    vm = _ffi.check(valid_match.reshape(-1).to(torch.uint8), torch.uint8, "valid_match", (n,))
+    dev = Xf_canon.device
+    Xf = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    Qk = torch.empty(n, dtype=torch.float32, device=dev)
+    vo = torch.empty(n, dtype=torch.uint8, device=dev)
+    vk = torch.empty(n, dtype=torch.uint8, device=dev)
+    counts = torch.empty(2, dtype=torch.int32, device=dev)
+    _ffi.call("m3_track_gather", _ffi.ptr(Xf_canon), _ffi.ptr(Cf_avg), _ffi.ptr(Ck_avg), _ffi.ptr(Qff),
+              _ffi.ptr(Qkf), _ffi.ptr(idx), _ffi.ptr(vm), _ffi.ptr(Xf), _ffi.ptr(Qk), _ffi.ptr(vo), _ffi.ptr(vk),
+              _ffi.ptr(counts), n, float(C_conf), float(Q_conf), _ffi.stream_ptr())
+    return Xf, Qk, vo, vk, counts
+
+
+def _ws(dev):
+    return torch.empty(int(_ffi.lib().m3_track_ws_doubles()), dtype=torch.float64, device=dev)
+
+
+def opt_pose_ray_dist_sim3(Xf, Xk, T_WCf, T_WCk, Qk, valid, cfg=None, fixed_iters: bool = False):
+    """tracker.py:258-324.  Xf [N,3] (gathered at idx_f2k), Xk [N,3], Qk [N(,1)], valid [N(,1)].
+    Returns (T_WCf [8], T_CkCf [8], info float64[4] = iterations, cost, |tau|, converged)."""
+    c = dict(get_config()["tracking"])
+    c.update(cfg or {})
+    Xf = _ffi.check(Xf.reshape(-1, 3), torch.float32, "Xf")
+    n = Xf.shape[0]
+    Xk = _ffi.check(Xk.reshape(-1, 3), torch.float32, "Xk", (n, 3))
+    Qk = _ffi.check(Qk.reshape(-1), torch.float32, "Qk", (n,))
+    v = _ffi.check(valid.reshape(-1).to(torch.uint8), torch.uint8, "valid", (n,))
+    Tf, Tk = _pose(T_WCf, "T_WCf"), _pose(T_WCk, "T_WCk")
+    dev = Xf.device
+    out_f = torch.empty(8, dtype=torch.float32, device=dev)
+    out_rel = torch.empty(8, dtype=torch.float32, device=dev)
+    info = torch.empty(4, dtype=torch.float64, device=dev)
+    ws = _ws(dev)
+    _ffi.call("m3_track_gn_ray_dist", _ffi.ptr(Xf), _ffi.ptr(Xk), _ffi.ptr(Qk), _ffi.ptr(v), _ffi.ptr(Tf),
+              _ffi.ptr(Tk), _ffi.ptr(out_f), _ffi.ptr(out_rel), _ffi.ptr(info), _ffi.ptr(ws), n,
+              int(c["max_iters"]), float(c["huber"]), float(c["sigma_ray"]), float(c["sigma_dist"]),
+              float(c["rel_error"]), float(c["delta_norm"]), 1 if fixed_iters else 0, _ffi.stream_ptr())
+    return out_f, out_rel, info
+
+
+def normal_equations(Xf, Xk, T_CkCf, Qk, valid, cfg=None):
+    """The J^T W J / J^T W r reduction of tracker.py:239-244 at pose T_CkCf.
+    Returns (H [7,7] float64, g [7] float64, cost float64 scalar tensor)."""
+    c = dict(get_config()["tracking"])
+    c.update(cfg or {})
+    Xf = _ffi.check(Xf.reshape(-1, 3), torch.float32, "Xf")
+    n = Xf.shape[0]
+    Xk = _ffi.check(Xk.reshape(-1, 3), torch.float32, "Xk", (n, 3))
+    Qk = _ffi.check(Qk.reshape(-1), torch.float32, "Qk", (n,))
+    v = _ffi.check(valid.reshape(-1).to(torch.uint8), torch.uint8, "valid", (n,))
+    T = _pose(T_CkCf, "T_CkCf")
+    dev = Xf.device
+    out = torch.empty(36, dtype=torch.float64, device=dev)
+    ws = _ws(dev)
+    _ffi.call("m3_track_normal_eq", _ffi.ptr(Xf), _ffi.ptr(Xk), _ffi.ptr(Qk), _ffi.ptr(v), _ffi.ptr(T),
+              _ffi.ptr(out), _ffi.ptr(ws), n, float(c["huber"]), float(c["sigma_ray"]), float(c["sigma_dist"]),
+              _ffi.stream_ptr())
+    iu = torch.triu_indices(7, 7, device=dev)
+    H = torch.zeros((7, 7), dtype=torch.float64, device=dev)
+    H[iu[0], iu[1]] = out[:28]
+    H = H + H.T - torch.diag(H.diagonal())
+    return H, out[28:35].clone(), out[35].clone()
+
+
+def sim3_act(T, X):
+    """Sim3.act (liegroups/sim3.py:222-231) over a point map: s R X + t."""
+    X = _ffi.check(X.reshape(-1, 3), torch.float32, "X")
+    T = _pose(T, "T")
+    out = torch.empty_like(X)
+    _ffi.call("m3_sim3_act", _ffi.ptr(T), _ffi.ptr(X), _ffi.ptr(out), X.shape[0], _ffi.stream_ptr())
+    return out
+
+
+class FrameTracker:
+    """tracker.py:21-175.  `keyframes` needs last_keyframe() and __len__/__setitem__; frames
+    need X_canon [N,3], get_average_conf() [N,1], T_WC [1,8] tensor, update_pointmap(X, C),
+    frame_id (see frame.py)."""
+
+    def __init__(self, model, keyframes) -> None:
+        self.model = model
+        self.keyframes = keyframes
+        self.cfg = get_config()["tracking"]
+        self.idx_f2k = None
+
+    def reset_idx_f2k(self) -> None:
+        self.idx_f2k = None
+
+    def track(self, frame, mast3r_match_fn):
+        """Returns (new_kf, match_info, try_reloc) as tracker.py:51-175."""
+        keyframe = self.keyframes.last_keyframe()
+        if keyframe is None:
+            return False, [], True
+        idx_f2k, valid_match_k, Xff, Cff, Qff, Xkf, Ckf, Qkf = mast3r_match_fn(
+            self.model, frame, keyframe, idx_i2j_init=self.idx_f2k)
+        self.idx_f2k = idx_f2k
+        idx = idx_f2k[0]
+        vm = valid_match_k[0].reshape(-1)
+        n = idx.numel()
+        frame.update_pointmap(Xff.reshape(n, 3), Cff.reshape(n, 1))
+        Xf, Qk, valid_opt, valid_kf, counts = track_gather(
+            frame.X_canon, frame.get_average_conf(), keyframe.get_average_conf(), Qff, Qkf, idx, vm,
+            self.cfg["C_conf"], self.cfg["Q_conf"])
+        cnt = counts.cpu()                       # the one host sync of the frame (match_frac gate, :116)
+        if float(cnt[0]) / n < self.cfg["min_match_frac"]:
+            print(f"Skipped frame {frame.frame_id}")
+            return False, [], True
+        T_WCf, T_CkCf, _ = opt_pose_ray_dist_sim3(Xf, keyframe.X_canon, frame.T_WC, keyframe.T_WC, Qk, valid_opt,
+                                                  self.cfg)
+        frame.T_WC = T_WCf.reshape(1, 8)
+        keyframe.update_pointmap(sim3_act(T_CkCf, Xkf.reshape(n, 3)), Ckf.reshape(n, 1))
+        self.keyframes[len(self.keyframes) - 1] = keyframe
+        match_frac_k = float(cnt[1]) / n
+        unique_frac_f = torch.unique(idx[vm.bool()]).numel() / n
+        new_kf = min(match_frac_k, unique_frac_f) < self.cfg["match_frac_thresh"]
+        if new_kf:
+            self.reset_idx_f2k()
+        match_info = [keyframe.X_canon, keyframe.get_average_conf(), frame.X_canon, frame.get_average_conf(),
+                      Qkf, Qff]
+        return new_kf, match_info, False

@@ -1,0 +1,139 @@
+"""Generate tests/golden/*.npz from the reference's importable numpy twins.
+
+Run ONLY in the build container (needs /root/reference):
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+The fixtures hold inputs + the reference's outputs (data, not source).  The GPU
+box never sees /root/reference; tests read only the committed .npz files.
+
+Reference entry points exercised (paths under /root/reference/src/mlx_mast3r_slam):
+  backends/mpsgraph/kernels.py      _iter_proj_numpy :151, _refine_matches_numpy :496
+  backends/mpsgraph/gauss_newton.py gauss_newton_rays :23
+  backends/mpsgraph/sim3_ops.py     quat_multiply, quat_rotate, sim3_relative, exp_so3,
+                                    exp_sim3, retract_sim3, huber_weight
+  backends/mpsgraph/linalg.py       cholesky_solve :17
+  /root/reference/benchmark_all_kernels.py create_gn_test_data :16 (input recipe)
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(REF, "src"))
+sys.path.insert(0, os.path.join(ROOT, "mast3r-slam_amd"))
+sys.path.insert(0, ROOT)
+
+from mlx_mast3r_slam.backends.mpsgraph import kernels as rk            # noqa: E402
+from mlx_mast3r_slam.backends.mpsgraph import gauss_newton as rgn     # noqa: E402
+from mlx_mast3r_slam.backends.mpsgraph import sim3_ops as rs          # noqa: E402
+from mlx_mast3r_slam.backends.mpsgraph import linalg as rl            # noqa: E402
+
+from mast3r_slam import synthetic                                      # noqa: E402
+from oracle import matching as om                                      # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _bench_module():
+    spec = importlib.util.spec_from_file_location("ref_bench", os.path.join(REF, "benchmark_all_kernels.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+
+    # ---- 1. iter_proj on a smooth two-view scene (B=1 and B=2) -------------
+    for tag, b, h, w in (("b1", 1, 48, 64), ("b2", 2, 40, 56)):
+        sc = synthetic.geometric_pair(h, w, seed=7, batch=b)
+        rays, tgt, p0 = om.prep_for_iter_proj(sc["X11"], sc["X21"], None)
+        p_ref, v_ref = rk._iter_proj_numpy(rays, tgt, p0, 10, 1e-8, 1e-6)
+        np.savez_compressed(os.path.join(OUT, f"iter_proj_{tag}.npz"),
+                            rays_with_grad=rays, pts3d_norm=tgt, p_init=p0,
+                            p_ref=p_ref.astype(np.float32), valid_ref=v_ref,
+                            max_iter=10, lambda_init=1e-8, convergence_thresh=1e-6)
+    # early-stop case: a sub-pixel warp that vanishes at the image border, so every point
+    # converges and the global max step norm really drops below the (large) threshold
+    h, w = 24, 32
+    vv, uu = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing="ij")
+    u1 = uu + 0.4 * np.sin(np.pi * uu / (w - 1)) * np.sin(np.pi * vv / (h - 1))
+    v1 = vv - 0.3 * np.sin(np.pi * uu / (w - 1)) * np.sin(np.pi * vv / (h - 1))
+    X11 = synthetic._surface(uu, vv, h, w)[None].astype(np.float32)
+    X21 = synthetic._surface(u1, v1, h, w)[None].astype(np.float32)
+    rays, tgt, p0 = om.prep_for_iter_proj(X11, X21, None)
+    p_ref, v_ref = rk._iter_proj_numpy(rays, tgt, p0, 10, 1e-8, 0.05)
+    np.savez_compressed(os.path.join(OUT, "iter_proj_earlystop.npz"),
+                        rays_with_grad=rays, pts3d_norm=tgt, p_init=p0,
+                        p_ref=p_ref.astype(np.float32), valid_ref=v_ref,
+                        max_iter=10, lambda_init=1e-8, convergence_thresh=0.05)
+
+    # ---- 2. refine_matches ---------------------------------------------------
+    sc = synthetic.geometric_pair(48, 64, seed=11, batch=1)
+    rng = np.random.default_rng(5)
+    n = 48 * 64
+    p1 = np.rint(sc["uv_true"] + rng.normal(0, 1.5, size=(1, n, 2))).astype(np.int32)
+    p1[0, :40, 0] = rng.integers(-3, 3, 40)           # some out-of-bounds / border centres
+    p1[0, 40:80, 1] = rng.integers(46, 52, 40)
+    D21 = sc["D21"].reshape(1, n, -1)
+    for dmax in (0, 2):
+        ref = rk._refine_matches_numpy(sc["D11"], D21, p1, 3, dmax)
+        np.savez_compressed(os.path.join(OUT, f"refine_matches_d{dmax}.npz"),
+                            D11=sc["D11"], D21=D21, p1=p1, p_ref=ref.astype(np.int32),
+                            radius=3, dilation_max=dmax)
+
+    # ---- 3. gauss_newton_rays on the reference's own generator ----------------
+    rb = _bench_module()
+    np.random.seed(42)
+    Twc, Xs, Cs, ii, jj, idx, valid, Q = rb.create_gn_test_data(5, 200, 8)
+    for it in (1, 3):
+        out = rgn.gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx, valid, Q, max_iter=it, pin=1)
+        np.savez_compressed(os.path.join(OUT, f"gn_rays_it{it}.npz"), Twc=Twc, Xs=Xs, Cs=Cs, ii=ii, jj=jj,
+                            idx=idx, valid=valid, Q=Q, Twc_ref=out, max_iter=it, pin=1)
+    # a solvable chain graph (converges), own generator
+    Twc, Xs, Cs, ii, jj, idx, valid, Q = synthetic.gn_graph(6, 150, 0, seed=9, chain=True, pose_noise=0.02)
+    out = rgn.gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx, valid, Q, max_iter=10, pin=1)
+    np.savez_compressed(os.path.join(OUT, "gn_rays_chain.npz"), Twc=Twc, Xs=Xs, Cs=Cs, ii=ii, jj=jj,
+                        idx=idx, valid=valid, Q=Q, Twc_ref=out, max_iter=10, pin=1)
+
+    # ---- 4. sim3_ops known answers -------------------------------------------------
+    rng = np.random.default_rng(1)
+    q1 = rng.normal(size=(16, 4)); q1 /= np.linalg.norm(q1, axis=-1, keepdims=True)
+    q2 = rng.normal(size=(16, 4)); q2 /= np.linalg.norm(q2, axis=-1, keepdims=True)
+    v = rng.normal(size=(16, 3))
+    t1, t2 = rng.normal(size=(16, 3)), rng.normal(size=(16, 3))
+    s1, s2 = rng.uniform(0.5, 2, 16), rng.uniform(0.5, 2, 16)
+    xi = rng.normal(size=(16, 7)) * 0.3
+    xi[0] = 0.0                      # small theta, small sigma
+    xi[1, 3:6] = 1e-5                # small theta, large sigma
+    xi[2, 6] = 1e-8                  # large theta, small sigma
+    xi[3, 3:6] *= 8.0                # big rotation
+    tij, qij, sij = rs.sim3_relative(t1, q1, s1, t2, q2, s2)
+    et, eq, es = rs.exp_sim3(xi)
+    rt, rq, rsc = rs.retract_sim3(xi, t1, q1, s1)
+    r = rng.normal(size=64) * 3
+    np.savez_compressed(os.path.join(OUT, "sim3_ops.npz"), q1=q1, q2=q2, v=v, t1=t1, t2=t2, s1=s1, s2=s2, xi=xi,
+                        qmul=rs.quat_multiply(q1, q2), qrot=rs.quat_rotate(q1, v),
+                        rel_t=tij, rel_q=qij, rel_s=sij, exp_so3=rs.exp_so3(xi[:, 3:6]),
+                        exp_t=et, exp_q=eq, exp_s=es, retr_t=rt, retr_q=rq, retr_s=rsc,
+                        hub_r=r, hub_w=rs.huber_weight(r))
+
+    # ---- 5. linalg.cholesky_solve 7x7 -------------------------------------------------
+    A = rng.normal(size=(40, 7))
+    H = A.T @ A
+    g = rng.normal(size=7)
+    np.savez_compressed(os.path.join(OUT, "cholesky_solve.npz"), H=H, g=g, x=rl.cholesky_solve(H, g, 1e-6),
+                        H32=H.astype(np.float32), g32=g.astype(np.float32),
+                        x32=rl.cholesky_solve(H.astype(np.float32), g.astype(np.float32), 1e-6))
+    print("golden fixtures written to", OUT)
+    for f in sorted(os.listdir(OUT)):
+        print(f"  {f:32s} {os.path.getsize(os.path.join(OUT, f)) / 1024:8.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,114 @@
+"""GPU parity: fused Gauss-Newton tracking solve vs the float64 CPU oracle.
+Floating point: HIP computes per-point terms in float32 and accumulates in float64;
+tolerances are stated per assertion."""
+import numpy as np
+import pytest
+import torch
+
+from mast3r_slam import synthetic, tracker
+from oracle import sim3 as S
+from oracle import tracking as ot
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _problem(h, w, seed, **kw):
+    pr = synthetic.tracking_problem(h, w, seed=seed, **kw)
+    pr["Xf"] = pr["Xf_canon"][pr["idx"]]
+    return pr
+
+
+def test_normal_equations_match_oracle(dev):
+    pr = _problem(48, 64, 1)
+    rng = np.random.default_rng(0)
+    q = np.array([0.01, -0.02, 0.015, 1.0]); q /= np.linalg.norm(q)
+    T = np.concatenate([rng.normal(size=3) * 0.02, q, [1.01]]).astype(np.float32)
+    H, g, cost = tracker.normal_equations(_t(pr["Xf"], dev), _t(pr["Xk"], dev), _t(T, dev), _t(pr["Qk"], dev),
+                                          _t(pr["valid"], dev))
+    # oracle: one _solve at the same pose
+    Xf = pr["Xf"].astype(np.float64); Xk = pr["Xk"].astype(np.float64)
+    v = pr["valid"].astype(np.float64)[:, None]; Qk = pr["Qk"].astype(np.float64)[:, None]
+    si = np.concatenate([np.repeat(v * np.sqrt(Qk) / 0.003, 3, 1), v * np.sqrt(Qk) / 10.0], 1)
+    p, dT = ot.act_sim3(T.astype(np.float64), Xf, True)
+    rd, drd = ot.point_to_ray_dist(p, True)
+    _, cost_o, H_o, g_o = ot.solve_step(si, ot.point_to_ray_dist(Xk) - rd, -drd @ dT)
+    Hs = np.abs(H_o).max()
+    assert np.abs(H.cpu().numpy() - H_o).max() <= 2e-5 * Hs              # float32 per-point terms
+    assert np.abs(g.cpu().numpy() - g_o).max() <= 2e-5 * np.abs(g_o).max()
+    assert abs(float(cost) - cost_o) <= 2e-5 * cost_o
+    assert np.allclose(H.cpu().numpy(), H.cpu().numpy().T)
+
+
+@pytest.mark.parametrize("fixed", [False, True])
+def test_gn_loop_matches_oracle(dev, fixed):
+    pr = _problem(48, 64, 2)
+    Tf, Trel, info = tracker.opt_pose_ray_dist_sim3(_t(pr["Xf"], dev), _t(pr["Xk"], dev), _t(pr["T_WCf"], dev),
+                                                    _t(pr["T_WCk"], dev), _t(pr["Qk"], dev), _t(pr["valid"], dev),
+                                                    fixed_iters=fixed)
+    To, Trel_o, io = ot.opt_pose_ray_dist_sim3(pr["Xf"], pr["Xk"], pr["T_WCf"], pr["T_WCk"], pr["Qk"], pr["valid"],
+                                               fixed_iters=10 if fixed else None)
+    info = info.cpu().numpy()
+    assert int(info[0]) == io["iters"]                                    # same stopping iteration
+    assert np.abs(Trel.cpu().numpy() - Trel_o).max() < 5e-5               # pose: abs 5e-5 (t, q, s ~ O(1))
+    assert np.abs(Tf.cpu().numpy() - To).max() < 5e-5
+    assert abs(info[1] - io["costs"][-1]) <= 1e-3 * io["costs"][-1]
+    assert bool(info[3]) == (not fixed)
+
+
+def test_nonidentity_world_poses(dev):
+    pr = _problem(32, 48, 3)
+    rng = np.random.default_rng(5)
+    qk = rng.normal(size=4); qk /= np.linalg.norm(qk)
+    T_WCk = np.concatenate([rng.normal(size=3), qk, [1.7]]).astype(np.float32)
+    T_WCf = S.sim3_mul_mlx(T_WCk.astype(np.float64), np.array([0.01, 0, 0, 0, 0, 0, 1, 1.0])).astype(np.float32)
+    Tf, Trel, _ = tracker.opt_pose_ray_dist_sim3(_t(pr["Xf"], dev), _t(pr["Xk"], dev), _t(T_WCf, dev),
+                                                 _t(T_WCk, dev), _t(pr["Qk"], dev), _t(pr["valid"], dev))
+    To, Trel_o, _ = ot.opt_pose_ray_dist_sim3(pr["Xf"], pr["Xk"], T_WCf, T_WCk, pr["Qk"], pr["valid"])
+    assert np.abs(Trel.cpu().numpy() - Trel_o).max() < 5e-5
+    assert np.abs(Tf.cpu().numpy() - To).max() < 2e-4                     # scaled by |T_WCk| ~ 2
+
+
+def test_full_size_recovers_known_sim3_and_is_deterministic(dev):
+    pr = _problem(512, 512, 0)
+    a = [_t(pr[k], dev) for k in ("Xf", "Xk", "T_WCf", "T_WCk", "Qk", "valid")]
+    _, T1, i1 = tracker.opt_pose_ray_dist_sim3(*a, cfg=dict(max_iters=30, rel_error=0.0, delta_norm=1e-7))
+    _, T2, i2 = tracker.opt_pose_ray_dist_sim3(*a, cfg=dict(max_iters=30, rel_error=0.0, delta_norm=1e-7))
+    assert torch.equal(T1, T2) and torch.equal(i1, i2)                    # fixed-order reduction: bitwise
+    T = T1.cpu().numpy()
+    assert np.abs(T[:3] - pr["T_true"][:3]).max() < 2e-3                  # 5 % outlier matches + noise 1e-3
+    assert abs(T[7] - pr["T_true"][7]) < 2e-3
+    assert np.abs(np.abs(T[3:7]) - np.abs(pr["T_true"][3:7])).max() < 1e-3
+
+
+def test_all_invalid_and_degenerate_input_do_not_crash(dev):
+    pr = _problem(16, 16, 7)
+    zeros = np.zeros_like(pr["valid"])
+    Tf, Trel, info = tracker.opt_pose_ray_dist_sim3(_t(pr["Xf"], dev), _t(pr["Xk"], dev), _t(pr["T_WCf"], dev),
+                                                    _t(pr["T_WCk"], dev), _t(pr["Qk"], dev), _t(zeros, dev))
+    # H = 1e-6 I, g = 0 -> tau = 0 -> converged by |tau| at the first step, pose unchanged
+    assert np.allclose(Trel.cpu().numpy(), [0, 0, 0, 0, 0, 0, 1, 1], atol=1e-7)
+    assert int(info.cpu()[0]) == 1 and bool(info.cpu()[3])
+
+
+def test_track_gather_and_sim3_act(dev):
+    rng = np.random.default_rng(9)
+    n = 5000
+    Xc = rng.normal(size=(n, 3)).astype(np.float32)
+    Cf = rng.uniform(-0.5, 3, n).astype(np.float32); Ck = rng.uniform(-0.5, 3, n).astype(np.float32)
+    Qff = rng.uniform(0.5, 4, n).astype(np.float32); Qkf = rng.uniform(0.5, 4, n).astype(np.float32)
+    idx = rng.integers(0, n, n).astype(np.int64); vm = rng.uniform(size=n) < 0.8
+    Xf, Qk, vo, vk, cnt = tracker.track_gather(*[_t(a, dev) for a in (Xc, Cf, Ck, Qff, Qkf, idx, vm)], 0.0, 1.5)
+    Qk_o = np.sqrt(Qff[idx] * Qkf)
+    vo_o, vk_o = ot.validity(vm, Cf[idx], Ck, Qk_o, 0.0, 1.5)
+    assert np.array_equal(Xf.cpu().numpy(), Xc[idx])
+    assert np.array_equal(Qk.cpu().numpy(), Qk_o)                         # one mul + correctly rounded sqrt
+    assert np.array_equal(vo.cpu().numpy().astype(bool), vo_o) and np.array_equal(vk.cpu().numpy().astype(bool), vk_o)
+    assert cnt.cpu().tolist() == [int(vo_o.sum()), int(vk_o.sum())]
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    T = np.concatenate([rng.normal(size=3), q, [1.2]]).astype(np.float32)
+    out = tracker.sim3_act(_t(T, dev), _t(Xc, dev)).cpu().numpy()
+    assert np.abs(out - S.sim3_act_mlx(T.astype(np.float64), Xc.astype(np.float64))).max() < 1e-5

@@ -70,9 +70,6 @@ k_track_accum(const float *__restrict__ Xf, const float *__restrict__ Xk, const 
             {di * di2 * p.y * p.x, -di * (1.0f - di2 * p.y * p.y), di * di2 * p.y * p.z},
             {di * di2 * p.z * p.x, di * di2 * p.z * p.y, -di * (1.0f - di2 * p.z * p.z)},
             {-r.x, -r.y, -r.z}};
-        float h[kSums];
-#pragma unroll
-        for (int i = 0; i < kSums; ++i) h[i] = 0.0f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float si = (c < 3) ? si_ray : si_dist;
@@ -83,17 +80,14 @@ k_track_accum(const float *__restrict__ Xf, const float *__restrict__ Xk, const 
             const float J[7] = {rsi * a[c].x, rsi * a[c].y, rsi * a[c].z, rsi * pa.x, rsi * pa.y,
                                 rsi * pa.z, rsi * dot(a[c], p)};
             const float bb = rsi * res[c];
-            int k = 0;
 #pragma unroll
-            for (int i = 0; i < 7; ++i)
+            for (int i = 0; i < 7; ++i) {
 #pragma unroll
-                for (int j = i; j < 7; ++j) h[k++] += J[i] * J[j];
-#pragma unroll
-            for (int i = 0; i < 7; ++i) h[28 + i] -= J[i] * bb;
-            h[35] += 0.5f * bb * bb;
+                for (int j = i; j < 7; ++j) acc[i * 7 - (i * (i - 1)) / 2 + (j - i)] += (double)(J[i] * J[j]);
+                acc[28 + i] -= (double)(J[i] * bb);
+            }
+            acc[35] += (double)(0.5f * bb * bb);
         }
-#pragma unroll
-        for (int i = 0; i < kSums; ++i) acc[i] += (double)h[i];
     }
 
     __shared__ double red[kThreads / 64][kSums];

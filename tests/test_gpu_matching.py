@@ -55,7 +55,7 @@ def test_iter_proj_scopes_and_early_stop(dev, scope):
     h, w = 24, 32
     vv, uu = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing="ij")
     X11, X21 = [], []
-    for amp in (0.4, 1.7):
+    for amp in (0.02, 2.5):
         bump = np.sin(np.pi * uu / (w - 1)) * np.sin(np.pi * vv / (h - 1))
         X11.append(synthetic._surface(uu, vv, h, w))
         X21.append(synthetic._surface(uu + amp * bump, vv - 0.5 * amp * bump, h, w))

@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Benchmark of the MASt3R-SLAM per-frame hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--pairs-per-gpu P]
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one pass of the hot path over one batch of P synthetic keyframe pairs per GPU:
+  two-view network (ViT-L encoder on 2P images, two 12-block decoders, DPT + feature heads)
+  -> dense matching (prep -> iter_proj -> refine_matches -> occlusion test)
+  -> Gauss-Newton Sim(3) tracking solve (10 iterations) per pair
+  [N > 1] -> RCCL all-gather of the per-pair results (pointmaps, confidences, indices, validity).
+Pairs are independent: each rank works on its own P pairs (weak scaling), the only collective
+is the result all-gather.  Inputs are resident in HBM before the timed region.  Weights are
+seeded random (no checkpoint can be fetched), data is synthetic - both stated in the JSON.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel =
+the bf16 MFMA GEMM, algorithmic FLOPs / HIP-event time per launch) and `cpu_baseline` (the CPU
+oracle timed on this host, rank 0, N=1 only, on one pair).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "mast3r-slam_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+H = W = 512
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs-per-gpu", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    return ap.parse_args()
+
+
+def make_inputs(model_mod, synthetic, pairs, rank, dev):
+    base = rank * pairs
+    im1 = np.stack([synthetic.textured_image(H, W, 2 * (base + p)) for p in range(pairs)])
+    im2 = np.stack([synthetic.textured_image(H, W, 2 * (base + p) + 1) for p in range(pairs)])
+    return torch.from_numpy(im1).to(dev), torch.from_numpy(im2).to(dev)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (the HIP path is the product; no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from mast3r_slam import _ffi, config, matching, model as model_mod, ops, synthetic, tracker
+    from mast3r_slam import dist as m3dist
+    if not os.path.exists(_ffi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+
+    P = args.pairs_per_gpu
+    config.set_config({"matching": {"use_simple": False}})            # the iter_proj + refine matcher
+    net = model_mod.Mast3rFull(seed=0, device=dev)
+    im1, im2 = make_inputs(model_mod, synthetic, P, rank, dev)
+    ident = torch.tensor([0, 0, 0, 0, 0, 0, 1, 1], dtype=torch.float32, device=dev)
+    n = H * W
+    tcfg = config.get_config()["tracking"]
+    stage_ms = {"infer": 0.0, "match": 0.0, "gn": 0.0, "gather": 0.0}
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+
+    def step(timers=None):
+        marks = []
+        if timers is not None:
+            marks.append(ev()); marks[-1].record()
+        o1, o2 = net.reconstruct_batch(im1, im2)
+        if timers is not None:
+            marks.append(ev()); marks[-1].record()
+        idx, valid = matching.match(o1["pts3d"], o2["pts3d"], o1["desc"], o2["desc"])
+        if timers is not None:
+            marks.append(ev()); marks[-1].record()
+        poses = []
+        for p in range(P):
+            # frame = view 1 (its own camera), keyframe = view 2; canonical keyframe points stand in
+            # as X_ji (same shapes and data flow as FrameTracker.track, tracker.py:88-123)
+            Xf, Qk, vo, vk, cnt = tracker.track_gather(
+                o1["pts3d"][p].reshape(n, 3), o1["conf"][p].reshape(n), o2["conf"][p].reshape(n),
+                o1["desc_conf"][p].reshape(n), o2["desc_conf"][p].reshape(n), idx[p], valid[p].reshape(n),
+                tcfg["C_conf"], tcfg["Q_conf"])
+            T_WCf, T_rel, info = tracker.opt_pose_ray_dist_sim3(Xf, o2["pts3d"][p].reshape(n, 3), ident, ident, Qk, vo,
+                                                                tcfg, fixed_iters=True)
+            poses.append(T_WCf)
+        poses = torch.stack(poses)
+        if timers is not None:
+            marks.append(ev()); marks[-1].record()
+        out = (o1["pts3d"], o2["pts3d"], o1["conf"], o2["conf"], idx, valid, poses)
+        if world > 1:
+            out = m3dist.all_gather_results(out)
+        if timers is not None:
+            marks.append(ev()); marks[-1].record()
+            torch.cuda.synchronize()
+            for k, (a, b) in zip(("infer", "match", "gn", "gather"), zip(marks[:-1], marks[1:])):
+                timers[k] += a.elapsed_time(b)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- untimed instrumented passes: per-stage times and per-launch MFMA kernel timing --------------
+    step(stage_ms)
+    ops.PROFILE = []
+    step()
+    torch.cuda.synchronize()
+    prof, ops.PROFILE = ops.PROFILE, None
+    by_kind = {}
+    for kind, flops, e0, e1 in prof:
+        d = by_kind.setdefault(kind, [0.0, 0.0, 0])
+        d[0] += flops; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1
+    g = by_kind.get("gemm", [0.0, 1.0, 1])
+    gemm_tflops = g[0] / g[1] / 1e12
+    model_flops = net.flops_per_pair(H, W) * P
+
+    result = {
+        "metric": "keyframe-pairs/sec (512x512 two-view infer+match+GN)",
+        "value": world * P * args.steps / elapsed,
+        "unit": "pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic 512x512 textured pairs; seeded random-init weights (no checkpoint available offline)",
+        "config": {"workload": f"{P} keyframe pairs/GPU at 512x512 (BASELINE configs[3] per-GPU shard): "
+                               "two-view MASt3R ViT-L infer + iter_proj/refine match + 10-iter GN tracking"
+                               + ("" if world == 1 else " + RCCL all-gather of results"),
+                   "pairs_per_gpu": P, "global_pairs": world * P, "image": [H, W], "gn_iters": tcfg["max_iters"],
+                   "parallelism": f"pair-sharded x{world}"},
+        "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+        "model_tflop_per_step": model_flops / 1e12,
+        "roofline": {"bound": "mfma", "kernel": "k_gemm (bf16 MFMA GEMM, 128x128x64 tile)",
+                     "achieved": gemm_tflops, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": gemm_tflops / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                     "launches": g[2], "avg_launch_us": g[1] / max(g[2], 1) * 1e6,
+                     "other_kernels_tflops": {k: v[0] / v[1] / 1e12 for k, v in by_kind.items() if k != "gemm"}},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args, net)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, net):
+    """The CPU oracle (kind "port": our restatement, pinned to the reference's numpy twins for
+    matching; torch fp32 for the network) timed on this host on ONE pair of the same workload."""
+    from mast3r_slam import synthetic
+    from oracle import matching as om
+    from oracle import model as omodel
+    from oracle import tracking as ot
+    threads = args.cpu_threads or os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    im1 = torch.from_numpy(synthetic.textured_image(H, W, 0)[None])
+    im2 = torch.from_numpy(synthetic.textured_image(H, W, 1)[None])
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        r1, r2 = omodel.reconstruct(net.host_weights, im1, im2, net.cfg)
+    t_model = time.perf_counter() - t0
+    X11, X21 = r1["pts3d"].numpy(), r2["pts3d"].numpy()
+    t0 = time.perf_counter()
+    idx, valid = om.match_iterative_proj(X11, X21, r1["desc"].numpy(), r2["desc"].numpy(), dilation_max=2)
+    t_match = time.perf_counter() - t0
+    n = H * W
+    Qk = ot.match_quality(r1["desc_conf"].numpy().reshape(n), r2["desc_conf"].numpy().reshape(n),
+                          np.clip(idx[0], 0, n - 1))
+    ident = np.array([0, 0, 0, 0, 0, 0, 1, 1], dtype=np.float64)
+    t0 = time.perf_counter()
+    ot.opt_pose_ray_dist_sim3(X11.reshape(n, 3)[np.clip(idx[0], 0, n - 1)], X21.reshape(n, 3), ident, ident, Qk,
+                              valid[0, :, 0], fixed_iters=10)
+    t_gn = time.perf_counter() - t0
+    total = t_model + t_match + t_gn
+    return {"value": 1.0 / total, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": "1 pair 512x512: torch-CPU fp32 network + numpy matching oracle + float64 GN oracle (10 iters)",
+            "seconds": {"model": round(t_model, 2), "match": round(t_match, 2), "gn": round(t_gn, 2)}}
+
+
+if __name__ == "__main__":
+    main()

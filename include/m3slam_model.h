@@ -1,0 +1,84 @@
+/*
+ * m3slam_model.h - C ABI of the network operators in libm3slam_hip.so (gfx950).
+ *
+ * These are the device ops behind model.encode / model.reconstruct, the two calls the
+ * reference makes into its (absent) third-party network package `mlx_mast3r`
+ * (/root/reference/src/mlx_mast3r_slam/mast3r_utils.py:278,281,347-355,418-421).
+ * The reference tree holds no source for that arithmetic; the architecture follows the
+ * public MASt3R / DUSt3R / CroCo-v2 definition (DESIGN.md "Model").  Conventions as in
+ * m3slam.h: device pointers, caller-owned buffers, stream-ordered, int status.
+ * bf16 tensors are passed as void* (16-bit storage, round-to-nearest-even).
+ */
+#ifndef M3SLAM_MODEL_H
+#define M3SLAM_MODEL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* epilogue selectors of m3_gemm_bf16 / m3_conv3x3_bf16 */
+enum {
+    M3_EPI_BF16 = 0,       /* C(bf16) = acc + bias */
+    M3_EPI_BF16_GELU = 1,  /* C(bf16) = gelu_erf(acc + bias) */
+    M3_EPI_F32 = 2,        /* C(f32)  = acc + bias */
+    M3_EPI_F32_ACCUM = 3,  /* C(f32)  = R(f32) + acc + bias   (residual stream; C may alias R) */
+    M3_EPI_BF16_RELU = 4,  /* C(bf16) = relu(acc + bias) */
+    M3_EPI_BF16_ADD = 5    /* C(bf16) = R(bf16) + acc + bias  (C may alias R) */
+};
+
+/* C[M,N] = epi(A[M,K] . W[N,K]^T + bias): A, W bf16 K-major (torch nn.Linear layout), fp32
+ * accumulation on v_mfma_f32_16x16x32_bf16.  K % 64 == 0, N % 4 == 0, ldc >= N. */
+int m3_gemm_bf16(const void *A, const void *W, const float *bias, void *C, const void *R,
+                 int M, int N, int K, int ldc, int epilogue, void *stream);
+
+/* 3x3 convolution, padding 1, stride 1 or 2, as an implicit GEMM: X bf16 NHWC [B,H,W,Cin],
+ * W bf16 [Cout,3,3,Cin], Y NHWC [B,OH,OW,Cout].  Cin % 64 == 0, Cout % 4 == 0.  zero16: 16
+ * zero bytes in device memory (source of the padding taps). */
+int m3_conv3x3_bf16(const void *X, const void *W, const float *bias, void *Y, const void *R,
+                    const void *zero16, int B, int H, int Wd, int Cin, int Cout, int stride,
+                    int epilogue, void *stream);
+
+/* Fused multi-head attention, head dim 64: O = softmax(scale * Q K^T) V, bf16 in/out, fp32
+ * softmax.  Q/K/V/O are addressed as base + batch*batch_stride + token*row_stride + head*64
+ * (element units), so q, k, v may live interleaved in one [tokens, 3C] projection buffer.
+ * Keys/values of batch item b are read from item (b + kv_batch_shift) % nbatch (decoder
+ * cross-attention to the other view).  Tq % 128 == 0, Tk % 64 == 0. */
+int m3_attention_bf16(const void *Q, const void *K, const void *V, void *O, int q_row_stride,
+                      int kv_row_stride, int o_row_stride, int64_t q_batch_stride,
+                      int64_t kv_batch_stride, int64_t o_batch_stride, int nbatch, int heads,
+                      int Tq, int Tk, int kv_batch_shift, float scale, void *stream);
+
+/* CroCo RoPE-2D ("RoPE100") in place on the 64-wide heads of X [tokens,row_stride] bf16:
+ * dims 0..31 rotate with the token's y, 32..63 with its x; pos_yx int32 [tokens_per_image,2],
+ * cos_sin f32 [max_pos,16,2]. */
+int m3_rope2d_bf16(void *X, const int32_t *pos_yx, const float *cos_sin, int row_stride, int tokens,
+                   int heads, int tokens_per_image, void *stream);
+
+/* y(bf16)[M,C] = LayerNorm(x(f32)[M,C]) * gamma + beta; C % 256 == 0, C <= 2048. */
+int m3_layernorm_bf16(const float *x, const float *gamma, const float *beta, void *y, int M, int C,
+                      float eps, void *stream);
+
+/* uint8 image [B,H,W,3] -> bf16 patch matrix [B*(H/16)*(W/16), 768] (column c*256+py*16+px),
+ * normalised (v/255-0.5)/0.5 (resize_img, mast3r_utils.py:186-188). */
+int m3_patchify16(const uint8_t *img, void *A, int B, int H, int W, void *stream);
+
+int m3_f32_to_bf16(const float *x, void *y, int64_t n, void *stream);               /* n % 4 == 0 */
+int m3_relu_bf16(const void *x, void *y, int64_t n, void *stream);                  /* n % 8 == 0 */
+int m3_add_bf16(const void *a, const void *b, void *y, int64_t n, void *stream);     /* n % 8 == 0 */
+int m3_concat2_bf16(const void *a, const void *b, void *out, int64_t M, int Ca, int Cb, void *stream);
+/* k = s transposed-conv GEMM output [B*h*w, s*s*C] -> NHWC [B,h*s,w*s,Cpad] (first C channels). */
+int m3_unshuffle_bf16(const void *in, void *out, int B, int h, int w, int s, int C, int Cpad, void *stream);
+/* bilinear x2, align_corners = True, NHWC bf16. */
+int m3_upsample2x_bf16(const void *in, void *out, int B, int H, int W, int C, void *stream);
+/* DPT output [P,4] f32 -> pts3d [P,3] = xyz/|xyz| * expm1(|xyz|), conf [P] = 1 + exp(c). */
+int m3_pts_post(const float *in, float *pts, float *conf, int64_t P, void *stream);
+/* feature-head output [B*(H/16)*(W/16), 6400] bf16 -> pixel shuffle 16 -> desc [B,H,W,24] f32
+ * (L2-normalised), desc_conf [B,H,W] = exp(channel 24). */
+int m3_desc_post(const void *in, float *desc, float *dconf, int B, int H, int W, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M3SLAM_MODEL_H */

@@ -1,0 +1,269 @@
+// Fused (flash-style) multi-head attention for gfx950, head dim 64, bf16 in / bf16 out, fp32
+// softmax and accumulation.  Serves the ViT encoder self-attention, the decoder self-attention
+// and the decoder cross-attention (keys/values of the OTHER view via kv_batch_shift).
+//
+// Workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 query rows
+// (two 16-row tiles) and walks the keys in tiles of 64.  Everything is computed TRANSPOSED so
+// that a query row lives on one lane (q = lane & 15) for the whole kernel:
+//     S^T = K . Q^T      (MFMA A = K fragment, B = Q fragment)  -> lane holds 16 keys of its q
+//     O^T = V^T . P^T    (MFMA A = V^T fragment, B = P fragment)  -> lane holds 16 d of its q
+// so the row max / row sum need only in-lane work plus two xor-shuffles, the rescale factor is
+// lane-local, and P goes from the S accumulators to the next MFMA's B operand with a bf16 pack
+// and no LDS round trip.  K and V tiles are staged global -> LDS by global_load_lds (double
+// buffered); K fragments are ds_read_b128 from an XOR-swizzled image, V^T fragments come from
+// the row-major V image through ds_read_b64_tr_b16 (hardware transpose), conflict-free with a
+// chunk-pair swizzle.
+#include "common.h"
+#include "../../include/m3slam_model.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef unsigned short bf16_t;
+
+constexpr int kThreads = 256;
+constexpr int QROWS = 128;     // query rows per workgroup
+constexpr int KT = 64;         // keys per tile
+constexpr int HD = 64;         // head dim
+constexpr int kTileBytes = KT * HD * 2;          // 8 KiB
+constexpr int kLds = 4 * kTileBytes;             // K,V x 2 stages = 32 KiB
+
+__device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) unsigned *)g,
+                                     (__attribute__((address_space(3))) unsigned *)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+struct AttnArgs {
+    const bf16_t *Q, *K, *V;
+    bf16_t *O;
+    int q_row_stride, kv_row_stride, o_row_stride;       // elements between consecutive tokens
+    long long q_batch_stride, kv_batch_stride, o_batch_stride;   // elements between batch items
+    int Tq, Tk, heads, nbatch, kv_batch_shift;
+    float scale_log2e;                                    // softmax scale * log2(e)
+};
+
+__global__ void __launch_bounds__(kThreads)
+k_attn(const AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kLds];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 15, g = lane >> 4;
+    const int qblk = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const int kvb = (b + a.kv_batch_shift) % a.nbatch;
+    const bf16_t *Qp = a.Q + (size_t)b * a.q_batch_stride + head * HD;
+    const bf16_t *Kp = a.K + (size_t)kvb * a.kv_batch_stride + head * HD;
+    const bf16_t *Vp = a.V + (size_t)kvb * a.kv_batch_stride + head * HD;
+
+    // Q fragments (B operand): lane -> q row (lane&15), d = 32*ks + 8*g + j
+    bf16x8 qf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int row = qblk * QROWS + wave * 32 + qt * 16 + lq;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[qt][ks] = *reinterpret_cast<const bf16x8 *>(Qp + (size_t)row * a.q_row_stride + ks * 32 + g * 8);
+    }
+
+    // staging: thread t moves 16-byte slot t (row = t/8, chunk' = t%8) of each 4 KiB half tile
+    const int srow = tid >> 3, sc = tid & 7;
+    const int kch = sc ^ ((srow >> 1) & 7);                 // K image: chunk ^ ((row>>1)&7)
+    const int vch = sc ^ (((srow >> 1) & 3) << 1);          // V image: chunk-pair ^ ((row>>1)&3)
+    auto stage = [&](int t, int buf) {
+        unsigned char *kb = lds + buf * 2 * kTileBytes, *vb = kb + kTileBytes;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const size_t row = (size_t)(t * KT + i * 32 + srow) * a.kv_row_stride;
+            glds16(Kp + row + kch * 8, kb + i * 4096 + wave * 1024);
+            glds16(Vp + row + vch * 8, vb + i * 4096 + wave * 1024);
+        }
+    };
+
+    f32x4 o[2][4];
+    float m_run[2], l_run[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        m_run[qt] = -INFINITY; l_run[qt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int nt = a.Tk / KT;
+    stage(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) { stage(t + 1, buf ^ 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned char *Ks = lds + buf * 2 * kTileBytes, *Vs = Ks + kTileBytes;
+
+        // ---- S^T = K . Q^T : s[qt][kt] holds keys kt*16 + g*4 + r of query lq ------------------
+        f32x4 s[2][4];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const int r = kt * 16 + lq;
+                const int c = (ks * 4 + g) ^ ((r >> 1) & 7);
+                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + r * 128 + c * 16);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                    s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][kt], 0, 0, 0);
+            }
+
+        // ---- online softmax (row = lane-local query) -------------------------------------------
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float mx = s[qt][0][0];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qt][kt][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qt], mx);
+            const float alpha = exp2f((m_run[qt] - m_new) * a.scale_log2e);
+            const float mb = m_new * a.scale_log2e;
+            m_run[qt] = m_new;
+            float rs = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = exp2f(s[qt][kt][r] * a.scale_log2e - mb);
+                    s[qt][kt][r] = p;
+                    rs += p;
+                }
+            l_run[qt] = l_run[qt] * alpha + rs;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
+            // P fragment for k-step kk: element j<4 -> key (2kk)*16 + g*4 + j, j>=4 -> key (2kk+1)*16 + g*4 + j-4
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                union { unsigned u[4]; bf16x8 v; } pk;
+                pk.u[0] = pack_bf16(s[qt][2 * kk][0], s[qt][2 * kk][1]);
+                pk.u[1] = pack_bf16(s[qt][2 * kk][2], s[qt][2 * kk][3]);
+                pk.u[2] = pack_bf16(s[qt][2 * kk + 1][0], s[qt][2 * kk + 1][1]);
+                pk.u[3] = pack_bf16(s[qt][2 * kk + 1][2], s[qt][2 * kk + 1][3]);
+                pf[qt][kk] = pk.v;
+            }
+        }
+
+        // ---- O^T += V^T . P^T : A fragment = V^T[d = dt*16 + lq][same key permutation] ------------
+        // transposed read: lane (4q+p) of a 16-lane group addresses row (key0 + q), cols d0 + 4p..4p+3
+        const int tq = lq >> 2, tp = lq & 3;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                union { bf16x4 h[2]; bf16x8 v; } vf;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int row = (2 * kk + half) * 16 + g * 4 + tq;
+                    const int ch = (dt * 2 + (tp >> 1)) ^ (((row >> 1) & 3) << 1);
+                    const unsigned char *p = Vs + row * 128 + ch * 16 + (tp & 1) * 8;
+                    vf.h[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) bf16x4 *)p);
+                }
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                    o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[qt][kk], o[qt][dt], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- finalize: O[q][dt*16 + g*4 + r] = o / l ---------------------------------------------------
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float l = l_run[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int row = qblk * QROWS + wave * 32 + qt * 16 + lq;
+        bf16_t *op = a.O + (size_t)b * a.o_batch_stride + (size_t)row * a.o_row_stride + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            uint2 w;
+            w.x = pack_bf16(o[qt][dt][0] * inv, o[qt][dt][1] * inv);
+            w.y = pack_bf16(o[qt][dt][2] * inv, o[qt][dt][3] * inv);
+            *reinterpret_cast<uint2 *>(op + dt * 16 + g * 4) = w;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- RoPE-2D (CroCo "RoPE100")
+// In place on a [tokens, row_stride] bf16 buffer: for every head, the first 32 dims rotate with
+// the token's y position, the last 32 with x; within a 32-block element i pairs with i+16:
+//   out[i]    = x[i] cos(p f_i) - x[i+16] sin(p f_i)
+//   out[i+16] = x[i+16] cos(p f_i) + x[i] sin(p f_i),   f_i = base^(-i/16), i = 0..15
+// cs: fp32 table [max_pos][16][2] = (cos, sin).  One thread handles one (token, head, 32-block).
+__global__ void __launch_bounds__(kThreads)
+k_rope2d(bf16_t *__restrict__ X, const int *__restrict__ pos_yx, const float *__restrict__ cs, int row_stride,
+         int tokens, int heads, int tokens_per_image) {
+    const int idx = blockIdx.x * kThreads + threadIdx.x;
+    const int total = tokens * heads * 2;
+    if (idx >= total) return;
+    const int blk = idx & 1, head = (idx >> 1) % heads, tok = (idx >> 1) / heads;
+    const int pos = pos_yx[(tok % tokens_per_image) * 2 + blk];
+    bf16_t *p = X + (size_t)tok * row_stride + head * HD + blk * 32;
+    union { uint4 q[4]; bf16_t h[32]; } v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v.q[i] = reinterpret_cast<const uint4 *>(p)[i];
+    const float *t = cs + (size_t)pos * 32;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float c = t[2 * i], sn = t[2 * i + 1];
+        const float x1 = __uint_as_float((unsigned)v.h[i] << 16), x2 = __uint_as_float((unsigned)v.h[i + 16] << 16);
+        const unsigned pk = pack_bf16(x1 * c - x2 * sn, x2 * c + x1 * sn);
+        v.h[i] = (bf16_t)(pk & 0xffff);
+        v.h[i + 16] = (bf16_t)(pk >> 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) reinterpret_cast<uint4 *>(p)[i] = v.q[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+int m3_attention_bf16(const void *Q, const void *K, const void *V, void *O, int q_row_stride, int kv_row_stride,
+                      int o_row_stride, int64_t q_batch_stride, int64_t kv_batch_stride, int64_t o_batch_stride,
+                      int nbatch, int heads, int Tq, int Tk, int kv_batch_shift, float scale, void *stream) {
+    M3_REQUIRE(Q && K && V && O && nbatch > 0 && heads > 0 && Tq > 0 && Tk > 0);
+    M3_REQUIRE(Tq % QROWS == 0 && Tk % KT == 0 && nbatch <= 65535 && heads <= 65535);
+    M3_REQUIRE(q_row_stride % 8 == 0 && kv_row_stride % 8 == 0 && o_row_stride % 4 == 0);
+    M3_REQUIRE(kv_batch_shift >= 0);
+    AttnArgs a;
+    a.Q = (const bf16_t *)Q; a.K = (const bf16_t *)K; a.V = (const bf16_t *)V; a.O = (bf16_t *)O;
+    a.q_row_stride = q_row_stride; a.kv_row_stride = kv_row_stride; a.o_row_stride = o_row_stride;
+    a.q_batch_stride = q_batch_stride; a.kv_batch_stride = kv_batch_stride; a.o_batch_stride = o_batch_stride;
+    a.Tq = Tq; a.Tk = Tk; a.heads = heads; a.nbatch = nbatch; a.kv_batch_shift = kv_batch_shift;
+    a.scale_log2e = scale * 1.4426950408889634f;
+    hipLaunchKernelGGL(k_attn, dim3(Tq / QROWS, heads, nbatch), dim3(kThreads), 0, (hipStream_t)stream, a);
+    M3_CHECK_LAUNCH("m3_attention_bf16");
+    return M3_OK;
+}
+
+int m3_rope2d_bf16(void *X, const int32_t *pos_yx, const float *cos_sin, int row_stride, int tokens, int heads,
+                   int tokens_per_image, void *stream) {
+    M3_REQUIRE(X && pos_yx && cos_sin && tokens > 0 && heads > 0 && tokens_per_image > 0 && row_stride % 8 == 0);
+    const int64_t total = (int64_t)tokens * heads * 2;
+    hipLaunchKernelGGL(k_rope2d, dim3(m3_cdiv(total, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (bf16_t *)X, pos_yx, cos_sin, row_stride, tokens, heads, tokens_per_image);
+    M3_CHECK_LAUNCH("m3_rope2d_bf16");
+    return M3_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,309 @@
+// HBM-bound helper kernels of the network path (gfx950): LayerNorm, patch extraction,
+// bilinear 2x upsampling, pixel shuffles and the output heads' post-processing.  All are
+// streaming kernels with 8-16 byte vector accesses per lane; none is on the MFMA roofline.
+#include "common.h"
+#include "../../include/m3slam_model.h"
+
+namespace {
+
+typedef unsigned short bf16_t;
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+// ---------------------------------------------------------------- LayerNorm: one wave per row
+// x f32 [M,C] -> y bf16 [M,C]; two-pass statistics in fp32 from registers (row read once).
+template <int VPL /* float4 per lane */>
+__global__ void __launch_bounds__(kThreads)
+k_layernorm(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+            bf16_t *__restrict__ y, int M, int C, float eps) {
+    const int row = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int lane = threadIdx.x & 63;
+    const float4 *xr = reinterpret_cast<const float4 *>(x + (size_t)row * C);
+    float4 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { v[i] = xr[lane + 64 * i]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    ushort4 *yr = reinterpret_cast<ushort4 *>(y + (size_t)row * C);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const float4 gm = reinterpret_cast<const float4 *>(gamma)[lane + 64 * i];
+        const float4 bt = reinterpret_cast<const float4 *>(beta)[lane + 64 * i];
+        ushort4 o;
+        o.x = f2bf((v[i].x - mean) * rstd * gm.x + bt.x);
+        o.y = f2bf((v[i].y - mean) * rstd * gm.y + bt.y);
+        o.z = f2bf((v[i].z - mean) * rstd * gm.z + bt.z);
+        o.w = f2bf((v[i].w - mean) * rstd * gm.w + bt.w);
+        yr[lane + 64 * i] = o;
+    }
+}
+
+// ---------------------------------------------------------------- patch extraction (im2col of the 16x16/16 conv)
+// img uint8 [B,H,W,3] -> A bf16 [B*(H/16)*(W/16), 768], column = c*256 + py*16 + px, value (v/255-0.5)/0.5
+__global__ void __launch_bounds__(kThreads)
+k_patchify(const uint8_t *__restrict__ img, bf16_t *__restrict__ A, int B, int H, int W) {
+    const int gw = W / 16, gh = H / 16;
+    const int64_t total = (int64_t)B * gh * gw * 768;
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= total) return;
+    const int col = (int)(i % 768);
+    const int64_t tok = i / 768;
+    const int c = col >> 8, py = (col >> 4) & 15, px = col & 15;
+    const int tx = (int)(tok % gw), ty = (int)((tok / gw) % gh), b = (int)(tok / ((int64_t)gw * gh));
+    const uint8_t v = img[(((size_t)b * H + ty * 16 + py) * W + tx * 16 + px) * 3 + c];
+    A[i] = f2bf(((float)v / 255.0f - 0.5f) / 0.5f);
+}
+
+// ---------------------------------------------------------------- generic small elementwise ops
+__global__ void __launch_bounds__(kThreads)
+k_f32_to_bf16(const float *__restrict__ x, bf16_t *__restrict__ y, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = reinterpret_cast<const float4 *>(x)[i];
+    ushort4 o; o.x = f2bf(v.x); o.y = f2bf(v.y); o.z = f2bf(v.z); o.w = f2bf(v.w);
+    reinterpret_cast<ushort4 *>(y)[i] = o;
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_relu_bf16(const bf16_t *__restrict__ x, bf16_t *__restrict__ y, int64_t n8) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n8) return;
+    uint4 v = reinterpret_cast<const uint4 *>(x)[i];
+    unsigned *w = reinterpret_cast<unsigned *>(&v);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {             // bf16 relu: clear halves whose sign bit is set
+        unsigned lo = w[k] & 0xffffu, hi = w[k] >> 16;
+        lo = (lo & 0x8000u) ? 0u : lo;
+        hi = (hi & 0x8000u) ? 0u : hi;
+        w[k] = lo | (hi << 16);
+    }
+    reinterpret_cast<uint4 *>(y)[i] = v;
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_add_bf16(const bf16_t *__restrict__ a, const bf16_t *__restrict__ b, bf16_t *__restrict__ y, int64_t n8) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n8) return;
+    union U { uint4 q; bf16_t h[8]; } u, v, o;
+    u.q = reinterpret_cast<const uint4 *>(a)[i];
+    v.q = reinterpret_cast<const uint4 *>(b)[i];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o.h[k] = f2bf(bf2f(u.h[k]) + bf2f(v.h[k]));
+    reinterpret_cast<uint4 *>(y)[i] = o.q;
+}
+
+// rows of `a` [M,Ca] and `b` [M,Cb] (bf16) side by side into out [M,Ca+Cb]; Ca, Cb multiples of 8
+__global__ void __launch_bounds__(kThreads)
+k_concat2(const bf16_t *__restrict__ a, const bf16_t *__restrict__ b, bf16_t *__restrict__ out, int64_t M,
+          int Ca, int Cb) {
+    const int cw = (Ca + Cb) / 8;
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= M * cw) return;
+    const int64_t m = i / cw;
+    const int c = (int)(i % cw) * 8;
+    const uint4 v = (c < Ca) ? *reinterpret_cast<const uint4 *>(a + m * Ca + c)
+                             : *reinterpret_cast<const uint4 *>(b + m * Cb + (c - Ca));
+    *reinterpret_cast<uint4 *>(out + m * (Ca + Cb) + c) = v;
+}
+
+// GEMM output of a k=s transposed conv, [B*h*w, s*s*C] with column (dy*s+dx)*C + c  ->  NHWC [B,h*s,w*s,C]
+__global__ void __launch_bounds__(kThreads)
+k_unshuffle(const bf16_t *__restrict__ in, bf16_t *__restrict__ out, int B, int h, int w, int s, int C, int Cpad) {
+    const int c8 = C / 8;
+    const int64_t total = (int64_t)B * h * s * w * s * c8;
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % c8) * 8;
+    int64_t p = i / c8;
+    const int X = (int)(p % (w * s)); p /= (w * s);
+    const int Y = (int)(p % (h * s));
+    const int b = (int)(p / (h * s));
+    const int y = Y / s, dy = Y % s, x = X / s, dx = X % s;
+    const uint4 v = *reinterpret_cast<const uint4 *>(in + (((size_t)b * h + y) * w + x) * (size_t)(s * s * C) +
+                                                     (dy * s + dx) * C + c);
+    *reinterpret_cast<uint4 *>(out + (((size_t)b * h * s + Y) * (w * s) + X) * Cpad + c) = v;
+}
+
+// bilinear x2, align_corners=True, NHWC bf16, C multiple of 8
+__global__ void __launch_bounds__(kThreads)
+k_upsample2x(const bf16_t *__restrict__ in, bf16_t *__restrict__ out, int B, int H, int W, int C) {
+    const int OH = 2 * H, OW = 2 * W, c8 = C / 8;
+    const int64_t total = (int64_t)B * OH * OW * c8;
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % c8) * 8;
+    int64_t p = i / c8;
+    const int ox = (int)(p % OW); p /= OW;
+    const int oy = (int)(p % OH);
+    const int b = (int)(p / OH);
+    const float sy = (OH > 1) ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+    const float sx = (OW > 1) ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+    const float fy = oy * sy, fx = ox * sx;
+    int y0 = (int)fy, x0 = (int)fx;
+    y0 = min(y0, H - 1); x0 = min(x0, W - 1);
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float wy = fy - (float)y0, wx = fx - (float)x0;
+    const bf16_t *base = in + (size_t)b * H * W * C + c;
+    union U { uint4 q; bf16_t h[8]; } a, bq, cq, d, o;
+    a.q = *reinterpret_cast<const uint4 *>(base + ((size_t)y0 * W + x0) * C);
+    bq.q = *reinterpret_cast<const uint4 *>(base + ((size_t)y0 * W + x1) * C);
+    cq.q = *reinterpret_cast<const uint4 *>(base + ((size_t)y1 * W + x0) * C);
+    d.q = *reinterpret_cast<const uint4 *>(base + ((size_t)y1 * W + x1) * C);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float top = bf2f(a.h[k]) * (1.f - wx) + bf2f(bq.h[k]) * wx;
+        const float bot = bf2f(cq.h[k]) * (1.f - wx) + bf2f(d.h[k]) * wx;
+        o.h[k] = f2bf(top * (1.f - wy) + bot * wy);
+    }
+    *reinterpret_cast<uint4 *>(out + (((size_t)b * OH + oy) * OW + ox) * C + c) = o.q;
+}
+
+// DPT head output [P,4] f32 (xyz, conf logit) -> pts3d [P,3] = xyz/|xyz| * expm1(|xyz|), conf [P] = 1 + exp(c)
+__global__ void __launch_bounds__(kThreads)
+k_pts_post(const float *__restrict__ in, float *__restrict__ pts, float *__restrict__ conf, int64_t P) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= P) return;
+    const float4 v = reinterpret_cast<const float4 *>(in)[i];
+    const float d = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    const float dc = fmaxf(d, 1e-8f);
+    const float sc = expm1f(d) / dc;
+    pts[3 * i + 0] = v.x * sc; pts[3 * i + 1] = v.y * sc; pts[3 * i + 2] = v.z * sc;
+    conf[i] = 1.0f + expf(v.w);
+}
+
+// feature-MLP output [B*gh*gw, 25*256] bf16 (column c*256 + dy*16 + dx) -> pixel shuffle(16) ->
+// desc [B,H,W,24] f32 L2-normalised, desc_conf [B,H,W] f32 = exp(channel 24).  One thread per pixel.
+__global__ void __launch_bounds__(kThreads)
+k_desc_post(const bf16_t *__restrict__ in, float *__restrict__ desc, float *__restrict__ dconf, int B, int H, int W) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int64_t P = (int64_t)B * H * W;
+    if (i >= P) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H), b = (int)(i / ((int64_t)W * H));
+    const int gw = W / 16, gh = H / 16;
+    const bf16_t *row = in + (((size_t)b * gh + y / 16) * gw + x / 16) * 6400 + (y % 16) * 16 + (x % 16);
+    float v[25], n2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 25; ++c) v[c] = bf2f(row[c * 256]);
+#pragma unroll
+    for (int c = 0; c < 24; ++c) n2 += v[c] * v[c];
+    const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+    float4 *o = reinterpret_cast<float4 *>(desc + i * 24);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) o[c] = make_float4(v[4 * c] * inv, v[4 * c + 1] * inv, v[4 * c + 2] * inv, v[4 * c + 3] * inv);
+    dconf[i] = expf(v[24]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int m3_layernorm_bf16(const float *x, const float *gamma, const float *beta, void *y, int M, int C, float eps,
+                      void *stream) {
+    M3_REQUIRE(x && gamma && beta && y && M > 0 && C > 0 && C % 256 == 0 && C <= 2048);
+    dim3 grid(m3_cdiv(M, kThreads / 64)), blk(kThreads);
+    hipStream_t st = (hipStream_t)stream;
+#define M3_LN(V) case V: hipLaunchKernelGGL(k_layernorm<V>, grid, blk, 0, st, x, gamma, beta, (bf16_t *)y, M, C, eps); break
+    switch (C / 256) {
+        M3_LN(1); M3_LN(2); M3_LN(3); M3_LN(4); M3_LN(5); M3_LN(6); M3_LN(7); M3_LN(8);
+        default: return M3_ERR_UNSUPPORTED;
+    }
+#undef M3_LN
+    M3_CHECK_LAUNCH("m3_layernorm_bf16");
+    return M3_OK;
+}
+
+int m3_patchify16(const uint8_t *img, void *A, int B, int H, int W, void *stream) {
+    M3_REQUIRE(img && A && B > 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0);
+    const int64_t total = (int64_t)B * (H / 16) * (W / 16) * 768;
+    hipLaunchKernelGGL(k_patchify, dim3(m3_cdiv(total, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, img,
+                       (bf16_t *)A, B, H, W);
+    M3_CHECK_LAUNCH("m3_patchify16");
+    return M3_OK;
+}
+
+int m3_f32_to_bf16(const float *x, void *y, int64_t n, void *stream) {
+    M3_REQUIRE(x && y && n > 0 && n % 4 == 0);
+    hipLaunchKernelGGL(k_f32_to_bf16, dim3(m3_cdiv(n / 4, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, x,
+                       (bf16_t *)y, n / 4);
+    M3_CHECK_LAUNCH("m3_f32_to_bf16");
+    return M3_OK;
+}
+
+int m3_relu_bf16(const void *x, void *y, int64_t n, void *stream) {
+    M3_REQUIRE(x && y && n > 0 && n % 8 == 0);
+    hipLaunchKernelGGL(k_relu_bf16, dim3(m3_cdiv(n / 8, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const bf16_t *)x, (bf16_t *)y, n / 8);
+    M3_CHECK_LAUNCH("m3_relu_bf16");
+    return M3_OK;
+}
+
+int m3_add_bf16(const void *a, const void *b, void *y, int64_t n, void *stream) {
+    M3_REQUIRE(a && b && y && n > 0 && n % 8 == 0);
+    hipLaunchKernelGGL(k_add_bf16, dim3(m3_cdiv(n / 8, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const bf16_t *)a, (const bf16_t *)b, (bf16_t *)y, n / 8);
+    M3_CHECK_LAUNCH("m3_add_bf16");
+    return M3_OK;
+}
+
+int m3_concat2_bf16(const void *a, const void *b, void *out, int64_t M, int Ca, int Cb, void *stream) {
+    M3_REQUIRE(a && b && out && M > 0 && Ca > 0 && Cb > 0 && Ca % 8 == 0 && Cb % 8 == 0);
+    const int64_t total = M * ((Ca + Cb) / 8);
+    hipLaunchKernelGGL(k_concat2, dim3(m3_cdiv(total, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const bf16_t *)a, (const bf16_t *)b, (bf16_t *)out, M, Ca, Cb);
+    M3_CHECK_LAUNCH("m3_concat2_bf16");
+    return M3_OK;
+}
+
+int m3_unshuffle_bf16(const void *in, void *out, int B, int h, int w, int s, int C, int Cpad, void *stream) {
+    M3_REQUIRE(in && out && B > 0 && h > 0 && w > 0 && s > 0 && C > 0 && C % 8 == 0 && Cpad >= C && Cpad % 8 == 0);
+    const int64_t total = (int64_t)B * h * s * w * s * (C / 8);
+    hipLaunchKernelGGL(k_unshuffle, dim3(m3_cdiv(total, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const bf16_t *)in, (bf16_t *)out, B, h, w, s, C, Cpad);
+    M3_CHECK_LAUNCH("m3_unshuffle_bf16");
+    return M3_OK;
+}
+
+int m3_upsample2x_bf16(const void *in, void *out, int B, int H, int W, int C, void *stream) {
+    M3_REQUIRE(in && out && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0);
+    const int64_t total = (int64_t)B * 2 * H * 2 * W * (C / 8);
+    hipLaunchKernelGGL(k_upsample2x, dim3(m3_cdiv(total, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const bf16_t *)in, (bf16_t *)out, B, H, W, C);
+    M3_CHECK_LAUNCH("m3_upsample2x_bf16");
+    return M3_OK;
+}
+
+int m3_pts_post(const float *in, float *pts, float *conf, int64_t P, void *stream) {
+    M3_REQUIRE(in && pts && conf && P > 0);
+    hipLaunchKernelGGL(k_pts_post, dim3(m3_cdiv(P, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, in, pts, conf, P);
+    M3_CHECK_LAUNCH("m3_pts_post");
+    return M3_OK;
+}
+
+int m3_desc_post(const void *in, float *desc, float *dconf, int B, int H, int W, void *stream) {
+    M3_REQUIRE(in && desc && dconf && B > 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0);
+    const int64_t P = (int64_t)B * H * W;
+    hipLaunchKernelGGL(k_desc_post, dim3(m3_cdiv(P, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const bf16_t *)in, desc, dconf, B, H, W);
+    M3_CHECK_LAUNCH("m3_desc_post");
+    return M3_OK;
+}
+
+}  // extern "C"

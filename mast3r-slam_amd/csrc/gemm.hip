@@ -1,0 +1,255 @@
+// bf16 MFMA GEMM / implicit-GEMM convolution for gfx950 (CDNA4).
+//
+//   C[M,N] = epilogue( A[M,K] . W[N,K]^T + bias[N] )          (torch Linear layout, both K-major)
+//
+// Workgroup = 256 threads = 4 waves (2 x 2), tile 128(M) x 128(N) x 64(K); each wave owns a
+// 64 x 64 sub-tile = 4 x 4 v_mfma_f32_16x16x32_bf16 accumulators (fp32).
+// Staging: global -> LDS directly with global_load_lds_dwordx4 (no VGPR round trip), two LDS
+// stages (64 KiB) so the loads of K-tile t+1 fly while tile t is multiplied.  LDS rows are 128 B
+// (64 bf16); the 16-byte chunk index is XOR-swizzled with (row>>1)&7 - applied on the global
+// SOURCE address (the LDS destination of a direct load is lane-linear) and again on the
+// ds_read_b128 fragment reads - which makes every 16-lane read group conflict-free.
+// The MFMA is issued "swapped" (W fragment as the A operand, activation fragment as B) so each
+// lane ends up with 4 CONSECUTIVE output columns of one row: bias / GELU / residual epilogues
+// and the stores are 8- or 16-byte vector ops.
+//
+// MODE_CONV3 turns the A operand into an on-the-fly im2col gather (implicit GEMM) of a 3x3,
+// pad 1 convolution over an NHWC bf16 image: K = 9*Cin, K-tile kt -> tap (kt*64)/Cin; taps that
+// fall outside the image read a 16-byte zero page instead.
+#include "common.h"
+#include "../../include/m3slam_model.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef unsigned short bf16_t;
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int kThreads = 256;
+constexpr int kStageBytes = (BM + BN) * BK * 2;          // 32 KiB
+constexpr int kLdsBytes = 2 * kStageBytes;               // 64 KiB
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {        // round-to-nearest-even, NaN preserved
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) unsigned *)g,
+                                     (__attribute__((address_space(3))) unsigned *)lds_wave_base, 16, 0, 0);
+}
+
+struct GemmArgs {
+    const bf16_t *A;        // [M,K] bf16 (dense) or NHWC image (conv)
+    const bf16_t *W;        // [N,K] bf16
+    const float *bias;      // [N] or null
+    void *C;                // bf16 [M,ldc] or f32 [M,ldc]
+    const void *R;          // residual (same dtype/shape as C) or null
+    const bf16_t *zero16;   // 16 zero bytes (conv padding source)
+    int M, N, K, ldc;
+    // conv geometry
+    int H, Wd, Cin, OH, OW, stride;
+};
+
+enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32 = 2, EPI_F32_ACCUM = 3, EPI_BF16_RELU = 4, EPI_BF16_ADD = 5 };
+
+template <int MODE /*0 dense, 1 conv3x3*/, int EPI>
+__global__ void __launch_bounds__(kThreads)
+k_gemm(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;               // wave position in the 2x2 grid (M, N)
+
+    // XCD-aware tile order: consecutive tiles of one M-panel land on one XCD (shared A panel in L2)
+    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- per-thread staging geometry: thread t moves 16-byte slot t of every 4 KiB issue ----
+    // slot s -> LDS (row = s/8, chunk' = s%8); global chunk = chunk' ^ ((row>>1)&7)
+    const int srow = tid >> 3, sch = (tid & 7) ^ ((srow >> 1) & 7);
+    const bf16_t *a_src[4];
+    const bf16_t *w_src[4];
+    int a_oy[4], a_ox[4];                                   // conv: output pixel of the row
+    const bf16_t *a_img[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + i * 32 + srow;
+        m = m < g.M ? m : g.M - 1;                          // clamp (stores are predicated)
+        int n = n0 + i * 32 + srow;
+        n = n < g.N ? n : g.N - 1;
+        w_src[i] = g.W + (size_t)n * g.K + sch * 8;
+        if (MODE == 0) {
+            a_src[i] = g.A + (size_t)m * g.K + sch * 8;
+        } else {
+            const int pix = g.OH * g.OW;
+            const int b = m / pix, rem = m - b * pix;
+            a_oy[i] = (rem / g.OW) * g.stride - 1;
+            a_ox[i] = (rem % g.OW) * g.stride - 1;
+            a_img[i] = g.A + (size_t)b * g.H * g.Wd * g.Cin + sch * 8;
+        }
+    }
+    const int nk = g.K / BK;
+
+    auto stage = [&](int kt, int buf) {
+        unsigned char *base = lds + buf * kStageBytes;
+        int ky = 0, kx = 0, c0 = 0;
+        if (MODE == 1) {
+            const int k0 = kt * BK, tap = k0 / g.Cin;
+            c0 = k0 - tap * g.Cin;
+            ky = tap / 3; kx = tap - ky * 3;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const void *src;
+            if (MODE == 0) {
+                src = a_src[i] + (size_t)kt * BK;
+            } else {
+                const int iy = a_oy[i] + ky, ix = a_ox[i] + kx;
+                const bool in = (iy >= 0) && (iy < g.H) && (ix >= 0) && (ix < g.Wd);
+                src = in ? (const void *)(a_img[i] + ((size_t)iy * g.Wd + ix) * g.Cin + c0) : (const void *)g.zero16;
+            }
+            glds16(src, base + i * 4096 + wave * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            glds16(w_src[i] + (size_t)kt * BK, base + BM * BK * 2 + i * 4096 + wave * 1024);
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets: lane -> row (lane&15), k-chunk (lane>>4) (+4 for the second k-step)
+    const int frow = lane & 15, fch = lane >> 4;
+
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        // wait for tile kt only (the 8 loads of tile kt+1 may stay in flight)
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned char *As = lds + buf * kStageBytes;
+        const unsigned char *Ws = As + BM * BK * 2;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ra = wr * 64 + i * 16 + frow;
+                const int ca = (ks * 4 + fch) ^ ((ra >> 1) & 7);
+                af[i] = *reinterpret_cast<const bf16x8 *>(As + ra * 128 + ca * 16);
+                const int rw = wc * 64 + i * 16 + frow;
+                const int cw = (ks * 4 + fch) ^ ((rw >> 1) & 7);
+                wf[i] = *reinterpret_cast<const bf16x8 *>(Ws + rw * 128 + cw * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_barrier();      // all waves done reading `buf` before it is restaged
+    }
+
+    // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] --------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+            if (n >= g.N) continue;                        // N is a multiple of 4 (checked on the host)
+            f32x4 v = acc[i][j];
+            if (g.bias) {
+                const float4 b = *reinterpret_cast<const float4 *>(g.bias + n);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            }
+            const size_t off = (size_t)m * g.ldc + n;
+            if (EPI == EPI_F32 || EPI == EPI_F32_ACCUM) {
+                float *C = reinterpret_cast<float *>(g.C) + off;
+                if (EPI == EPI_F32_ACCUM) {
+                    const float4 r = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(g.R) + off);
+                    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+                }
+                *reinterpret_cast<float4 *>(C) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                if (EPI == EPI_BF16_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                }
+                if (EPI == EPI_BF16_ADD) {
+                    const ushort4 r = *reinterpret_cast<const ushort4 *>(reinterpret_cast<const bf16_t *>(g.R) + off);
+                    v[0] += bf2f(r.x); v[1] += bf2f(r.y); v[2] += bf2f(r.z); v[3] += bf2f(r.w);
+                }
+                if (EPI == EPI_BF16_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                }
+                ushort4 o;
+                o.x = f2bf(v[0]); o.y = f2bf(v[1]); o.z = f2bf(v[2]); o.w = f2bf(v[3]);
+                *reinterpret_cast<ushort4 *>(reinterpret_cast<bf16_t *>(g.C) + off) = o;
+            }
+        }
+    }
+}
+
+template <int MODE>
+int launch(const GemmArgs &a, int epi, hipStream_t st) {
+    const int tiles = m3_cdiv(a.M, BM) * m3_cdiv(a.N, BN);
+    dim3 grid(tiles), blk(kThreads);
+#define M3_L(E) case E: hipLaunchKernelGGL((k_gemm<MODE, E>), grid, blk, kLdsBytes, st, a); break
+    switch (epi) {
+        M3_L(EPI_BF16); M3_L(EPI_BF16_GELU); M3_L(EPI_F32); M3_L(EPI_F32_ACCUM); M3_L(EPI_BF16_RELU); M3_L(EPI_BF16_ADD);
+        default: return M3_ERR_INVALID_ARG;
+    }
+#undef M3_L
+    M3_CHECK_LAUNCH("m3_gemm");
+    return M3_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int m3_gemm_bf16(const void *A, const void *W, const float *bias, void *C, const void *R, int M, int N, int K,
+                 int ldc, int epilogue, void *stream) {
+    M3_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0);
+    M3_REQUIRE(K % BK == 0 && N % 4 == 0 && ldc >= N && ldc % 4 == 0);
+    M3_REQUIRE(!((epilogue == EPI_F32_ACCUM || epilogue == EPI_BF16_ADD) && !R));
+    GemmArgs a{};
+    a.A = (const bf16_t *)A; a.W = (const bf16_t *)W; a.bias = bias; a.C = C; a.R = R;
+    a.M = M; a.N = N; a.K = K; a.ldc = ldc;
+    return launch<0>(a, epilogue, (hipStream_t)stream);
+}
+
+int m3_conv3x3_bf16(const void *X, const void *W, const float *bias, void *Y, const void *R, const void *zero16,
+                    int B, int H, int Wd, int Cin, int Cout, int stride, int epilogue, void *stream) {
+    M3_REQUIRE(X && W && Y && zero16 && B > 0 && H > 0 && Wd > 0 && Cin > 0 && Cout > 0);
+    M3_REQUIRE(Cin % BK == 0 && Cout % 4 == 0 && (stride == 1 || stride == 2));
+    M3_REQUIRE(!((epilogue == EPI_F32_ACCUM || epilogue == EPI_BF16_ADD) && !R));
+    GemmArgs a{};
+    a.A = (const bf16_t *)X; a.W = (const bf16_t *)W; a.bias = bias; a.C = Y; a.R = R;
+    a.zero16 = (const bf16_t *)zero16;
+    a.H = H; a.Wd = Wd; a.Cin = Cin; a.stride = stride;
+    a.OH = (H + 2 - 3) / stride + 1; a.OW = (Wd + 2 - 3) / stride + 1;
+    a.M = B * a.OH * a.OW; a.N = Cout; a.K = 9 * Cin; a.ldc = Cout;
+    return launch<1>(a, epilogue, (hipStream_t)stream);
+}
+
+}  // extern "C"

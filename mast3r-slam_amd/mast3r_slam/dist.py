@@ -1,0 +1,61 @@
+"""Multi-GPU sharding of keyframe pairs / graph edges: one process per GPU, RCCL over xGMI.
+
+The reference has no multi-device code; this is new design.  Pairs (and backend
+edges) are independent units, so the data path needs NO collective: rank r simply owns pairs
+[r*P, (r+1)*P).  The only exchange is the result all-gather, issued as ONE collective per step
+on a single packed byte buffer (pointmaps + confidences + indices + validity + poses): xGMI is
+point-to-point (7 links per GPU), so one large all-gather keeps every link busy, whereas many
+small ones would each pay the launch + ring latency.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total: int, rank: int, world: int) -> range:
+    """Static block partition of `total` units; the first (total % world) ranks get one extra."""
+    q, r = divmod(total, world)
+    lo = rank * q + min(rank, r)
+    return range(lo, lo + q + (1 if rank < r else 0))
+
+
+def pack(tensors):
+    """Flatten a tuple of tensors into one uint8 buffer (+ the metadata to undo it)."""
+    meta = [(t.shape, t.dtype) for t in tensors]
+    flat = [t.contiguous().view(-1).view(torch.uint8) for t in tensors]
+    pad = [(-f.numel()) % 16 for f in flat]                      # keep every segment 16-byte aligned
+    parts = []
+    for f, p in zip(flat, pad):
+        parts.append(f)
+        if p:
+            parts.append(torch.zeros(p, dtype=torch.uint8, device=f.device))
+    return torch.cat(parts), meta
+
+
+def unpack(buf, meta, world):
+    """buf uint8 [world, nbytes] -> tuple of tensors with the rank axis folded into dim 0."""
+    out, off = [], 0
+    for shape, dtype in meta:
+        nbytes = int(torch.empty(0, dtype=dtype).element_size())
+        for s in shape:
+            nbytes *= s
+        seg = buf[:, off:off + nbytes].contiguous().view(-1).view(dtype)
+        out.append(seg.view((world * shape[0],) + tuple(shape[1:])))
+        off += nbytes + ((-nbytes) % 16)
+    return tuple(out)
+
+
+def all_gather_results(tensors, group=None):
+    """All ranks end up with every rank's per-pair results concatenated along dim 0 (rank order).
+    One collective for the whole tuple.  Every rank must pass identically shaped tensors."""
+    world = dist.get_world_size(group)
+    buf, meta = pack(tensors)
+    if dist.get_backend(group) == "nccl":
+        out = torch.empty((world, buf.numel()), dtype=torch.uint8, device=buf.device)
+        dist.all_gather_into_tensor(out.view(-1), buf, group=group)
+    else:                                                       # gloo (CPU tests)
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf, group=group)
+        out = torch.stack(parts)
+    return unpack(out, meta, world)

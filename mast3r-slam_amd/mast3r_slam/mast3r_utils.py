@@ -1,0 +1,174 @@
+"""Level-3 operator API on the MI355X: the functions the SLAM loop injects as callables.
+
+Mirror of /root/reference/src/mlx_mast3r_slam/mast3r_utils.py (same names, argument meaning and
+return tuples; `__all__` :800-823): load_mast3r :47, frame_to_numpy :210, downsample :234,
+mast3r_inference_mono :255, mast3r_asymmetric_inference :324, mast3r_symmetric_inference :382,
+mast3r_match_asymmetric :451, mast3r_match_symmetric :503, mast3r_decode_symmetric_batch :572.
+Tensors are torch tensors on the ROCm device instead of mx.array.
+
+Differences, on purpose:
+  * mast3r_match_symmetric / mast3r_decode_symmetric_batch are REAL (decode from cached encoder
+    tokens, both directions, batched over B pairs); the reference bodies are stubs that return
+    identity matches / zeros (:556-569, :611-616).
+  * cached `frame.feat` is reused; the reference re-encodes both images on every call (:345-355).
+  * *_batch variants take P pairs at once (the data-parallel unit that shards across GPUs).
+Image preprocessing from files (PIL resize, :121-207) and the retrieval database (:640-795) are
+outside the hot path and not provided.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .config import get_config
+from .model import Mast3rFull
+from . import matching
+
+__all__ = [
+    "load_mast3r", "frame_to_numpy", "downsample", "mast3r_inference_mono", "mast3r_asymmetric_inference",
+    "mast3r_symmetric_inference", "mast3r_match_asymmetric", "mast3r_match_symmetric",
+    "mast3r_decode_symmetric_batch", "mast3r_match_asymmetric_batch",
+]
+
+
+def load_mast3r(model_type: str = "mast3r_full", variant: str = "base", resolution: int = 512,
+                precision: str = "bf16", weights_path: Optional[str] = None, **kw) -> Mast3rFull:
+    """mast3r_utils.py:47-80.  Only the full ViT-L model named by the hot path is provided."""
+    if model_type == "mast3r_full":
+        return Mast3rFull.from_pretrained(resolution=resolution, precision=precision, weights_path=weights_path, **kw)
+    if model_type == "dunemast3r":
+        raise ValueError("model_type 'dunemast3r' (DUNE encoder) is outside this build's scope; use 'mast3r_full'")
+    raise ValueError(f"Unknown model type: {model_type}. Use 'dunemast3r' or 'mast3r_full'")
+
+
+def frame_to_numpy(frame) -> torch.Tensor:
+    """mast3r_utils.py:210-226: frame image -> uint8 [H,W,3] (a device tensor here)."""
+    img = frame.img
+    if isinstance(img, np.ndarray):
+        img = torch.from_numpy(img)
+    if img.dim() == 3 and img.shape[0] == 3:
+        img = img.permute(1, 2, 0)
+    if img.dtype != torch.uint8:
+        img = (img * 255).to(torch.uint8) if float(img.max()) <= 1.0 else img.to(torch.uint8)
+    return img.contiguous()
+
+
+def downsample(X, C, D, Q):
+    """mast3r_utils.py:234-252."""
+    k = get_config().get("dataset", {}).get("img_downsample", 1)
+    if k > 1:
+        X = X[..., ::k, ::k, :].contiguous()
+        C = C[..., ::k, ::k].contiguous()
+        D = D[..., ::k, ::k, :].contiguous()
+        Q = Q[..., ::k, ::k].contiguous()
+    return X, C, D, Q
+
+
+def _feat(model: Mast3rFull, frame) -> torch.Tensor:
+    if frame.feat is None:
+        frame.feat = model.encode(frame_to_numpy(frame).to(model.device))
+    return frame.feat
+
+
+def _grid(frame):
+    img = frame.img
+    h, w = (img.shape[1], img.shape[2]) if img.shape[0] == 3 else (img.shape[0], img.shape[1])
+    return h // 16, w // 16
+
+
+def _stack(outs):
+    X = torch.cat([o["pts3d"] for o in outs], 0)
+    C = torch.cat([o["conf"] for o in outs], 0)
+    D = torch.cat([o["desc"] for o in outs], 0)
+    Q = torch.cat([o["desc_conf"] for o in outs], 0)
+    return X, C, D, Q
+
+
+def mast3r_inference_mono(model: Mast3rFull, frame):
+    """mast3r_utils.py:255-321 -> (Xii [H*W,3], Cii [H*W,1], feat [T,1024], pos [T,2] (x,y))."""
+    f = _feat(model, frame)
+    gh, gw = _grid(frame)
+    o1, o2 = model.decode_heads(f, f, 1, (gh, gw))
+    X, C, D, Q = downsample(*_stack([o1, o2]))
+    h, w = X.shape[1:3]
+    gy, gx = torch.meshgrid(torch.arange(gh), torch.arange(gw), indexing="ij")
+    pos = torch.stack([gx.reshape(-1), gy.reshape(-1)], dim=-1).to(X.device)
+    return X[0].reshape(h * w, 3), C[0].reshape(h * w, 1), frame.feat, pos
+
+
+def mast3r_asymmetric_inference(model: Mast3rFull, frame_i, frame_j):
+    """mast3r_utils.py:324-379 -> X [2,H,W,3], C [2,H,W], D [2,H,W,24], Q [2,H,W]."""
+    fi, fj = _feat(model, frame_i), _feat(model, frame_j)
+    o_i, o_j = model.decode_heads(fi, fj, 1, _grid(frame_i))
+    return downsample(*_stack([o_i, o_j]))
+
+
+def mast3r_symmetric_inference(model: Mast3rFull, frame_i, frame_j):
+    """mast3r_utils.py:382-443 -> [4,...] in the order (ii, ji, jj, ij); both directions are decoded
+    as one batch of two pairs."""
+    fi, fj = _feat(model, frame_i), _feat(model, frame_j)
+    o1, o2 = model.decode_heads(torch.stack([fi, fj]), torch.stack([fj, fi]), 2, _grid(frame_i))
+    # pair 0 = (i,j): o1[0]=ii, o2[0]=ji ; pair 1 = (j,i): o1[1]=jj, o2[1]=ij
+    pick = lambda o, k: {n: v[k:k + 1] for n, v in o.items()}
+    return downsample(*_stack([pick(o1, 0), pick(o2, 0), pick(o1, 1), pick(o2, 1)]))
+
+
+def mast3r_match_asymmetric(model: Mast3rFull, frame_i, frame_j, idx_i2j_init=None):
+    """mast3r_utils.py:451-500 -> (idx_i2j [1,N], valid_match_j [1,N,1], Xii, Cii, Qii, Xji, Cji, Qji)."""
+    X, C, D, Q = mast3r_asymmetric_inference(model, frame_i, frame_j)
+    h, w = X.shape[1:3]
+    idx, valid = matching.match(X[0:1], X[1:2], D[0:1], D[1:2], idx_1_to_2_init=idx_i2j_init)
+    n = h * w
+    return (idx, valid, X[0:1].reshape(1, n, 3), C[0:1].reshape(1, n, 1), Q[0:1].reshape(1, n, 1),
+            X[1:2].reshape(1, n, 3), C[1:2].reshape(1, n, 1), Q[1:2].reshape(1, n, 1))
+
+
+def mast3r_match_asymmetric_batch(model: Mast3rFull, imgs_i, imgs_j, idx_i2j_init=None):
+    """P pairs at once from raw uint8 images [P,H,W,3]: encode + decode + heads + match.
+    Returns (idx [P,N], valid [P,N,1], X [2,P,H,W,3], C [2,P,H,W], D [2,P,H,W,24], Q [2,P,H,W])."""
+    o1, o2 = model.reconstruct_batch(imgs_i, imgs_j)
+    idx, valid = matching.match(o1["pts3d"], o2["pts3d"], o1["desc"], o2["desc"], idx_1_to_2_init=idx_i2j_init)
+    st = lambda k: torch.stack([o1[k], o2[k]])
+    return idx, valid, st("pts3d"), st("conf"), st("desc"), st("desc_conf")
+
+
+def _hw(shape):
+    s = shape[0]
+    s = s.cpu() if isinstance(s, torch.Tensor) else np.asarray(s)
+    return int(s.reshape(-1)[0]), int(s.reshape(-1)[1])
+
+
+def mast3r_decode_symmetric_batch(model: Mast3rFull, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j):
+    """mast3r_utils.py:572-632 -> X [4,B,H,W,3], C [4,B,H,W], D [4,B,H,W,24], Q [4,B,H,W] in the order
+    (ii, ji, jj, ij).  feat_* [B,T,1024] cached encoder tokens."""
+    b = feat_i.shape[0]
+    h, w = _hw(shape_i)
+    grid = (h // 16, w // 16)
+    fi = feat_i.to(model.device, torch.bfloat16)
+    fj = feat_j.to(model.device, torch.bfloat16)
+    o1, o2 = model.decode_heads(torch.cat([fi, fj], 0), torch.cat([fj, fi], 0), 2 * b, grid)
+    sl = lambda o, lo: {n: v[lo:lo + b] for n, v in o.items()}
+    parts = [sl(o1, 0), sl(o2, 0), sl(o1, b), sl(o2, b)]           # ii, ji, jj, ij
+    X = torch.stack([p["pts3d"] for p in parts])
+    C = torch.stack([p["conf"] for p in parts])
+    D = torch.stack([p["desc"] for p in parts])
+    Q = torch.stack([p["desc_conf"] for p in parts])
+    return downsample(X, C, D, Q)
+
+
+def mast3r_match_symmetric(model: Mast3rFull, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j):
+    """mast3r_utils.py:503-569 -> (idx_i2j, idx_j2i [B,N], valid_match_j, valid_match_i [B,N,1],
+    Qii, Qjj, Qji, Qij [B,N,1]).  Both matching directions run as one batch of 2B maps."""
+    X, C, D, Q = mast3r_decode_symmetric_batch(model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j)
+    b, h, w = X.shape[1:4]
+    n = h * w
+    # match(X11, X21): i->j uses (ii, ji); j->i uses (jj, ij)
+    X11 = torch.cat([X[0], X[2]], 0)
+    X21 = torch.cat([X[1], X[3]], 0)
+    D11 = torch.cat([D[0], D[2]], 0)
+    D21 = torch.cat([D[1], D[3]], 0)
+    idx, valid = matching.match(X11, X21, D11, D21)
+    q = lambda k: Q[k].reshape(b, n, 1)
+    return idx[:b], idx[b:], valid[:b], valid[b:], q(0), q(2), q(1), q(3)

@@ -1,0 +1,443 @@
+"""Two-view MASt3R network on the MI355X (the `model` object of the operator API).
+
+Replaces the reference's external network package: `Mast3rFull.from_pretrained`, `.encode`,
+`.reconstruct`, `.embed_dim` (call sites /root/reference/src/mlx_mast3r_slam/mast3r_utils.py:
+67-76, 104-109, 278-294, 347-355, 418-421).  The reference tree carries no source or weights
+for it (un-vendored submodule thirdparty/mlx-mast3r), so the architecture is the public
+MASt3R ViT-L/16 + base decoder + catmlp+dpt head (see oracle/model.py for the layer list) and
+weights are either random-initialised (seeded) or loaded from a state dict that uses the public
+checkpoint's key names.
+
+Device-side design (all kernels are hand-written HIP behind include/m3slam_model.h):
+  * activations entering a GEMM are bf16, every GEMM accumulates in fp32 on MFMA;
+  * the residual stream stays fp32 (GEMM epilogue `C = R + acc + bias`), LayerNorm reads it
+    and writes the bf16 GEMM operand - no separate add / cast passes;
+  * q, k, v stay interleaved in the projection buffer; RoPE-2D is applied in place to the q|k
+    columns and the fused attention kernel reads them through strides;
+  * the DPT head runs NHWC so every 3x3 convolution is an implicit GEMM over contiguous
+    channel runs; k=s transposed convolutions are GEMMs followed by a pixel un-shuffle.
+Batching: all 2P images of P pairs go through the encoder as one [2P*T, 1024] token matrix.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import ops
+
+FULL_CFG = dict(enc_depth=24, enc_dim=1024, enc_heads=16, dec_depth=12, dec_dim=768, dec_heads=12,
+                mlp_ratio=4, feat_dim=256, last_dim=128, desc_dim=24, patch=16, rope_base=100.0,
+                layer_dims=(96, 192, 384, 768), hooks=(0, 6, 9, 12))
+# A tiny configuration with the same structure, for fast parity tests against the CPU oracle.
+TINY_CFG = dict(FULL_CFG, enc_depth=2, dec_depth=4, hooks=(0, 2, 3, 4))
+
+
+def _round_bf16(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def init_random_weights(cfg: Optional[dict] = None, seed: int = 0, std: float = 0.02) -> dict:
+    """Seeded random weights with the public checkpoint's key names (fp32 CPU tensors whose matrix
+    entries are bf16-representable).  trunc-normal(std) matrices, N(0, std) biases, LayerNorm
+    gamma = 1 + N(0, std), beta = N(0, std)."""
+    cfg = cfg or FULL_CFG
+    g = torch.Generator().manual_seed(seed)
+    w: dict[str, torch.Tensor] = {}
+
+    def mat(*shape):
+        t = torch.empty(*shape)
+        torch.nn.init.trunc_normal_(t, std=std, a=-2 * std, b=2 * std, generator=g)
+        return _round_bf16(t)
+
+    def vec(n, base=0.0):
+        return base + torch.randn(n, generator=g) * std
+
+    def linear(p, n, k):
+        w[p + ".weight"], w[p + ".bias"] = mat(n, k), vec(n)
+
+    def norm(p, n):
+        w[p + ".weight"], w[p + ".bias"] = vec(n, 1.0), vec(n)
+
+    def conv(p, co, ci, k, bias=True):
+        w[p + ".weight"] = mat(co, ci, k, k)
+        if bias:
+            w[p + ".bias"] = vec(co)
+
+    E, D, r = cfg["enc_dim"], cfg["dec_dim"], cfg["mlp_ratio"]
+    conv("patch_embed.proj", E, 3, 16)
+    for i in range(cfg["enc_depth"]):
+        p = f"enc_blocks.{i}"
+        norm(p + ".norm1", E); linear(p + ".attn.qkv", 3 * E, E); linear(p + ".attn.proj", E, E)
+        norm(p + ".norm2", E); linear(p + ".mlp.fc1", r * E, E); linear(p + ".mlp.fc2", E, r * E)
+    norm("enc_norm", E)
+    linear("decoder_embed", D, E)
+    for name in ("dec_blocks", "dec_blocks2"):
+        for i in range(cfg["dec_depth"]):
+            p = f"{name}.{i}"
+            norm(p + ".norm1", D); linear(p + ".attn.qkv", 3 * D, D); linear(p + ".attn.proj", D, D)
+            norm(p + ".norm2", D); norm(p + ".norm_y", D)
+            for q in ("projq", "projk", "projv", "proj"):
+                linear(p + ".cross_attn." + q, D, D)
+            norm(p + ".norm3", D); linear(p + ".mlp.fc1", r * D, D); linear(p + ".mlp.fc2", D, r * D)
+    norm("dec_norm", D)
+    F_, L = cfg["feat_dim"], cfg["last_dim"]
+    ld = cfg["layer_dims"]
+    for hname in ("downstream_head1", "downstream_head2"):
+        p = hname + ".dpt"
+        conv(p + ".act_postprocess.0.0", ld[0], E, 1)
+        w[p + ".act_postprocess.0.1.weight"], w[p + ".act_postprocess.0.1.bias"] = mat(ld[0], ld[0], 4, 4), vec(ld[0])
+        conv(p + ".act_postprocess.1.0", ld[1], D, 1)
+        w[p + ".act_postprocess.1.1.weight"], w[p + ".act_postprocess.1.1.bias"] = mat(ld[1], ld[1], 2, 2), vec(ld[1])
+        conv(p + ".act_postprocess.2.0", ld[2], D, 1)
+        conv(p + ".act_postprocess.3.0", ld[3], D, 1)
+        conv(p + ".act_postprocess.3.1", ld[3], ld[3], 3)
+        for i in range(4):
+            conv(p + f".scratch.layer_rn.{i}", F_, ld[i], 3, bias=False)
+        for i in (1, 2, 3, 4):
+            q = p + f".scratch.refinenet{i}"
+            for u in ("resConfUnit1", "resConfUnit2"):
+                conv(q + f".{u}.conv1", F_, F_, 3); conv(q + f".{u}.conv2", F_, F_, 3)
+            conv(q + ".out_conv", F_, F_, 1)
+        conv(p + ".head.0", F_ // 2, F_, 3)
+        conv(p + ".head.2", L, F_ // 2, 3)
+        conv(p + ".head.4", 4, L, 1)
+        linear(hname + ".head_local_features.fc1", r * (E + D), E + D)
+        linear(hname + ".head_local_features.fc2", (cfg["desc_dim"] + 1) * 256, r * (E + D))
+    return w
+
+
+def _pad_to(t: torch.Tensor, dim: int, size: int) -> torch.Tensor:
+    if t.shape[dim] == size:
+        return t
+    shape = list(t.shape)
+    shape[dim] = size - t.shape[dim]
+    return torch.cat([t, torch.zeros(shape, dtype=t.dtype)], dim=dim)
+
+
+def _ceil64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+class Mast3rFull:
+    """Drop-in for the reference's `Mast3rFull` model object (mast3r_utils.py:72-76)."""
+
+    embed_dim = 1024
+    patch_size = 16
+
+    def __init__(self, weights: Optional[dict] = None, cfg: Optional[dict] = None, device="cuda",
+                 resolution: int = 512, precision: str = "bf16", seed: int = 0) -> None:
+        if precision not in ("bf16",):
+            raise ValueError("the MI355X path computes in bf16 with fp32 accumulation; precision must be 'bf16'")
+        if not torch.cuda.is_available():
+            raise RuntimeError("Mast3rFull needs a ROCm device; there is no CPU path")
+        self.cfg = dict(cfg or FULL_CFG)
+        self.device = torch.device(device)
+        self.resolution = resolution
+        self.host_weights = weights if weights is not None else init_random_weights(self.cfg, seed)
+        self._prepare(self.host_weights)
+        self._rope_cache = {}
+
+    @classmethod
+    def from_pretrained(cls, resolution: int = 512, precision: str = "bf16", weights_path: Optional[str] = None,
+                        **kw) -> "Mast3rFull":
+        """mast3r_utils.py:72-76.  No checkpoint can be fetched here (no network); `weights_path` may name a
+        torch state dict with the public MASt3R key names, else seeded random weights are used."""
+        weights = None
+        if weights_path is not None:
+            sd = torch.load(weights_path, map_location="cpu")
+            sd = sd.get("model", sd)
+            weights = {k: v.float() for k, v in sd.items() if isinstance(v, torch.Tensor)}
+        return cls(weights=weights, resolution=resolution, precision=precision, **kw)
+
+    # ------------------------------------------------------------------ weight preparation
+    def _prepare(self, w: dict) -> None:
+        dev = self.device
+        P: dict[str, torch.Tensor] = {}
+
+        def lin(p):
+            P[p + ".w"] = w[p + ".weight"].to(dev, torch.bfloat16).contiguous()
+            P[p + ".b"] = w[p + ".bias"].to(dev, torch.float32).contiguous()
+
+        def norm(p):
+            P[p + ".g"] = w[p + ".weight"].to(dev, torch.float32).contiguous()
+            P[p + ".b"] = w[p + ".bias"].to(dev, torch.float32).contiguous()
+
+        def conv3(p, cin_pad=None, bias=True):
+            t = w[p + ".weight"].permute(0, 2, 3, 1)                       # [Co,3,3,Ci]
+            if cin_pad:
+                t = _pad_to(t, 3, cin_pad)
+            P[p + ".w"] = t.to(dev, torch.bfloat16).contiguous()
+            P[p + ".b"] = w[p + ".bias"].to(dev, torch.float32).contiguous() if bias else None
+
+        def conv1(p, kpad=None):
+            t = w[p + ".weight"][:, :, 0, 0]
+            if kpad:
+                t = _pad_to(t, 1, kpad)
+            P[p + ".w"] = t.to(dev, torch.bfloat16).contiguous()
+            P[p + ".b"] = w[p + ".bias"].to(dev, torch.float32).contiguous()
+
+        def convT(p, s, kpad=None):
+            t = w[p + ".weight"]                                            # [Ci,Co,s,s]
+            ci, co = t.shape[0], t.shape[1]
+            t = t.permute(2, 3, 1, 0).reshape(s * s * co, ci)               # row (dy*s+dx)*Co+co
+            if kpad:
+                t = _pad_to(t, 1, kpad)
+            P[p + ".w"] = t.to(dev, torch.bfloat16).contiguous()
+            P[p + ".b"] = w[p + ".bias"].repeat(s * s).to(dev, torch.float32).contiguous()
+
+        c = self.cfg
+        P["patch.w"] = w["patch_embed.proj.weight"].reshape(c["enc_dim"], -1).to(dev, torch.bfloat16).contiguous()
+        P["patch.b"] = w["patch_embed.proj.bias"].to(dev, torch.float32).contiguous()
+        for i in range(c["enc_depth"]):
+            p = f"enc_blocks.{i}"
+            norm(p + ".norm1"); lin(p + ".attn.qkv"); lin(p + ".attn.proj")
+            norm(p + ".norm2"); lin(p + ".mlp.fc1"); lin(p + ".mlp.fc2")
+        norm("enc_norm"); lin("decoder_embed")
+        for name in ("dec_blocks", "dec_blocks2"):
+            for i in range(c["dec_depth"]):
+                p = f"{name}.{i}"
+                norm(p + ".norm1"); lin(p + ".attn.qkv"); lin(p + ".attn.proj")
+                norm(p + ".norm2"); norm(p + ".norm_y"); lin(p + ".cross_attn.projq"); lin(p + ".cross_attn.proj")
+                P[p + ".cross_attn.kv.w"] = torch.cat([w[p + ".cross_attn.projk.weight"],
+                                                       w[p + ".cross_attn.projv.weight"]], 0).to(dev, torch.bfloat16).contiguous()
+                P[p + ".cross_attn.kv.b"] = torch.cat([w[p + ".cross_attn.projk.bias"],
+                                                       w[p + ".cross_attn.projv.bias"]], 0).to(dev, torch.float32).contiguous()
+                norm(p + ".norm3"); lin(p + ".mlp.fc1"); lin(p + ".mlp.fc2")
+        norm("dec_norm")
+        ld = c["layer_dims"]
+        for hname in ("downstream_head1", "downstream_head2"):
+            p = hname + ".dpt"
+            conv1(p + ".act_postprocess.0.0"); convT(p + ".act_postprocess.0.1", 4, _ceil64(ld[0]))
+            conv1(p + ".act_postprocess.1.0"); convT(p + ".act_postprocess.1.1", 2, _ceil64(ld[1]))
+            conv1(p + ".act_postprocess.2.0"); conv1(p + ".act_postprocess.3.0"); conv3(p + ".act_postprocess.3.1")
+            for i in range(4):
+                conv3(p + f".scratch.layer_rn.{i}", cin_pad=_ceil64(ld[i]), bias=False)
+            for i in (1, 2, 3, 4):
+                q = p + f".scratch.refinenet{i}"
+                for u in ("resConfUnit1", "resConfUnit2"):
+                    conv3(q + f".{u}.conv1"); conv3(q + f".{u}.conv2")
+                conv1(q + ".out_conv")
+            conv3(p + ".head.0"); conv3(p + ".head.2"); conv1(p + ".head.4")
+            lin(hname + ".head_local_features.fc1"); lin(hname + ".head_local_features.fc2")
+        self.P = P
+
+    # ------------------------------------------------------------------ helpers
+    def _rope(self, gh: int, gw: int):
+        key = (gh, gw)
+        if key not in self._rope_cache:
+            n = max(gh, gw) + 1
+            inv = 1.0 / (self.cfg["rope_base"] ** (torch.arange(0, 32, 2, dtype=torch.float32) / 32.0))
+            ang = torch.arange(n, dtype=torch.float32)[:, None] * inv[None, :]
+            cs = torch.stack([ang.cos(), ang.sin()], dim=-1).to(self.device).contiguous()       # [n,16,2]
+            gy, gx = torch.meshgrid(torch.arange(gh), torch.arange(gw), indexing="ij")
+            pos = torch.stack([gy.reshape(-1), gx.reshape(-1)], -1).to(torch.int32).to(self.device).contiguous()
+            self._rope_cache[key] = (pos, cs)
+        return self._rope_cache[key]
+
+    def _as_images(self, img) -> torch.Tensor:
+        """uint8 [H,W,3] or [B,H,W,3], numpy or tensor -> device uint8 [B,H,W,3]."""
+        if isinstance(img, np.ndarray):
+            img = torch.from_numpy(np.ascontiguousarray(img))
+        if img.dtype != torch.uint8:
+            raise TypeError("images must be uint8 [H,W,3] (frame_to_numpy, mast3r_utils.py:210-226)")
+        if img.dim() == 3:
+            img = img[None]
+        if img.shape[-1] != 3 or img.shape[1] % 16 or img.shape[2] % 16:
+            raise ValueError(f"images must be [B,H,W,3] with H,W multiples of 16, got {tuple(img.shape)}")
+        return img.to(self.device).contiguous()
+
+    def _self_attn(self, xn, p, heads, nb, t, pos, cs):
+        P = self.P
+        c = heads * 64
+        qkv = ops.gemm(xn, P[p + ".qkv.w"], P[p + ".qkv.b"], ops.EPI_BF16)              # [M,3c]
+        ops.rope2d_(qkv, pos, cs, row_stride=3 * c, tokens=nb * t, heads=2 * heads, tokens_per_image=t)
+        out = torch.empty((nb * t, c), dtype=torch.bfloat16, device=xn.device)
+        ops.attention(qkv, qkv[:, c:], qkv[:, 2 * c:], out, nbatch=nb, heads=heads, tq=t, tk=t,
+                      q_row_stride=3 * c, kv_row_stride=3 * c, o_row_stride=c, q_batch_stride=t * 3 * c,
+                      kv_batch_stride=t * 3 * c, o_batch_stride=t * c)
+        return out
+
+    # ------------------------------------------------------------------ encoder
+    def encode_tokens(self, imgs_u8: torch.Tensor):
+        """uint8 [B,H,W,3] -> (enc_norm tokens bf16 [B*T,1024], (gh,gw))."""
+        P, c = self.P, self.cfg
+        b, h, w, _ = imgs_u8.shape
+        gh, gw = h // 16, w // 16
+        t = gh * gw
+        if t % 128:
+            raise ValueError(f"token count {t} must be a multiple of 128 (e.g. 512x512, 512x384)")
+        pos, cs = self._rope(gh, gw)
+        x = ops.gemm(ops.patchify16(imgs_u8), P["patch.w"], P["patch.b"], ops.EPI_F32)   # fp32 residual stream
+        for i in range(c["enc_depth"]):
+            p = f"enc_blocks.{i}"
+            xn = ops.layernorm(x, P[p + ".norm1.g"], P[p + ".norm1.b"])
+            a = self._self_attn(xn, p + ".attn", c["enc_heads"], b, t, pos, cs)
+            ops.gemm(a, P[p + ".attn.proj.w"], P[p + ".attn.proj.b"], ops.EPI_F32_ACCUM, out=x, resid=x)
+            xn = ops.layernorm(x, P[p + ".norm2.g"], P[p + ".norm2.b"])
+            hdn = ops.gemm(xn, P[p + ".mlp.fc1.w"], P[p + ".mlp.fc1.b"], ops.EPI_BF16_GELU)
+            ops.gemm(hdn, P[p + ".mlp.fc2.w"], P[p + ".mlp.fc2.b"], ops.EPI_F32_ACCUM, out=x, resid=x)
+        return ops.layernorm(x, P["enc_norm.g"], P["enc_norm.b"]), (gh, gw)
+
+    def encode(self, img):
+        """model.encode(img) (mast3r_utils.py:278): uint8 [H,W,3] -> tokens [T,1024] (bf16 tensor);
+        a batch [B,H,W,3] gives [B,T,1024]."""
+        imgs = self._as_images(img)
+        tok, _ = self.encode_tokens(imgs)
+        tok = tok.view(imgs.shape[0], -1, self.embed_dim)
+        return tok[0] if (not isinstance(img, torch.Tensor) or img.dim() == 3) and imgs.shape[0] == 1 else tok
+
+    # ------------------------------------------------------------------ decoder
+    def decode_tokens(self, f1: torch.Tensor, f2: torch.Tensor, npairs: int, grid):
+        """f1, f2 bf16 [P*T,1024] (enc_norm outputs of view 1 / view 2) -> two lists of DPT taps
+        (bf16 [P*T,C]) at hooks (0, 6, 9, 12)."""
+        P, c = self.P, self.cfg
+        gh, gw = grid
+        t = gh * gw
+        pos, cs = self._rope(gh, gw)
+        D, heads = c["dec_dim"], c["dec_heads"]
+        m = npairs * t
+        xs = [ops.gemm(f, P["decoder_embed.w"], P["decoder_embed.b"], ops.EPI_F32) for f in (f1, f2)]
+        taps = [[f1], [f2]]
+        hooks = set(c["hooks"])
+        for i in range(c["dec_depth"]):
+            names = (f"dec_blocks.{i}", f"dec_blocks2.{i}")
+            # cross-attention memories come from the PREVIOUS layer's tokens of the other view
+            kvs = []
+            for v, p in enumerate(names):
+                yn = ops.layernorm(xs[1 - v], P[p + ".norm_y.g"], P[p + ".norm_y.b"])
+                kv = ops.gemm(yn, P[p + ".cross_attn.kv.w"], P[p + ".cross_attn.kv.b"], ops.EPI_BF16)  # [M,2D]
+                ops.rope2d_(kv, pos, cs, row_stride=2 * D, tokens=m, heads=heads, tokens_per_image=t)
+                kvs.append(kv)
+            for v, p in enumerate(names):
+                x = xs[v]
+                xn = ops.layernorm(x, P[p + ".norm1.g"], P[p + ".norm1.b"])
+                a = self._self_attn(xn, p + ".attn", heads, npairs, t, pos, cs)
+                ops.gemm(a, P[p + ".attn.proj.w"], P[p + ".attn.proj.b"], ops.EPI_F32_ACCUM, out=x, resid=x)
+                xn = ops.layernorm(x, P[p + ".norm2.g"], P[p + ".norm2.b"])
+                q = ops.gemm(xn, P[p + ".cross_attn.projq.w"], P[p + ".cross_attn.projq.b"], ops.EPI_BF16)
+                ops.rope2d_(q, pos, cs, row_stride=D, tokens=m, heads=heads, tokens_per_image=t)
+                kv = kvs[v]
+                a = torch.empty((m, D), dtype=torch.bfloat16, device=x.device)
+                ops.attention(q, kv, kv[:, D:], a, nbatch=npairs, heads=heads, tq=t, tk=t, q_row_stride=D,
+                              kv_row_stride=2 * D, o_row_stride=D, q_batch_stride=t * D,
+                              kv_batch_stride=t * 2 * D, o_batch_stride=t * D)
+                ops.gemm(a, P[p + ".cross_attn.proj.w"], P[p + ".cross_attn.proj.b"], ops.EPI_F32_ACCUM, out=x, resid=x)
+                xn = ops.layernorm(x, P[p + ".norm3.g"], P[p + ".norm3.b"])
+                hdn = ops.gemm(xn, P[p + ".mlp.fc1.w"], P[p + ".mlp.fc1.b"], ops.EPI_BF16_GELU)
+                ops.gemm(hdn, P[p + ".mlp.fc2.w"], P[p + ".mlp.fc2.b"], ops.EPI_F32_ACCUM, out=x, resid=x)
+            layer = i + 1
+            if layer in hooks:
+                for v in range(2):
+                    if layer == c["dec_depth"]:
+                        taps[v].append(ops.layernorm(xs[v], P["dec_norm.g"], P["dec_norm.b"]))
+                    else:
+                        taps[v].append(ops.f32_to_bf16(xs[v]))
+        return taps
+
+    # ------------------------------------------------------------------ heads
+    def _rcu(self, x, q):
+        P = self.P
+        c1 = ops.conv3x3(ops.relu(x), P[q + ".conv1.w"], P[q + ".conv1.b"], ops.EPI_BF16_RELU)
+        return ops.conv3x3(c1, P[q + ".conv2.w"], P[q + ".conv2.b"], ops.EPI_BF16_ADD, resid=x)
+
+    def _fusion(self, q, x0, x1=None):
+        P = self.P
+        out = x0 if x1 is None else ops.add(x0, self._rcu(x1, q + ".resConfUnit1"))
+        out = ops.upsample2x(self._rcu(out, q + ".resConfUnit2"))
+        b, h, w, ch = out.shape
+        return ops.gemm(out.view(-1, ch), P[q + ".out_conv.w"], P[q + ".out_conv.b"], ops.EPI_BF16).view(b, h, w, -1)
+
+    def head(self, hname: str, taps, npairs: int, grid):
+        """taps: 4 bf16 [P*T,C] tensors -> dict(pts3d [P,H,W,3], conf [P,H,W], desc [P,H,W,24], desc_conf [P,H,W])."""
+        P, c = self.P, self.cfg
+        gh, gw = grid
+        m = npairs * gh * gw
+        p = hname + ".dpt"
+        ld = c["layer_dims"]
+        dev = taps[0].device
+        # act_postprocess
+        k0 = _ceil64(ld[0])
+        t0 = torch.zeros((m, k0), dtype=torch.bfloat16, device=dev) if k0 != ld[0] else None
+        t0 = ops.gemm(taps[0], P[p + ".act_postprocess.0.0.w"], P[p + ".act_postprocess.0.0.b"], ops.EPI_BF16, out=t0)
+        u0 = ops.gemm(t0, P[p + ".act_postprocess.0.1.w"], P[p + ".act_postprocess.0.1.b"], ops.EPI_BF16)
+        l0 = ops.unshuffle(u0, npairs, gh, gw, 4, ld[0], _ceil64(ld[0]))
+        k1 = _ceil64(ld[1])
+        t1 = torch.zeros((m, k1), dtype=torch.bfloat16, device=dev) if k1 != ld[1] else None
+        t1 = ops.gemm(taps[1], P[p + ".act_postprocess.1.0.w"], P[p + ".act_postprocess.1.0.b"], ops.EPI_BF16, out=t1)
+        u1 = ops.gemm(t1, P[p + ".act_postprocess.1.1.w"], P[p + ".act_postprocess.1.1.b"], ops.EPI_BF16)
+        l1 = ops.unshuffle(u1, npairs, gh, gw, 2, ld[1], _ceil64(ld[1]))
+        l2 = ops.gemm(taps[2], P[p + ".act_postprocess.2.0.w"], P[p + ".act_postprocess.2.0.b"], ops.EPI_BF16)
+        l2 = l2.view(npairs, gh, gw, ld[2])
+        t3 = ops.gemm(taps[3], P[p + ".act_postprocess.3.0.w"], P[p + ".act_postprocess.3.0.b"], ops.EPI_BF16)
+        l3 = ops.conv3x3(t3.view(npairs, gh, gw, ld[3]), P[p + ".act_postprocess.3.1.w"],
+                         P[p + ".act_postprocess.3.1.b"], ops.EPI_BF16, stride=2)
+        rn = [ops.conv3x3(l, P[p + f".scratch.layer_rn.{i}.w"], None, ops.EPI_BF16)
+              for i, l in enumerate((l0, l1, l2, l3))]
+        path = self._fusion(p + ".scratch.refinenet4", rn[3])
+        path = self._fusion(p + ".scratch.refinenet3", path, rn[2])
+        path = self._fusion(p + ".scratch.refinenet2", path, rn[1])
+        path = self._fusion(p + ".scratch.refinenet1", path, rn[0])
+        h0 = ops.upsample2x(ops.conv3x3(path, P[p + ".head.0.w"], P[p + ".head.0.b"], ops.EPI_BF16))
+        h2 = ops.conv3x3(h0, P[p + ".head.2.w"], P[p + ".head.2.b"], ops.EPI_BF16_RELU)
+        b, h, w, ch = h2.shape
+        raw = ops.gemm(h2.view(-1, ch), P[p + ".head.4.w"], P[p + ".head.4.b"], ops.EPI_F32)
+        pts, conf = ops.pts_post(raw.view(b, h, w, 4))
+        # local features
+        q = hname + ".head_local_features"
+        cat = ops.concat2(taps[0], taps[3])
+        f = ops.gemm(cat, P[q + ".fc1.w"], P[q + ".fc1.b"], ops.EPI_BF16_GELU)
+        f = ops.gemm(f, P[q + ".fc2.w"], P[q + ".fc2.b"], ops.EPI_BF16)
+        desc, dconf = ops.desc_post(f, npairs, gh * 16, gw * 16)
+        return dict(pts3d=pts, conf=conf, desc=desc, desc_conf=dconf)
+
+    # ------------------------------------------------------------------ public two-view API
+    def reconstruct_batch(self, imgs1: torch.Tensor, imgs2: torch.Tensor):
+        """P pairs at once: uint8 [P,H,W,3] x2 -> (out1, out2), dicts with a leading pair axis.
+        Both outputs are expressed in view 1's frame (mast3r_utils.py:329-343)."""
+        imgs1, imgs2 = self._as_images(imgs1), self._as_images(imgs2)
+        if imgs1.shape != imgs2.shape:
+            raise ValueError("both views must have the same shape")
+        npairs = imgs1.shape[0]
+        tok, grid = self.encode_tokens(torch.cat([imgs1, imgs2], 0))
+        m = npairs * grid[0] * grid[1]
+        return self.decode_heads(tok[:m], tok[m:], npairs, grid)
+
+    def decode_heads(self, f1, f2, npairs, grid):
+        """Decoder + both heads from cached encoder tokens (bf16 [P*T,1024] each)."""
+        taps = self.decode_tokens(f1.reshape(-1, self.embed_dim), f2.reshape(-1, self.embed_dim), npairs, grid)
+        return (self.head("downstream_head1", taps[0], npairs, grid),
+                self.head("downstream_head2", taps[1], npairs, grid))
+
+    def reconstruct(self, img1, img2):
+        """model.reconstruct(img1, img2) (mast3r_utils.py:281,355): uint8 [H,W,3] x2 -> two dicts with
+        pts3d [H,W,3], conf [H,W,1], desc [H,W,24], desc_conf [H,W] (device tensors)."""
+        o1, o2 = self.reconstruct_batch(self._as_images(img1), self._as_images(img2))
+
+        def one(o):
+            return dict(pts3d=o["pts3d"][0], conf=o["conf"][0][..., None], desc=o["desc"][0], desc_conf=o["desc_conf"][0])
+        return one(o1), one(o2)
+
+    def flops_per_pair(self, h: int = 512, w: int = 512) -> float:
+        """Algorithmic FLOPs (2*MAC) of one reconstruct() call, from this model's own layer table."""
+        c = self.cfg
+        t = (h // 16) * (w // 16)
+        E, D, r = c["enc_dim"], c["dec_dim"], c["mlp_ratio"]
+        enc = c["enc_depth"] * (2 * t * E * 3 * E + 2 * t * E * E + 4 * t * E * r * E + 4 * t * t * E) + 2 * t * 768 * E
+        dec = c["dec_depth"] * (2 * t * D * 3 * D + 2 * t * D * D + 4 * t * t * D          # self
+                                + 4 * 2 * t * D * D + 4 * t * t * D                          # cross (q,k,v,proj)
+                                + 4 * t * D * r * D) + 2 * t * E * D
+        feat = 2 * t * (E + D) * r * (E + D) + 2 * t * r * (E + D) * 25 * 256
+        F_, ld = c["feat_dim"], c["layer_dims"]
+        gh, gw = h // 16, w // 16
+        px = [gh * 4 * gw * 4, gh * 2 * gw * 2, gh * gw, gh * gw // 4]
+        conv = lambda n, ci, co, k: 2.0 * n * ci * co * k * k
+        dpt = (conv(t, E, ld[0], 1) + conv(t, ld[0], ld[0] * 16, 1) + conv(t, D, ld[1], 1) + conv(t, ld[1], ld[1] * 4, 1)
+               + conv(t, D, ld[2], 1) + conv(t, D, ld[3], 1) + conv(px[3], ld[3], ld[3], 3)
+               + sum(conv(px[i], ld[i], F_, 3) for i in range(4))
+               + 2 * conv(px[3], F_, F_, 3) + conv(px[3] * 4, F_, F_, 1)
+               + sum(4 * conv(px[i], F_, F_, 3) + conv(px[i] * 4, F_, F_, 1) for i in (2, 1, 0))
+               + conv(px[0] * 4, F_, F_ // 2, 3) + conv(px[0] * 16, F_ // 2, c["last_dim"], 3) + conv(px[0] * 16, c["last_dim"], 4, 1))
+        return 2.0 * (enc + dec + feat + dpt)

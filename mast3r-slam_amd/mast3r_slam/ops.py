@@ -1,0 +1,201 @@
+"""Thin torch-tensor wrappers over the network operators of the C ABI (include/m3slam_model.h).
+
+bf16 activations / weights, fp32 accumulation.  All ops are stream-ordered; outputs are
+allocated by the caller-facing wrapper (torch caching allocator) and passed as raw pointers.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _ffi
+
+EPI_BF16, EPI_BF16_GELU, EPI_F32, EPI_F32_ACCUM, EPI_BF16_RELU, EPI_BF16_ADD = range(6)
+_F32_EPIS = (EPI_F32, EPI_F32_ACCUM)
+
+_zero16 = {}
+
+# When set to a list, every MFMA GEMM / implicit-GEMM conv launch appends
+# (kind, algorithmic_flops, start_event, end_event): events are recorded on the current stream,
+# i.e. the stream the kernel is launched on (bench.py's roofline measurement).
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(e0, kind, flops):
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PROFILE.append((kind, flops, e0, e1))
+
+
+def zero_page(dev):
+    """16 zero bytes on `dev` (padding source of the implicit-GEMM convolution)."""
+    z = _zero16.get(dev)
+    if z is None:
+        z = torch.zeros(64, dtype=torch.uint8, device=dev)
+        _zero16[dev] = z
+    return z
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, epi: int = EPI_BF16, out=None, resid=None):
+    """out[M,N] = epi(a[M,K] @ w[N,K].T + bias).  a, w bf16; out bf16 or f32 by epilogue."""
+    a = _ffi.check(a, torch.bfloat16, "a")
+    w = _ffi.check(w, torch.bfloat16, "w")
+    m, k = a.shape
+    n = w.shape[0]
+    if w.shape[1] != k:
+        raise ValueError(f"K mismatch: a {tuple(a.shape)} vs w {tuple(w.shape)}")
+    odt = torch.float32 if epi in _F32_EPIS else torch.bfloat16
+    if out is None:
+        out = torch.empty((m, n), dtype=odt, device=a.device)
+    else:
+        if out.dtype != odt or out.shape[0] != m or out.shape[1] < n or out.stride(1) != 1:
+            raise ValueError("bad `out`")
+    ldc = out.stride(0)
+    if bias is not None:
+        bias = _ffi.check(bias, torch.float32, "bias", (n,))
+    if resid is not None and (resid.dtype != odt or resid.stride(0) != ldc):
+        raise ValueError("residual must match out dtype/stride")
+    e0 = _prof_begin()
+    _ffi.call("m3_gemm_bf16", _ffi.ptr(a), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(out), _ffi.ptr(resid),
+              m, n, k, ldc, epi, _ffi.stream_ptr())
+    _prof_end(e0, "gemm", 2.0 * m * n * k)
+    return out
+
+
+def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, epi: int = EPI_BF16, stride: int = 1, resid=None, out=None):
+    """x NHWC bf16 [B,H,W,Cin], w bf16 [Cout,3,3,Cin] -> NHWC [B,OH,OW,Cout], padding 1."""
+    x = _ffi.check(x, torch.bfloat16, "x")
+    w = _ffi.check(w, torch.bfloat16, "w")
+    b, h, wd, cin = x.shape
+    cout = w.shape[0]
+    if tuple(w.shape[1:]) != (3, 3, cin):
+        raise ValueError(f"weight must be [Cout,3,3,{cin}], got {tuple(w.shape)}")
+    oh, ow = (h + 2 - 3) // stride + 1, (wd + 2 - 3) // stride + 1
+    odt = torch.float32 if epi in _F32_EPIS else torch.bfloat16
+    if out is None:
+        out = torch.empty((b, oh, ow, cout), dtype=odt, device=x.device)
+    if bias is not None:
+        bias = _ffi.check(bias, torch.float32, "bias", (cout,))
+    if resid is not None:
+        resid = _ffi.check(resid, odt, "resid", (b, oh, ow, cout))
+    e0 = _prof_begin()
+    _ffi.call("m3_conv3x3_bf16", _ffi.ptr(x), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(out), _ffi.ptr(resid),
+              _ffi.ptr(zero_page(x.device)), b, h, wd, cin, cout, stride, epi, _ffi.stream_ptr())
+    _prof_end(e0, "conv3x3", 2.0 * b * oh * ow * cout * 9 * cin)
+    return out
+
+
+def attention(q, k, v, out, *, nbatch, heads, tq, tk, q_row_stride, kv_row_stride, o_row_stride,
+              q_batch_stride, kv_batch_stride, o_batch_stride, kv_batch_shift=0, scale=0.125):
+    """Fused MHA (head dim 64).  q/k/v/out are (views into) bf16 device tensors; the strides are in
+    elements, so q, k, v may be column slices of one projection buffer."""
+    for name, t in (("q", q), ("k", k), ("v", v), ("out", out)):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.bfloat16):
+            raise TypeError(f"{name}: expected a bf16 tensor on the ROCm device")
+    e0 = _prof_begin()
+    _ffi.call("m3_attention_bf16", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q_row_stride,
+              kv_row_stride, o_row_stride, q_batch_stride, kv_batch_stride, o_batch_stride, nbatch, heads, tq, tk,
+              kv_batch_shift, float(scale), _ffi.stream_ptr())
+    _prof_end(e0, "attention", 4.0 * nbatch * heads * tq * tk * 64)
+    return out
+
+
+def rope2d_(x, pos_yx, cos_sin, *, row_stride, tokens, heads, tokens_per_image):
+    """In-place RoPE-2D on `heads` 64-wide heads starting at x.data_ptr()."""
+    _ffi.call("m3_rope2d_bf16", x.data_ptr(), _ffi.ptr(pos_yx), _ffi.ptr(cos_sin), row_stride, tokens, heads,
+              tokens_per_image, _ffi.stream_ptr())
+    return x
+
+
+def layernorm(x, gamma, beta, eps=1e-6, out=None):
+    x = _ffi.check(x, torch.float32, "x")
+    m, c = x.shape
+    if out is None:
+        out = torch.empty((m, c), dtype=torch.bfloat16, device=x.device)
+    _ffi.call("m3_layernorm_bf16", _ffi.ptr(x), _ffi.ptr(gamma), _ffi.ptr(beta), _ffi.ptr(out), m, c, float(eps),
+              _ffi.stream_ptr())
+    return out
+
+
+def patchify16(img_u8):
+    img_u8 = _ffi.check(img_u8, torch.uint8, "img")
+    b, h, w, _ = img_u8.shape
+    out = torch.empty((b * (h // 16) * (w // 16), 768), dtype=torch.bfloat16, device=img_u8.device)
+    _ffi.call("m3_patchify16", _ffi.ptr(img_u8), _ffi.ptr(out), b, h, w, _ffi.stream_ptr())
+    return out
+
+
+def f32_to_bf16(x):
+    x = _ffi.check(x, torch.float32, "x")
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _ffi.call("m3_f32_to_bf16", _ffi.ptr(x), _ffi.ptr(out), x.numel(), _ffi.stream_ptr())
+    return out
+
+
+def relu(x):
+    x = _ffi.check(x, torch.bfloat16, "x")
+    out = torch.empty_like(x)
+    _ffi.call("m3_relu_bf16", _ffi.ptr(x), _ffi.ptr(out), x.numel(), _ffi.stream_ptr())
+    return out
+
+
+def concat2(a, b):
+    a = _ffi.check(a, torch.bfloat16, "a")
+    b = _ffi.check(b, torch.bfloat16, "b")
+    m = a.shape[0]
+    out = torch.empty((m, a.shape[1] + b.shape[1]), dtype=torch.bfloat16, device=a.device)
+    _ffi.call("m3_concat2_bf16", _ffi.ptr(a), _ffi.ptr(b), _ffi.ptr(out), m, a.shape[1], b.shape[1],
+              _ffi.stream_ptr())
+    return out
+
+
+def unshuffle(x, b, h, w, s, c, cpad=None):
+    """[B*h*w, s*s*c] -> NHWC [B,h*s,w*s,cpad] (extra channels zero)."""
+    cpad = cpad or c
+    x = _ffi.check(x, torch.bfloat16, "x", (b * h * w, s * s * c))
+    alloc = torch.zeros if cpad != c else torch.empty
+    out = alloc((b, h * s, w * s, cpad), dtype=torch.bfloat16, device=x.device)
+    _ffi.call("m3_unshuffle_bf16", _ffi.ptr(x), _ffi.ptr(out), b, h, w, s, c, cpad, _ffi.stream_ptr())
+    return out
+
+
+def upsample2x(x):
+    x = _ffi.check(x, torch.bfloat16, "x")
+    b, h, w, c = x.shape
+    out = torch.empty((b, 2 * h, 2 * w, c), dtype=torch.bfloat16, device=x.device)
+    _ffi.call("m3_upsample2x_bf16", _ffi.ptr(x), _ffi.ptr(out), b, h, w, c, _ffi.stream_ptr())
+    return out
+
+
+def pts_post(raw):
+    """[...,4] f32 -> pts3d [...,3], conf [...]."""
+    raw = _ffi.check(raw, torch.float32, "raw")
+    p = raw.numel() // 4
+    pts = torch.empty(raw.shape[:-1] + (3,), dtype=torch.float32, device=raw.device)
+    conf = torch.empty(raw.shape[:-1], dtype=torch.float32, device=raw.device)
+    _ffi.call("m3_pts_post", _ffi.ptr(raw), _ffi.ptr(pts), _ffi.ptr(conf), p, _ffi.stream_ptr())
+    return pts, conf
+
+
+def desc_post(f, b, h, w):
+    f = _ffi.check(f, torch.bfloat16, "f", (b * (h // 16) * (w // 16), 6400))
+    desc = torch.empty((b, h, w, 24), dtype=torch.float32, device=f.device)
+    dconf = torch.empty((b, h, w), dtype=torch.float32, device=f.device)
+    _ffi.call("m3_desc_post", _ffi.ptr(f), _ffi.ptr(desc), _ffi.ptr(dconf), b, h, w, _ffi.stream_ptr())
+    return desc, dconf
+
+
+def add(a, b):
+    a = _ffi.check(a, torch.bfloat16, "a")
+    b = _ffi.check(b, torch.bfloat16, "b", tuple(a.shape))
+    out = torch.empty_like(a)
+    _ffi.call("m3_add_bf16", _ffi.ptr(a), _ffi.ptr(b), _ffi.ptr(out), a.numel(), _ffi.stream_ptr())
+    return out

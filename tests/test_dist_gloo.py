@@ -1,0 +1,72 @@
+"""CPU: the N>1 path (pair sharding + the single packed all-gather) with world_size 2 on gloo."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mast3r_slam import dist as m3dist
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pairs = list(m3dist.shard_range(5, rank, world))
+        g = torch.Generator().manual_seed(100 + rank)
+        p = 3                                                    # equal per-rank batch (weak scaling)
+        X = torch.randn(p, 4, 6, 3, generator=g)
+        idx = torch.randint(0, 24, (p, 24), generator=g)
+        valid = torch.rand(p, 24, 1, generator=g) > 0.5
+        pose = torch.randn(p, 8, generator=g)
+        out = m3dist.all_gather_results((X, idx, valid, pose))
+        ok = True
+        for r in range(world):
+            gr = torch.Generator().manual_seed(100 + r)
+            Xr = torch.randn(p, 4, 6, 3, generator=gr); ir = torch.randint(0, 24, (p, 24), generator=gr)
+            vr = torch.rand(p, 24, 1, generator=gr) > 0.5; pr = torch.randn(p, 8, generator=gr)
+            sl = slice(r * p, (r + 1) * p)
+            ok &= torch.equal(out[0][sl], Xr) and torch.equal(out[1][sl], ir)
+            ok &= torch.equal(out[2][sl], vr) and torch.equal(out[3][sl], pr)
+        ok &= out[1].dtype == torch.int64 and out[2].dtype == torch.bool and out[0].shape == (world * p, 4, 6, 3)
+        q.put((rank, ok, pairs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_shard_and_all_gather():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert res[0][2] == [0, 1, 2] and res[1][2] == [3, 4]       # block partition, remainder to low ranks
+
+
+def test_shard_range_covers_everything_once():
+    for total in (0, 1, 7, 64, 1524):
+        for world in (1, 2, 3, 8):
+            got = [i for r in range(world) for i in m3dist.shard_range(total, r, world)]
+            assert got == list(range(total))
+
+
+def test_pack_unpack_roundtrip_single_rank():
+    ts = (torch.randn(2, 5, 3), torch.arange(14, dtype=torch.int64).view(2, 7), torch.tensor([[True], [False]]),
+          torch.randn(2, 8).to(torch.bfloat16))
+    buf, meta = m3dist.pack(ts)
+    assert buf.numel() % 16 == 0
+    out = m3dist.unpack(buf[None], meta, 1)
+    assert all(torch.equal(a, b) for a, b in zip(ts, out))

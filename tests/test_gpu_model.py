@@ -1,0 +1,199 @@
+"""GPU parity: network operators (through the C ABI) vs plain PyTorch fp32 references of the same
+op, and the two-view network end to end vs the torch-CPU fp32 oracle (oracle/model.py).
+bf16 storage rounds to 8 significant bits (2^-9 relative), so tolerances are stated per test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from mast3r_slam import mast3r_utils, model as M, ops, synthetic
+from mast3r_slam.frame import create_frame
+from oracle import model as OM
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.float().cpu() - b.float().cpu()).norm() / b.float().cpu().norm())
+
+
+@pytest.mark.parametrize("epi", [ops.EPI_BF16, ops.EPI_BF16_GELU, ops.EPI_F32, ops.EPI_F32_ACCUM, ops.EPI_BF16_RELU,
+                                 ops.EPI_BF16_ADD])
+@pytest.mark.parametrize("shape", [(256, 256, 128), (300, 132, 64), (2048, 768, 3072), (128, 4, 64)])
+def test_gemm_epilogues(dev, epi, shape):
+    m, n, k = shape
+    g = torch.Generator(device="cpu").manual_seed(m + n + k + epi)
+    a = torch.randn(m, k, generator=g).bfloat16()
+    w = (torch.randn(n, k, generator=g) * 0.05).bfloat16()
+    b = torch.randn(n, generator=g)
+    ref = a.float() @ w.float().T + b
+    r = None
+    if epi == ops.EPI_BF16_GELU:
+        ref = F.gelu(ref)
+    if epi == ops.EPI_BF16_RELU:
+        ref = torch.relu(ref)
+    if epi == ops.EPI_F32_ACCUM:
+        r = torch.randn(m, n, generator=g); ref = ref + r
+    if epi == ops.EPI_BF16_ADD:
+        r = torch.randn(m, n, generator=g).bfloat16(); ref = ref + r.float()
+    out = ops.gemm(a.to(dev), w.to(dev), b.to(dev), epi, resid=None if r is None else r.to(dev))
+    f32 = epi in (ops.EPI_F32, ops.EPI_F32_ACCUM)
+    assert out.dtype == (torch.float32 if f32 else torch.bfloat16)
+    assert _rel(out, ref) < (2e-6 if f32 else 3e-3)            # fp32 accumulate; bf16 output rounding 2^-9
+
+
+def test_gemm_layout_identity_asymmetric(dev):
+    """A = I with an asymmetric W catches a transposed C write (guide: 'A=I-check with ASYMMETRIC B')."""
+    eye = torch.eye(128, device=dev).bfloat16()
+    w = (torch.arange(128 * 128, device=dev).reshape(128, 128) % 251).float().bfloat16()
+    assert torch.equal(ops.gemm(eye, w, None, ops.EPI_F32), w.float().T)
+
+
+def test_gemm_rejects_bad_k(dev):
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        ops.gemm(torch.zeros(128, 96, device=dev).bfloat16(), torch.zeros(128, 96, device=dev).bfloat16())
+
+
+@pytest.mark.parametrize("cfg", [(2, 16, 16, 64, 128, 1), (1, 32, 32, 256, 256, 1), (1, 32, 32, 128, 64, 2),
+                                 (1, 20, 28, 64, 36, 1)])
+def test_conv3x3_implicit_gemm(dev, cfg):
+    b, h, w_, cin, cout, s = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = torch.randn(b, h, w_, cin, generator=g).bfloat16()
+    w = (torch.randn(cout, 3, 3, cin, generator=g) * 0.05).bfloat16()
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias, stride=s, padding=1).permute(0, 2, 3, 1)
+    out = ops.conv3x3(x.to(dev), w.to(dev), bias.to(dev), ops.EPI_F32, stride=s)
+    assert tuple(out.shape) == tuple(ref.shape) and _rel(out, ref) < 2e-6
+    res = torch.randn(ref.shape, generator=g).bfloat16()
+    out = ops.conv3x3(x.to(dev), w.to(dev), bias.to(dev), ops.EPI_BF16_ADD, stride=s, resid=res.to(dev))
+    assert _rel(out, ref + res.float()) < 3e-3
+
+
+@pytest.mark.parametrize("cross", [False, True])
+def test_attention_vs_softmax_reference(dev, cross):
+    b, h, t = 2, 3, 256
+    g = torch.Generator().manual_seed(7)
+    c = h * 64
+    qkv = torch.randn(b * t, 3 * c, generator=g).bfloat16()
+    qkv[5, :64] *= 30.0                                           # a spiked query: exercises the running-max rescale
+    out = torch.empty(b * t, c, dtype=torch.bfloat16, device=dev)
+    d = qkv.to(dev)
+    ops.attention(d, d[:, c:], d[:, 2 * c:], out, nbatch=b, heads=h, tq=t, tk=t, q_row_stride=3 * c,
+                  kv_row_stride=3 * c, o_row_stride=c, q_batch_stride=t * 3 * c, kv_batch_stride=t * 3 * c,
+                  o_batch_stride=t * c, kv_batch_shift=1 if cross else 0)
+    q = qkv[:, :c].float().view(b, t, h, 64).transpose(1, 2)
+    k = qkv[:, c:2 * c].float().view(b, t, h, 64).transpose(1, 2)
+    v = qkv[:, 2 * c:].float().view(b, t, h, 64).transpose(1, 2)
+    if cross:
+        k, v = k.roll(-1, 0), v.roll(-1, 0)                      # batch item i attends item (i+1) % b
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).transpose(1, 2).reshape(b * t, c)
+    assert _rel(out, ref) < 4e-3                                  # P and O are bf16
+    assert torch.isfinite(out).all()
+
+
+def test_rope2d_layernorm_and_elementwise(dev):
+    g = torch.Generator().manual_seed(3)
+    gh, gw, heads = 8, 16, 4
+    t = gh * gw
+    x = torch.randn(2 * t, heads * 64, generator=g).bfloat16()
+    pos = OM.patch_positions(gh * 16, gw * 16)
+    cos, sin = OM.rope_tables(17)
+    ref = OM.rope2d(x.float().view(2, t, heads, 64).transpose(1, 2), pos, cos, sin).transpose(1, 2).reshape(2 * t, -1)
+    cs = torch.stack([cos, sin], -1).to(dev).contiguous()
+    xd = x.to(dev).clone()
+    ops.rope2d_(xd, pos.to(torch.int32).to(dev), cs, row_stride=heads * 64, tokens=2 * t, heads=heads, tokens_per_image=t)
+    assert _rel(xd, ref) < 3e-3
+    # LayerNorm (C = 768 and 1024)
+    for c in (768, 1024):
+        xf = torch.randn(37, c, generator=g) * 3 + 1
+        gm, bt = torch.randn(c, generator=g), torch.randn(c, generator=g)
+        out = ops.layernorm(xf.to(dev), gm.to(dev), bt.to(dev))
+        assert _rel(out, F.layer_norm(xf, (c,), gm, bt, 1e-6)) < 3e-3
+    # bilinear x2 align_corners, un-shuffle, concat, relu, add
+    y = torch.randn(2, 5, 7, 16, generator=g).bfloat16()
+    ref = F.interpolate(y.float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    assert _rel(ops.upsample2x(y.to(dev)), ref) < 3e-3
+    z = torch.randn(2 * 3 * 4, 4 * 8, generator=g).bfloat16()    # s=2, C=8
+    un = ops.unshuffle(z.to(dev), 2, 3, 4, 2, 8, 16).cpu()
+    ref = z.view(2, 3, 4, 2, 2, 8).permute(0, 1, 3, 2, 4, 5).reshape(2, 6, 8, 8)
+    assert torch.equal(un[..., :8], ref) and bool((un[..., 8:] == 0).all())
+    a, b = torch.randn(9, 16, generator=g).bfloat16(), torch.randn(9, 24, generator=g).bfloat16()
+    assert torch.equal(ops.concat2(a.to(dev), b.to(dev)).cpu(), torch.cat([a, b], 1))
+    r = torch.randn(64, generator=g).bfloat16()
+    assert torch.equal(ops.relu(r.to(dev)).cpu(), torch.relu(r))
+    assert torch.equal(ops.add(r.to(dev), r.to(dev)).cpu(), (r.float() * 2).bfloat16())
+
+
+def test_heads_postprocessing(dev):
+    g = torch.Generator().manual_seed(11)
+    raw = torch.randn(2, 16, 16, 4, generator=g)
+    pts, conf = ops.pts_post(raw.to(dev))
+    d = raw[..., :3].norm(dim=-1, keepdim=True)
+    assert _rel(pts, raw[..., :3] / d * torch.expm1(d)) < 1e-6 and _rel(conf, 1 + raw[..., 3].exp()) < 1e-6
+    f = torch.randn(2 * 1 * 2, 6400, generator=g).bfloat16()      # B=2, 16x32 image
+    desc, dconf = ops.desc_post(f.to(dev), 2, 16, 32)
+    ps = F.pixel_shuffle(f.float().view(2, 2, 6400).transpose(1, 2).reshape(2, 6400, 1, 2), 16).permute(0, 2, 3, 1)
+    assert _rel(desc, ps[..., :24] / ps[..., :24].norm(dim=-1, keepdim=True)) < 1e-6
+    assert _rel(dconf, ps[..., 24].exp()) < 1e-6
+
+
+@pytest.fixture(scope="module")
+def tiny(dev):
+    cfg = M.TINY_CFG
+    w = M.init_random_weights(cfg, seed=1)
+    return cfg, w, M.Mast3rFull(weights=w, cfg=cfg, device=dev)
+
+
+def test_two_view_network_vs_cpu_oracle(tiny, dev):
+    """Same structure as the full model (2 encoder + 4 decoder blocks, DPT + feature heads) on 128x256
+    images, 2 pairs: pointmaps within 1e-3 rel-L2 of the fp32 oracle (BASELINE target), descriptors
+    within 6e-3 (the feature MLP output is stored in bf16)."""
+    cfg, w, net = tiny
+    h, wd = 128, 256
+    im1 = np.stack([synthetic.textured_image(h, wd, s) for s in (0, 2)])
+    im2 = np.stack([synthetic.textured_image(h, wd, s) for s in (1, 3)])
+    o1, o2 = net.reconstruct_batch(im1, im2)
+    r1, r2 = OM.reconstruct(w, torch.from_numpy(im1), torch.from_numpy(im2), cfg)
+    for o, r in ((o1, r1), (o2, r2)):
+        assert o["pts3d"].shape == (2, h, wd, 3) and o["desc"].shape == (2, h, wd, 24)
+        assert _rel(o["pts3d"], r["pts3d"]) < 1e-3
+        assert _rel(o["conf"], r["conf"]) < 1e-4
+        assert _rel(o["desc"], r["desc"]) < 6e-3
+        assert _rel(o["desc_conf"], r["desc_conf"]) < 6e-3
+        assert float((o["desc"].norm(dim=-1) - 1).abs().max()) < 1e-5
+    # batched == per-pair (pairs are independent units: the sharding invariant)
+    s1, s2 = net.reconstruct_batch(im1[1:], im2[1:])
+    assert torch.equal(s1["pts3d"][0], o1["pts3d"][1]) and torch.equal(s2["desc"][0], o2["desc"][1])
+
+
+def test_operator_api_contract(tiny, dev):
+    """Return tuples and shapes of the reference operator API (mast3r_utils.py:255-500)."""
+    cfg, w, net = tiny
+    h, wd = 128, 256
+    fi = create_frame(0, torch.from_numpy(synthetic.textured_image(h, wd, 0)).to(dev))
+    fj = create_frame(1, torch.from_numpy(synthetic.textured_image(h, wd, 1)).to(dev))
+    Xii, Cii, feat, pos = mast3r_utils.mast3r_inference_mono(net, fi)
+    n, t = h * wd, (h // 16) * (wd // 16)
+    assert Xii.shape == (n, 3) and Cii.shape == (n, 1) and feat.shape == (t, 1024) and pos.shape == (t, 2)
+    X, C, D, Q = mast3r_utils.mast3r_asymmetric_inference(net, fi, fj)
+    assert X.shape == (2, h, wd, 3) and C.shape == (2, h, wd) and D.shape == (2, h, wd, 24) and Q.shape == (2, h, wd)
+    X4, C4, D4, Q4 = mast3r_utils.mast3r_symmetric_inference(net, fi, fj)
+    assert X4.shape == (4, h, wd, 3) and Q4.shape == (4, h, wd)
+    assert torch.equal(X4[0], X[0]) and torch.equal(X4[1], X[1])      # (ii, ji) agree with the asymmetric call
+    out = mast3r_utils.mast3r_match_asymmetric(net, fi, fj)
+    assert len(out) == 8
+    idx, valid, Xi, Ci, Qi, Xj, Cj, Qj = out
+    assert idx.shape == (1, n) and valid.shape == (1, n, 1) and valid.dtype == torch.bool
+    assert Xi.shape == (1, n, 3) and Ci.shape == (1, n, 1) and Qj.shape == (1, n, 1)
+    feats = torch.stack([fi.feat, fj.feat])
+    shp = [torch.tensor([[h, wd]])] * 2
+    sym = mast3r_utils.mast3r_match_symmetric(net, feats, None, feats.flip(0), None, shp, shp)
+    assert len(sym) == 8 and sym[0].shape == (2, n) and sym[2].shape == (2, n, 1) and sym[4].shape == (2, n, 1)
+    Xs, Cs, Ds, Qs = mast3r_utils.mast3r_decode_symmetric_batch(net, feats, None, feats.flip(0), None, shp, shp)
+    assert Xs.shape == (4, 2, h, wd, 3)
+    assert _rel(Xs[0, 0], X[0]) < 1e-6                                 # same decode, batched with others
+    with pytest.raises(ValueError):
+        mast3r_utils.load_mast3r("dunemast3r")

@@ -96,18 +96,14 @@ def main():
         idx, valid = matching.match(o1["pts3d"], o2["pts3d"], o1["desc"], o2["desc"])
         if timers is not None:
             marks.append(ev()); marks[-1].record()
-        poses = []
-        for p in range(P):
-            # frame = view 1 (its own camera), keyframe = view 2; canonical keyframe points stand in
-            # as X_ji (same shapes and data flow as FrameTracker.track, tracker.py:88-123)
-            Xf, Qk, vo, vk, cnt = tracker.track_gather(
-                o1["pts3d"][p].reshape(n, 3), o1["conf"][p].reshape(n), o2["conf"][p].reshape(n),
-                o1["desc_conf"][p].reshape(n), o2["desc_conf"][p].reshape(n), idx[p], valid[p].reshape(n),
-                tcfg["C_conf"], tcfg["Q_conf"])
-            T_WCf, T_rel, info = tracker.opt_pose_ray_dist_sim3(Xf, o2["pts3d"][p].reshape(n, 3), ident, ident, Qk, vo,
-                                                                tcfg, fixed_iters=True)
-            poses.append(T_WCf)
-        poses = torch.stack(poses)
+        # frame = view 1 (its own camera), keyframe = view 2; the keyframe's canonical points stand in as
+        # X_ji (same shapes and data flow as FrameTracker.track, tracker.py:88-123); all P solves batched
+        Xf, Qk, vo, vk, cnt = tracker.track_gather(
+            o1["pts3d"].reshape(P, n, 3), o1["conf"].reshape(P, n), o2["conf"].reshape(P, n),
+            o1["desc_conf"].reshape(P, n), o2["desc_conf"].reshape(P, n), idx, valid.reshape(P, n),
+            tcfg["C_conf"], tcfg["Q_conf"])
+        poses, T_rel, info = tracker.opt_pose_ray_dist_sim3(Xf, o2["pts3d"].reshape(P, n, 3), ident, ident, Qk, vo, tcfg,
+                                                           fixed_iters=True)
         if timers is not None:
             marks.append(ev()); marks[-1].record()
         out = (o1["pts3d"], o2["pts3d"], o1["conf"], o2["conf"], idx, valid, poses)

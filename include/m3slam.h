@@ -96,7 +96,22 @@ int m3_track_gather(const float *Xf_canon, const float *Cf_avg, const float *Ck_
                     uint8_t *valid_opt, uint8_t *valid_kf, int32_t *counts,
                     int N, float C_conf, float Q_conf, void *stream);
 
-/* Number of doubles the tracking workspace needs. */
+/* Batched forms: P independent problems laid out back to back ([P,N,...] arrays, [P,8] poses,
+ * counts int32 [P,2], info double [P,4], ws double [P * m3_track_ws_doubles()]); one launch
+ * sequence serves all P (the per-GPU shard of a keyframe-pair batch). */
+int m3_track_gather_batch(const float *Xf_canon, const float *Cf_avg, const float *Ck_avg,
+                          const float *Qff, const float *Qkf, const int64_t *idx,
+                          const uint8_t *valid_match, float *Xf_g, float *Qk, uint8_t *valid_opt,
+                          uint8_t *valid_kf, int32_t *counts, int P, int N, float C_conf,
+                          float Q_conf, void *stream);
+int m3_track_gn_ray_dist_batch(const float *Xf, const float *Xk, const float *Qk,
+                               const uint8_t *valid, const float *T_WCf, const float *T_WCk,
+                               float *T_WCf_out, float *T_CkCf_out, double *info, double *ws,
+                               int P, int N, int max_iters, float huber_k, float sigma_ray,
+                               float sigma_dist, float rel_error, float delta_norm,
+                               int fixed_iters, void *stream);
+
+/* Number of doubles the tracking workspace needs (per problem). */
 int64_t m3_track_ws_doubles(void);
 
 /* FrameTracker._opt_pose_ray_dist_sim3 (tracker.py:258-324) with _solve (:216-256),

@@ -33,6 +33,13 @@ enum {
 int m3_gemm_bf16(const void *A, const void *W, const float *bias, void *C, const void *R,
                  int M, int N, int K, int ldc, int epilogue, void *stream);
 
+/* Projection GEMM with RoPE-2D fused into the epilogue: C(bf16) = rope(A . W^T + bias) on the
+ * 64-wide heads in columns [0, rope_cols) (q|k of a q|k|v projection), plain bias add beyond.
+ * Row m is token m % tokens_per_image of its image; tables as in m3_rope2d_bf16.  N % 64 == 0. */
+int m3_gemm_bf16_rope(const void *A, const void *W, const float *bias, void *C, int M, int N, int K,
+                      int ldc, const int32_t *pos_yx, const float *cos_sin, int tokens_per_image,
+                      int rope_cols, void *stream);
+
 /* 3x3 convolution, padding 1, stride 1 or 2, as an implicit GEMM: X bf16 NHWC [B,H,W,Cin],
  * W bf16 [Cout,3,3,Cin], Y NHWC [B,OH,OW,Cout].  Cin % 64 == 0, Cout % 4 == 0.  zero16: 16
  * zero bytes in device memory (source of the padding taps). */

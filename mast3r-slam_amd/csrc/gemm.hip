@@ -16,46 +16,17 @@
 // MODE_CONV3 turns the A operand into an on-the-fly im2col gather (implicit GEMM) of a 3x3,
 // pad 1 convolution over an NHWC bf16 image: K = 9*Cin, K-tile kt -> tap (kt*64)/Cin; taps that
 // fall outside the image read a 16-byte zero page instead.
-#include "common.h"
-#include "../../include/m3slam_model.h"
+#include "gemm_common.h"
+#include <stdlib.h>
+
+using namespace m3gemm;
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef unsigned short bf16_t;
-
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BM = 128, BN = 128;
 constexpr int kThreads = 256;
 constexpr int kStageBytes = (BM + BN) * BK * 2;          // 32 KiB
 constexpr int kLdsBytes = 2 * kStageBytes;               // 64 KiB
-
-__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float((unsigned)v << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {        // round-to-nearest-even, NaN preserved
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-
-__device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) unsigned *)g,
-                                     (__attribute__((address_space(3))) unsigned *)lds_wave_base, 16, 0, 0);
-}
-
-struct GemmArgs {
-    const bf16_t *A;        // [M,K] bf16 (dense) or NHWC image (conv)
-    const bf16_t *W;        // [N,K] bf16
-    const float *bias;      // [N] or null
-    void *C;                // bf16 [M,ldc] or f32 [M,ldc]
-    const void *R;          // residual (same dtype/shape as C) or null
-    const bf16_t *zero16;   // 16 zero bytes (conv padding source)
-    int M, N, K, ldc;
-    // conv geometry
-    int H, Wd, Cin, OH, OW, stride;
-};
-
-enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32 = 2, EPI_F32_ACCUM = 3, EPI_BF16_RELU = 4, EPI_BF16_ADD = 5 };
 
 template <int MODE /*0 dense, 1 conv3x3*/, int EPI>
 __global__ void __launch_bounds__(kThreads)
@@ -67,11 +38,7 @@ k_gemm(const GemmArgs g) {
     // XCD-aware tile order: consecutive tiles of one M-panel land on one XCD (shared A panel in L2)
     const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
     const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-    }
+    const int bid = xcd_remap(blockIdx.x, nwg);
     const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
@@ -169,43 +136,10 @@ k_gemm(const GemmArgs g) {
     // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] --------------
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wr * 64 + i * 16 + (lane & 15);
-        if (m >= g.M) continue;
+        if (EPI == EPI_BF16_ROPE) rope_strip(g, acc[i], m0 + wr * 64 + i * 16 + (lane & 15), n0 + wc * 64, lane);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
-            if (n >= g.N) continue;                        // N is a multiple of 4 (checked on the host)
-            f32x4 v = acc[i][j];
-            if (g.bias) {
-                const float4 b = *reinterpret_cast<const float4 *>(g.bias + n);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
-            const size_t off = (size_t)m * g.ldc + n;
-            if (EPI == EPI_F32 || EPI == EPI_F32_ACCUM) {
-                float *C = reinterpret_cast<float *>(g.C) + off;
-                if (EPI == EPI_F32_ACCUM) {
-                    const float4 r = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(g.R) + off);
-                    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-                }
-                *reinterpret_cast<float4 *>(C) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                if (EPI == EPI_BF16_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-                }
-                if (EPI == EPI_BF16_ADD) {
-                    const ushort4 r = *reinterpret_cast<const ushort4 *>(reinterpret_cast<const bf16_t *>(g.R) + off);
-                    v[0] += bf2f(r.x); v[1] += bf2f(r.y); v[2] += bf2f(r.z); v[3] += bf2f(r.w);
-                }
-                if (EPI == EPI_BF16_RELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-                }
-                ushort4 o;
-                o.x = f2bf(v[0]); o.y = f2bf(v[1]); o.z = f2bf(v[2]); o.w = f2bf(v[3]);
-                *reinterpret_cast<ushort4 *>(reinterpret_cast<bf16_t *>(g.C) + off) = o;
-            }
-        }
+        for (int j = 0; j < 4; ++j)
+            store_tile<EPI>(g, acc[i][j], m0 + wr * 64 + i * 16 + (lane & 15), n0 + wc * 64 + j * 16 + (lane >> 4) * 4);
     }
 }
 
@@ -215,7 +149,7 @@ int launch(const GemmArgs &a, int epi, hipStream_t st) {
     dim3 grid(tiles), blk(kThreads);
 #define M3_L(E) case E: hipLaunchKernelGGL((k_gemm<MODE, E>), grid, blk, kLdsBytes, st, a); break
     switch (epi) {
-        M3_L(EPI_BF16); M3_L(EPI_BF16_GELU); M3_L(EPI_F32); M3_L(EPI_F32_ACCUM); M3_L(EPI_BF16_RELU); M3_L(EPI_BF16_ADD);
+        M3_L(EPI_BF16); M3_L(EPI_BF16_GELU); M3_L(EPI_F32); M3_L(EPI_F32_ACCUM); M3_L(EPI_BF16_RELU); M3_L(EPI_BF16_ADD); M3_L(EPI_BF16_ROPE);
         default: return M3_ERR_INVALID_ARG;
     }
 #undef M3_L
@@ -223,25 +157,54 @@ int launch(const GemmArgs &a, int epi, hipStream_t st) {
     return M3_OK;
 }
 
+// Tile choice: the 256x256 ping-pong kernel runs one workgroup per CU, the 128x128 kernel two.
+// Estimated cost = rounds over the 256 CUs x work per tile (the 256 kernel is ~1.4x more efficient
+// per FLOP once the grid fills the chip).  M3_GEMM_TILE=128|256 forces a path (experiments).
+bool use_256(int M, int N) {
+    static const int forced = [] { const char *e = getenv("M3_GEMM_TILE"); return e ? atoi(e) : 0; }();
+    if (forced == 128) return false;
+    if (forced == 256) return true;
+    const long t256 = (long)m3_cdiv(M, 256) * m3_cdiv(N, 256), t128 = (long)m3_cdiv(M, 128) * m3_cdiv(N, 128);
+    const double c256 = (double)((t256 + 255) / 256) * 4.0 / 1.4, c128 = (double)((t128 + 511) / 512) * 2.0;
+    return c256 < c128;
+}
+
 }  // namespace
+
+int m3_launch_gemm256_dense(const GemmArgs &a, int epi, hipStream_t st);
+int m3_launch_gemm256_conv(const GemmArgs &a, int epi, hipStream_t st);
 
 extern "C" {
 
 int m3_gemm_bf16(const void *A, const void *W, const float *bias, void *C, const void *R, int M, int N, int K,
                  int ldc, int epilogue, void *stream) {
     M3_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0);
-    M3_REQUIRE(K % BK == 0 && N % 4 == 0 && ldc >= N && ldc % 4 == 0);
+    M3_REQUIRE(K % BK == 0 && N % 4 == 0 && ldc >= N && ldc % 4 == 0 && epilogue != EPI_BF16_ROPE);
     M3_REQUIRE(!((epilogue == EPI_F32_ACCUM || epilogue == EPI_BF16_ADD) && !R));
     GemmArgs a{};
     a.A = (const bf16_t *)A; a.W = (const bf16_t *)W; a.bias = bias; a.C = C; a.R = R;
     a.M = M; a.N = N; a.K = K; a.ldc = ldc;
+    if (use_256(M, N)) return m3_launch_gemm256_dense(a, epilogue, (hipStream_t)stream);
     return launch<0>(a, epilogue, (hipStream_t)stream);
+}
+
+int m3_gemm_bf16_rope(const void *A, const void *W, const float *bias, void *C, int M, int N, int K, int ldc,
+                      const int32_t *pos_yx, const float *cos_sin, int tokens_per_image, int rope_cols,
+                      void *stream) {
+    M3_REQUIRE(A && W && C && pos_yx && cos_sin && M > 0 && N > 0 && K > 0 && tokens_per_image > 0);
+    M3_REQUIRE(K % BK == 0 && N % 64 == 0 && ldc >= N && ldc % 4 == 0 && rope_cols % 64 == 0 && rope_cols <= N);
+    GemmArgs a{};
+    a.A = (const bf16_t *)A; a.W = (const bf16_t *)W; a.bias = bias; a.C = C;
+    a.M = M; a.N = N; a.K = K; a.ldc = ldc;
+    a.pos_yx = pos_yx; a.cos_sin = cos_sin; a.tokens_per_image = tokens_per_image; a.rope_cols = rope_cols;
+    if (use_256(M, N)) return m3_launch_gemm256_dense(a, EPI_BF16_ROPE, (hipStream_t)stream);
+    return launch<0>(a, EPI_BF16_ROPE, (hipStream_t)stream);
 }
 
 int m3_conv3x3_bf16(const void *X, const void *W, const float *bias, void *Y, const void *R, const void *zero16,
                     int B, int H, int Wd, int Cin, int Cout, int stride, int epilogue, void *stream) {
     M3_REQUIRE(X && W && Y && zero16 && B > 0 && H > 0 && Wd > 0 && Cin > 0 && Cout > 0);
-    M3_REQUIRE(Cin % BK == 0 && Cout % 4 == 0 && (stride == 1 || stride == 2));
+    M3_REQUIRE(Cin % BK == 0 && Cout % 4 == 0 && (stride == 1 || stride == 2) && epilogue != EPI_BF16_ROPE);
     M3_REQUIRE(!((epilogue == EPI_F32_ACCUM || epilogue == EPI_BF16_ADD) && !R));
     GemmArgs a{};
     a.A = (const bf16_t *)X; a.W = (const bf16_t *)W; a.bias = bias; a.C = Y; a.R = R;
@@ -249,6 +212,7 @@ int m3_conv3x3_bf16(const void *X, const void *W, const float *bias, void *Y, co
     a.H = H; a.Wd = Wd; a.Cin = Cin; a.stride = stride;
     a.OH = (H + 2 - 3) / stride + 1; a.OW = (Wd + 2 - 3) / stride + 1;
     a.M = B * a.OH * a.OW; a.N = Cout; a.K = 9 * Cin; a.ldc = Cout;
+    if (use_256(a.M, a.N)) return m3_launch_gemm256_conv(a, epilogue, (hipStream_t)stream);
     return launch<1>(a, epilogue, (hipStream_t)stream);
 }
 

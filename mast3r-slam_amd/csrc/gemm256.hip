@@ -1,0 +1,215 @@
+// 256x256x64 "ping-pong" bf16 MFMA GEMM / implicit-GEMM conv for gfx950 - the large-problem path.
+//
+// Why: on the 128x128 kernel every wave issues 8 global_load_lds and 16 ds_read_b128 per 32 MFMAs
+// and all waves of a SIMD do the same thing at the same time, so the matrix pipe idles while
+// loads/LDS reads issue (ablation in profiles/r01_gemm_ablation.md: MFMA-only 1480 TFLOP/s,
+// +LDS reads 1110, +global loads 960, both 760).  Here:
+//   * tile 256x256, 8 waves (2 x 4), wave sub-tile 128x64 = 8x4 MFMA tiles: per 32 MFMAs only
+//     4 global_load_lds and 12 ds_read_b128;
+//   * one workgroup per CU (128 KiB LDS, two stages), so the two waves that share a SIMD belong to
+//     the same workgroup: waves 0-3 ("ping") and 4-7 ("pong") run the SAME per-K-tile sequence
+//          READ(ks0)+LOADS(next tile) | MFMA(ks0) | READ(ks1) | MFMA(ks1)
+//     one phase apart, a workgroup barrier between phases - while one wave of a SIMD issues its
+//     32 MFMAs the other one issues its LDS reads / global loads.  Each group has its own
+//     straight-line loop (register liveness stays per phase); both execute the same barrier count.
+// LDS image, swizzle, swapped-operand accumulator layout and epilogues are those of gemm.hip.
+#include "gemm_common.h"
+
+using namespace m3gemm;
+
+namespace {
+
+constexpr int BM = 256, BN = 256;
+constexpr int kThreads = 512;
+constexpr int kStageBytes = (BM + BN) * BK * 2;          // 64 KiB
+constexpr int kLdsBytes = 2 * kStageBytes;               // 128 KiB
+
+template <int MODE /*0 dense, 1 conv3x3*/, int EPI>
+__global__ void __launch_bounds__(kThreads, 2)
+k_gemm256(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int group = wave >> 2;                            // 0 = ping (first wave of each SIMD), 1 = pong
+    const int wr = wave >> 2, wc = wave & 3;                // wave sub-tile: rows wr*128, cols wc*64
+
+    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+    const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // staging: thread t moves 16-byte slot t of each 8 KiB issue (64 rows x 128 B); 4 issues per operand
+    const int srow = tid >> 3, sch = (tid & 7) ^ ((srow >> 1) & 7);
+    const bf16_t *a_src[4];
+    const bf16_t *w_src[4];
+    int a_oy[4], a_ox[4];
+    const bf16_t *a_img[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + i * 64 + srow;
+        m = m < g.M ? m : g.M - 1;
+        int n = n0 + i * 64 + srow;
+        n = n < g.N ? n : g.N - 1;
+        w_src[i] = g.W + (size_t)n * g.K + sch * 8;
+        if (MODE == 0) {
+            a_src[i] = g.A + (size_t)m * g.K + sch * 8;
+        } else {
+            const int pix = g.OH * g.OW;
+            const int b = m / pix, rem = m - b * pix;
+            a_oy[i] = (rem / g.OW) * g.stride - 1;
+            a_ox[i] = (rem % g.OW) * g.stride - 1;
+            a_img[i] = g.A + (size_t)b * g.H * g.Wd * g.Cin + sch * 8;
+        }
+    }
+    const int nk = g.K / BK;
+
+    auto stage = [&](int kt, int buf) {
+        unsigned char *base = lds + buf * kStageBytes;
+        int ky = 0, kx = 0, c0 = 0;
+        if (MODE == 1) {
+            const int k0 = kt * BK, tap = k0 / g.Cin;
+            c0 = k0 - tap * g.Cin;
+            ky = tap / 3; kx = tap - ky * 3;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const void *src;
+            if (MODE == 0) {
+                src = a_src[i] + (size_t)kt * BK;
+            } else {
+                const int iy = a_oy[i] + ky, ix = a_ox[i] + kx;
+                const bool in = (iy >= 0) && (iy < g.H) && (ix >= 0) && (ix < g.Wd);
+                src = in ? (const void *)(a_img[i] + ((size_t)iy * g.Wd + ix) * g.Cin + c0) : (const void *)g.zero16;
+            }
+            glds16(src, base + i * 8192 + wave * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            glds16(w_src[i] + (size_t)kt * BK, base + BM * BK * 2 + i * 8192 + wave * 1024);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fch = lane >> 4;
+    // per-lane LDS byte offsets of the fragments (k-step 0; k-step 1 flips chunk bit 2 = byte 64)
+    int a_off[8], w_off[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = wr * 128 + i * 16 + frow;
+        a_off[i] = r * 128 + ((fch ^ ((r >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = wc * 64 + j * 16 + frow;
+        w_off[j] = BM * BK * 2 + r * 128 + ((fch ^ ((r >> 1) & 7)) << 4);
+    }
+
+    bf16x8 af[8], wf[4];
+    auto read_frags = [&](int buf, int ks) {
+        const unsigned char *base = lds + buf * kStageBytes;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8 *>(base + (w_off[j] ^ (ks << 6)));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(base + (a_off[i] ^ (ks << 6)));
+    };
+    auto mfma_all = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto phase_end = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto phase_end_wait = [&]() {                          // retire this wave's loads of the next tile first
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // prologue: tile 0 into stage 0, visible to everyone
+    stage(0, 0);
+    phase_end_wait();
+
+    if (group == 0) {
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            read_frags(buf, 0);                            // phase 0
+            if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            phase_end();
+            mfma_all();                                    // phase 1
+            phase_end();
+            read_frags(buf, 1);                            // phase 2
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            phase_end();
+            mfma_all();                                    // phase 3
+            phase_end_wait();
+        }
+        phase_end();                                       // matches the pong group's drain phase
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt > 0) mfma_all();                        // phase 0: k-step 1 of the previous tile
+            phase_end();
+            read_frags(buf, 0);                            // phase 1
+            if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            phase_end();
+            mfma_all();                                    // phase 2
+            phase_end();
+            read_frags(buf, 1);                            // phase 3
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            phase_end_wait();
+        }
+        mfma_all();                                        // drain: k-step 1 of the last tile
+        phase_end();
+    }
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (EPI == EPI_BF16_ROPE) rope_strip(g, acc[i], m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 64, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            store_tile<EPI>(g, acc[i][j], m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 64 + j * 16 + (lane >> 4) * 4);
+    }
+}
+
+template <int MODE>
+int launch256(const GemmArgs &a, int epi, hipStream_t st) {
+    const int tiles = m3_cdiv(a.M, BM) * m3_cdiv(a.N, BN);
+    dim3 grid(tiles), blk(kThreads);
+#define M3_L(E)                                                                                              \
+    case E: {                                                                                                \
+        static bool attr_set = false;                                                                        \
+        if (!attr_set) {                                                                                     \
+            M3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm256<MODE, E>),            \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes),         \
+                         "m3_gemm256/attr");                                                                 \
+            attr_set = true;                                                                                 \
+        }                                                                                                    \
+        hipLaunchKernelGGL((k_gemm256<MODE, E>), grid, blk, kLdsBytes, st, a);                               \
+    } break
+    switch (epi) {
+        M3_L(EPI_BF16); M3_L(EPI_BF16_GELU); M3_L(EPI_F32); M3_L(EPI_F32_ACCUM); M3_L(EPI_BF16_RELU); M3_L(EPI_BF16_ADD); M3_L(EPI_BF16_ROPE);
+        default: return M3_ERR_INVALID_ARG;
+    }
+#undef M3_L
+    M3_CHECK_LAUNCH("m3_gemm256");
+    return M3_OK;
+}
+
+}  // namespace
+
+// entry points used by gemm.hip's dispatcher
+int m3_launch_gemm256_dense(const GemmArgs &a, int epi, hipStream_t st) { return launch256<0>(a, epi, st); }
+int m3_launch_gemm256_conv(const GemmArgs &a, int epi, hipStream_t st) { return launch256<1>(a, epi, st); }

@@ -30,9 +30,16 @@ constexpr int WS_COST = 12;
 constexpr int WS_CONV = 13;
 constexpr int WS_PART = 16;           // partials [kBlocks][kSums]
 
+constexpr int WS_STRIDE = WS_PART + kBlocks * kSums;   // doubles per problem
+
 __global__ void k_track_init(const float *__restrict__ T_WCf, const float *__restrict__ T_WCk,
                              const float *__restrict__ T_rel, double *__restrict__ ws) {
     if (threadIdx.x != 0) return;
+    const int pb = blockIdx.x;
+    ws += (size_t)pb * WS_STRIDE;
+    if (T_WCf) T_WCf += 8 * pb;
+    if (T_WCk) T_WCk += 8 * pb;
+    if (T_rel) T_rel += 8 * pb;
     Pose<double> T;
     if (T_rel) T = load_pose<double>(T_rel);
     else T = mul(inv_mlx(load_pose<double>(T_WCk)), load_pose<double>(T_WCf));
@@ -45,6 +52,10 @@ __global__ void __launch_bounds__(kThreads)
 k_track_accum(const float *__restrict__ Xf, const float *__restrict__ Xk, const float *__restrict__ Qk,
               const uint8_t *__restrict__ valid, double *__restrict__ ws, int N, float huber_k,
               float inv_sigma_ray, float inv_sigma_dist) {
+    {
+        const size_t pb = blockIdx.y;
+        Xf += pb * N * 3; Xk += pb * N * 3; Qk += pb * N; valid += pb * N; ws += pb * WS_STRIDE;
+    }
     if (ws[WS_DONE] != 0.0) return;
     const Pose<float> T = load_pose<float>(ws + WS_T);
     double acc[kSums];
@@ -122,6 +133,7 @@ __device__ __forceinline__ void reduce_partials(const double *__restrict__ part,
 
 __global__ void __launch_bounds__(kThreads)
 k_track_solve(double *__restrict__ ws, float rel_error, float delta_norm, int fixed_iters) {
+    ws += (size_t)blockIdx.x * WS_STRIDE;
     if (ws[WS_DONE] != 0.0) return;
     __shared__ double sums[kSums];
     reduce_partials(ws + WS_PART, sums);
@@ -155,6 +167,10 @@ __global__ void k_track_final(const double *__restrict__ ws, const float *__rest
                               float *__restrict__ T_WCf_out, float *__restrict__ T_rel_out,
                               double *__restrict__ info) {
     if (threadIdx.x != 0) return;
+    {
+        const int pb = blockIdx.x;
+        ws += (size_t)pb * WS_STRIDE; T_WCk += 8 * pb; T_WCf_out += 8 * pb; T_rel_out += 8 * pb; info += 4 * pb;
+    }
     Pose<double> T = load_pose<double>(ws + WS_T);
     store_pose(T_rel_out, T);
     store_pose(T_WCf_out, mul(load_pose<double>(T_WCk), T));
@@ -163,6 +179,7 @@ __global__ void k_track_final(const double *__restrict__ ws, const float *__rest
 
 __global__ void __launch_bounds__(kThreads)
 k_track_export(const double *__restrict__ ws, double *__restrict__ out) {
+    ws += (size_t)blockIdx.x * WS_STRIDE; out += (size_t)blockIdx.x * kSums;
     __shared__ double sums[kSums];
     reduce_partials(ws + WS_PART, sums);
     if (threadIdx.x < kSums) out[threadIdx.x] = sums[threadIdx.x];
@@ -174,6 +191,11 @@ k_track_gather(const float *__restrict__ Xf_canon, const float *__restrict__ Cf_
                const int64_t *__restrict__ idx, const uint8_t *__restrict__ valid_match,
                float *__restrict__ Xf_g, float *__restrict__ Qk, uint8_t *__restrict__ valid_opt,
                uint8_t *__restrict__ valid_kf, int32_t *__restrict__ counts, int N, float C_conf, float Q_conf) {
+    {
+        const size_t pb = blockIdx.y;
+        Xf_canon += pb * N * 3; Cf_avg += pb * N; Ck_avg += pb * N; Qff += pb * N; Qkf += pb * N; idx += pb * N;
+        valid_match += pb * N; Xf_g += pb * N * 3; Qk += pb * N; valid_opt += pb * N; valid_kf += pb * N; counts += 2 * pb;
+    }
     const int n = blockIdx.x * kThreads + threadIdx.x;
     int vo = 0, vk = 0;
     if (n < N) {
@@ -211,19 +233,50 @@ k_sim3_act(const float *__restrict__ Tp, const float *__restrict__ X, float *__r
 
 extern "C" {
 
-int64_t m3_track_ws_doubles(void) { return WS_PART + (int64_t)kBlocks * kSums; }
+int64_t m3_track_ws_doubles(void) { return WS_STRIDE; }
+
+int m3_track_gather_batch(const float *Xf_canon, const float *Cf_avg, const float *Ck_avg, const float *Qff,
+                          const float *Qkf, const int64_t *idx, const uint8_t *valid_match, float *Xf_g,
+                          float *Qk, uint8_t *valid_opt, uint8_t *valid_kf, int32_t *counts, int P, int N,
+                          float C_conf, float Q_conf, void *stream) {
+    M3_REQUIRE(Xf_canon && Cf_avg && Ck_avg && Qff && Qkf && idx && valid_match);
+    M3_REQUIRE(Xf_g && Qk && valid_opt && valid_kf && counts && N > 0 && P > 0 && P <= 65535);
+    hipStream_t st = (hipStream_t)stream;
+    M3_CHECK_HIP(hipMemsetAsync(counts, 0, 2 * P * sizeof(int32_t), st), "m3_track_gather/memset");
+    hipLaunchKernelGGL(k_track_gather, dim3(m3_cdiv(N, kThreads), P), dim3(kThreads), 0, st, Xf_canon, Cf_avg,
+                       Ck_avg, Qff, Qkf, idx, valid_match, Xf_g, Qk, valid_opt, valid_kf, counts, N, C_conf, Q_conf);
+    M3_CHECK_LAUNCH("m3_track_gather");
+    return M3_OK;
+}
 
 int m3_track_gather(const float *Xf_canon, const float *Cf_avg, const float *Ck_avg, const float *Qff,
                     const float *Qkf, const int64_t *idx, const uint8_t *valid_match, float *Xf_g,
                     float *Qk, uint8_t *valid_opt, uint8_t *valid_kf, int32_t *counts, int N,
                     float C_conf, float Q_conf, void *stream) {
-    M3_REQUIRE(Xf_canon && Cf_avg && Ck_avg && Qff && Qkf && idx && valid_match);
-    M3_REQUIRE(Xf_g && Qk && valid_opt && valid_kf && counts && N > 0);
+    return m3_track_gather_batch(Xf_canon, Cf_avg, Ck_avg, Qff, Qkf, idx, valid_match, Xf_g, Qk, valid_opt, valid_kf,
+                                 counts, 1, N, C_conf, Q_conf, stream);
+}
+
+int m3_track_gn_ray_dist_batch(const float *Xf, const float *Xk, const float *Qk, const uint8_t *valid,
+                               const float *T_WCf, const float *T_WCk, float *T_WCf_out, float *T_CkCf_out,
+                               double *info, double *ws, int P, int N, int max_iters, float huber_k,
+                               float sigma_ray, float sigma_dist, float rel_error, float delta_norm,
+                               int fixed_iters, void *stream) {
+    M3_REQUIRE(Xf && Xk && Qk && valid && T_WCf && T_WCk && T_WCf_out && T_CkCf_out && info && ws);
+    M3_REQUIRE(N > 0 && P > 0 && P <= 65535 && max_iters >= 0 && sigma_ray > 0.f && sigma_dist > 0.f && huber_k > 0.f);
     hipStream_t st = (hipStream_t)stream;
-    M3_CHECK_HIP(hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), st), "m3_track_gather/memset");
-    hipLaunchKernelGGL(k_track_gather, dim3(m3_cdiv(N, kThreads)), dim3(kThreads), 0, st, Xf_canon, Cf_avg,
-                       Ck_avg, Qff, Qkf, idx, valid_match, Xf_g, Qk, valid_opt, valid_kf, counts, N, C_conf, Q_conf);
-    M3_CHECK_LAUNCH("m3_track_gather");
+    hipLaunchKernelGGL(k_track_init, dim3(P), dim3(64), 0, st, T_WCf, T_WCk, (const float *)nullptr, ws);
+    M3_CHECK_LAUNCH("m3_track_gn/init");
+    const float isr = (float)(1.0 / (double)sigma_ray), isd = (float)(1.0 / (double)sigma_dist);
+    for (int it = 0; it < max_iters; ++it) {
+        hipLaunchKernelGGL(k_track_accum, dim3(kBlocks, P), dim3(kThreads), 0, st, Xf, Xk, Qk, valid, ws, N,
+                           huber_k, isr, isd);
+        hipLaunchKernelGGL(k_track_solve, dim3(P), dim3(kThreads), 0, st, ws, rel_error, delta_norm, fixed_iters);
+    }
+    M3_CHECK_LAUNCH("m3_track_gn/loop");
+    hipLaunchKernelGGL(k_track_final, dim3(P), dim3(64), 0, st, (const double *)ws, T_WCk, T_WCf_out,
+                       T_CkCf_out, info);
+    M3_CHECK_LAUNCH("m3_track_gn/final");
     return M3_OK;
 }
 
@@ -231,22 +284,9 @@ int m3_track_gn_ray_dist(const float *Xf, const float *Xk, const float *Qk, cons
                          const float *T_WCf, const float *T_WCk, float *T_WCf_out, float *T_CkCf_out,
                          double *info, double *ws, int N, int max_iters, float huber_k, float sigma_ray,
                          float sigma_dist, float rel_error, float delta_norm, int fixed_iters, void *stream) {
-    M3_REQUIRE(Xf && Xk && Qk && valid && T_WCf && T_WCk && T_WCf_out && T_CkCf_out && info && ws);
-    M3_REQUIRE(N > 0 && max_iters >= 0 && sigma_ray > 0.f && sigma_dist > 0.f && huber_k > 0.f);
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_track_init, dim3(1), dim3(64), 0, st, T_WCf, T_WCk, (const float *)nullptr, ws);
-    M3_CHECK_LAUNCH("m3_track_gn/init");
-    const float isr = (float)(1.0 / (double)sigma_ray), isd = (float)(1.0 / (double)sigma_dist);
-    for (int it = 0; it < max_iters; ++it) {
-        hipLaunchKernelGGL(k_track_accum, dim3(kBlocks), dim3(kThreads), 0, st, Xf, Xk, Qk, valid, ws, N,
-                           huber_k, isr, isd);
-        hipLaunchKernelGGL(k_track_solve, dim3(1), dim3(kThreads), 0, st, ws, rel_error, delta_norm, fixed_iters);
-    }
-    M3_CHECK_LAUNCH("m3_track_gn/loop");
-    hipLaunchKernelGGL(k_track_final, dim3(1), dim3(64), 0, st, (const double *)ws, T_WCk, T_WCf_out,
-                       T_CkCf_out, info);
-    M3_CHECK_LAUNCH("m3_track_gn/final");
-    return M3_OK;
+    return m3_track_gn_ray_dist_batch(Xf, Xk, Qk, valid, T_WCf, T_WCk, T_WCf_out, T_CkCf_out, info, ws, 1, N,
+                                      max_iters, huber_k, sigma_ray, sigma_dist, rel_error, delta_norm, fixed_iters,
+                                      stream);
 }
 
 int m3_track_normal_eq(const float *Xf, const float *Xk, const float *Qk, const uint8_t *valid,

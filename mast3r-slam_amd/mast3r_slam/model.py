@@ -252,8 +252,7 @@ class Mast3rFull:
     def _self_attn(self, xn, p, heads, nb, t, pos, cs):
         P = self.P
         c = heads * 64
-        qkv = ops.gemm(xn, P[p + ".qkv.w"], P[p + ".qkv.b"], ops.EPI_BF16)              # [M,3c]
-        ops.rope2d_(qkv, pos, cs, row_stride=3 * c, tokens=nb * t, heads=2 * heads, tokens_per_image=t)
+        qkv = ops.gemm_rope(xn, P[p + ".qkv.w"], P[p + ".qkv.b"], pos, cs, t, 2 * c)    # [M,3c], q|k rotated
         out = torch.empty((nb * t, c), dtype=torch.bfloat16, device=xn.device)
         ops.attention(qkv, qkv[:, c:], qkv[:, 2 * c:], out, nbatch=nb, heads=heads, tq=t, tk=t,
                       q_row_stride=3 * c, kv_row_stride=3 * c, o_row_stride=c, q_batch_stride=t * 3 * c,
@@ -308,8 +307,7 @@ class Mast3rFull:
             kvs = []
             for v, p in enumerate(names):
                 yn = ops.layernorm(xs[1 - v], P[p + ".norm_y.g"], P[p + ".norm_y.b"])
-                kv = ops.gemm(yn, P[p + ".cross_attn.kv.w"], P[p + ".cross_attn.kv.b"], ops.EPI_BF16)  # [M,2D]
-                ops.rope2d_(kv, pos, cs, row_stride=2 * D, tokens=m, heads=heads, tokens_per_image=t)
+                kv = ops.gemm_rope(yn, P[p + ".cross_attn.kv.w"], P[p + ".cross_attn.kv.b"], pos, cs, t, D)  # [M,2D]
                 kvs.append(kv)
             for v, p in enumerate(names):
                 x = xs[v]
@@ -317,8 +315,7 @@ class Mast3rFull:
                 a = self._self_attn(xn, p + ".attn", heads, npairs, t, pos, cs)
                 ops.gemm(a, P[p + ".attn.proj.w"], P[p + ".attn.proj.b"], ops.EPI_F32_ACCUM, out=x, resid=x)
                 xn = ops.layernorm(x, P[p + ".norm2.g"], P[p + ".norm2.b"])
-                q = ops.gemm(xn, P[p + ".cross_attn.projq.w"], P[p + ".cross_attn.projq.b"], ops.EPI_BF16)
-                ops.rope2d_(q, pos, cs, row_stride=D, tokens=m, heads=heads, tokens_per_image=t)
+                q = ops.gemm_rope(xn, P[p + ".cross_attn.projq.w"], P[p + ".cross_attn.projq.b"], pos, cs, t, D)
                 kv = kvs[v]
                 a = torch.empty((m, D), dtype=torch.bfloat16, device=x.device)
                 ops.attention(q, kv, kv[:, D:], a, nbatch=npairs, heads=heads, tq=t, tk=t, q_row_stride=D,

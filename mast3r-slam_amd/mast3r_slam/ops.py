@@ -70,6 +70,20 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, epi: int = EPI_BF16, out=N
     return out
 
 
+def gemm_rope(a, w, bias, pos_yx, cos_sin, tokens_per_image: int, rope_cols: int):
+    """bf16 out[M,N] = a @ w.T + bias with RoPE-2D applied to the 64-wide heads in columns < rope_cols."""
+    a = _ffi.check(a, torch.bfloat16, "a")
+    w = _ffi.check(w, torch.bfloat16, "w")
+    m, k = a.shape
+    n = w.shape[0]
+    out = torch.empty((m, n), dtype=torch.bfloat16, device=a.device)
+    e0 = _prof_begin()
+    _ffi.call("m3_gemm_bf16_rope", _ffi.ptr(a), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(out), m, n, k, n,
+              _ffi.ptr(pos_yx), _ffi.ptr(cos_sin), tokens_per_image, rope_cols, _ffi.stream_ptr())
+    _prof_end(e0, "gemm", 2.0 * m * n * k)
+    return out
+
+
 def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, epi: int = EPI_BF16, stride: int = 1, resid=None, out=None):
     """x NHWC bf16 [B,H,W,Cin], w bf16 [Cout,3,3,Cin] -> NHWC [B,OH,OW,Cout], padding 1."""
     x = _ffi.check(x, torch.bfloat16, "x")

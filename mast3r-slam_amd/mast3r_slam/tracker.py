@@ -22,54 +22,73 @@ def _pose(T, name):
     return T
 
 
+def _batch_of(t: torch.Tensor, inner: int) -> int:
+    """Leading batch size of a [P,N,(inner)] / [N,(inner)] tensor (1 when unbatched)."""
+    want = 3 if inner > 1 else 2
+    return t.shape[0] if t.dim() == want else 1
+
+
 def track_gather(Xf_canon, Cf_avg, Ck_avg, Qff, Qkf, idx_f2k, valid_match, C_conf=0.0, Q_conf=1.5):
     """tracker.py:88-113 + :214 fused: returns (Xf[idx] [N,3], Qk [N], valid_opt [N] u8,
-    valid_kf [N] u8, counts int32[2] = (#valid_opt, #valid_kf))."""
-    n = idx_f2k.numel()
-    Xf_canon = _ffi.check(Xf_canon.reshape(-1, 3), torch.float32, "Xf_canon", (n, 3))
-    Cf_avg = _ffi.check(Cf_avg.reshape(-1), torch.float32, "Cf", (n,))
-    Ck_avg = _ffi.check(Ck_avg.reshape(-1), torch.float32, "Ck", (n,))
-    Qff = _ffi.check(Qff.reshape(-1), torch.float32, "Qff", (n,))
-    Qkf = _ffi.check(Qkf.reshape(-1), torch.float32, "Qkf", (n,))
-    idx = _ffi.check(idx_f2k.reshape(-1).to(torch.int64), torch.int64, "idx_f2k", (n,))
-    vm = _ffi.check(valid_match.reshape(-1).to(torch.uint8), torch.uint8, "valid_match", (n,))
+    valid_kf [N] u8, counts int32[2] = (#valid_opt, #valid_kf)).
+    Batched: Xf_canon [P,N,3] and idx_f2k [P,N] (all other inputs [P,N] or [P,N,1]) give [P,...] outputs
+    from ONE launch."""
+    batched = Xf_canon.dim() == 3 and idx_f2k.dim() == 2 and idx_f2k.shape[0] == Xf_canon.shape[0]
+    P = Xf_canon.shape[0] if batched else 1
+    n = idx_f2k.numel() // P
+    Xf_canon = _ffi.check(Xf_canon.reshape(P, n, 3), torch.float32, "Xf_canon", (P, n, 3))
+    Cf_avg = _ffi.check(Cf_avg.reshape(P, n), torch.float32, "Cf", (P, n))
+    Ck_avg = _ffi.check(Ck_avg.reshape(P, n), torch.float32, "Ck", (P, n))
+    Qff = _ffi.check(Qff.reshape(P, n), torch.float32, "Qff", (P, n))
+    Qkf = _ffi.check(Qkf.reshape(P, n), torch.float32, "Qkf", (P, n))
+    idx = _ffi.check(idx_f2k.reshape(P, n).to(torch.int64), torch.int64, "idx_f2k", (P, n))
+    vm = _ffi.check(valid_match.reshape(P, n).to(torch.uint8), torch.uint8, "valid_match", (P, n))
     dev = Xf_canon.device
-    Xf = torch.empty((n, 3), dtype=torch.float32, device=dev)
-    Qk = torch.empty(n, dtype=torch.float32, device=dev)
-    vo = torch.empty(n, dtype=torch.uint8, device=dev)
-    vk = torch.empty(n, dtype=torch.uint8, device=dev)
-    counts = torch.empty(2, dtype=torch.int32, device=dev)
-    _ffi.call("m3_track_gather", _ffi.ptr(Xf_canon), _ffi.ptr(Cf_avg), _ffi.ptr(Ck_avg), _ffi.ptr(Qff),
+    Xf = torch.empty((P, n, 3), dtype=torch.float32, device=dev)
+    Qk = torch.empty((P, n), dtype=torch.float32, device=dev)
+    vo = torch.empty((P, n), dtype=torch.uint8, device=dev)
+    vk = torch.empty((P, n), dtype=torch.uint8, device=dev)
+    counts = torch.empty((P, 2), dtype=torch.int32, device=dev)
+    _ffi.call("m3_track_gather_batch", _ffi.ptr(Xf_canon), _ffi.ptr(Cf_avg), _ffi.ptr(Ck_avg), _ffi.ptr(Qff),
               _ffi.ptr(Qkf), _ffi.ptr(idx), _ffi.ptr(vm), _ffi.ptr(Xf), _ffi.ptr(Qk), _ffi.ptr(vo), _ffi.ptr(vk),
-              _ffi.ptr(counts), n, float(C_conf), float(Q_conf), _ffi.stream_ptr())
-    return Xf, Qk, vo, vk, counts
+              _ffi.ptr(counts), P, n, float(C_conf), float(Q_conf), _ffi.stream_ptr())
+    if batched:
+        return Xf, Qk, vo, vk, counts
+    return Xf[0], Qk[0], vo[0], vk[0], counts[0]
 
 
-def _ws(dev):
-    return torch.empty(int(_ffi.lib().m3_track_ws_doubles()), dtype=torch.float64, device=dev)
+def _ws(dev, P=1):
+    return torch.empty(P * int(_ffi.lib().m3_track_ws_doubles()), dtype=torch.float64, device=dev)
 
 
 def opt_pose_ray_dist_sim3(Xf, Xk, T_WCf, T_WCk, Qk, valid, cfg=None, fixed_iters: bool = False):
     """tracker.py:258-324.  Xf [N,3] (gathered at idx_f2k), Xk [N,3], Qk [N(,1)], valid [N(,1)].
-    Returns (T_WCf [8], T_CkCf [8], info float64[4] = iterations, cost, |tau|, converged)."""
+    Returns (T_WCf [8], T_CkCf [8], info float64[4] = iterations, cost, |tau|, converged).
+    Batched: Xf [P,N,3] with poses [P,8] solves P independent problems in one launch sequence
+    (outputs [P,8], [P,8], [P,4])."""
     c = dict(get_config()["tracking"])
     c.update(cfg or {})
-    Xf = _ffi.check(Xf.reshape(-1, 3), torch.float32, "Xf")
-    n = Xf.shape[0]
-    Xk = _ffi.check(Xk.reshape(-1, 3), torch.float32, "Xk", (n, 3))
-    Qk = _ffi.check(Qk.reshape(-1), torch.float32, "Qk", (n,))
-    v = _ffi.check(valid.reshape(-1).to(torch.uint8), torch.uint8, "valid", (n,))
-    Tf, Tk = _pose(T_WCf, "T_WCf"), _pose(T_WCk, "T_WCk")
+    batched = Xf.dim() == 3
+    P = Xf.shape[0] if batched else 1
+    Xf = _ffi.check(Xf.reshape(P, -1, 3), torch.float32, "Xf")
+    n = Xf.shape[1]
+    Xk = _ffi.check(Xk.reshape(P, n, 3), torch.float32, "Xk", (P, n, 3))
+    Qk = _ffi.check(Qk.reshape(P, n), torch.float32, "Qk", (P, n))
+    v = _ffi.check(valid.reshape(P, n).to(torch.uint8), torch.uint8, "valid", (P, n))
+    Tf = _ffi.check(T_WCf.reshape(-1, 8).expand(P, 8).contiguous(), torch.float32, "T_WCf", (P, 8))
+    Tk = _ffi.check(T_WCk.reshape(-1, 8).expand(P, 8).contiguous(), torch.float32, "T_WCk", (P, 8))
     dev = Xf.device
-    out_f = torch.empty(8, dtype=torch.float32, device=dev)
-    out_rel = torch.empty(8, dtype=torch.float32, device=dev)
-    info = torch.empty(4, dtype=torch.float64, device=dev)
-    ws = _ws(dev)
-    _ffi.call("m3_track_gn_ray_dist", _ffi.ptr(Xf), _ffi.ptr(Xk), _ffi.ptr(Qk), _ffi.ptr(v), _ffi.ptr(Tf),
-              _ffi.ptr(Tk), _ffi.ptr(out_f), _ffi.ptr(out_rel), _ffi.ptr(info), _ffi.ptr(ws), n,
+    out_f = torch.empty((P, 8), dtype=torch.float32, device=dev)
+    out_rel = torch.empty((P, 8), dtype=torch.float32, device=dev)
+    info = torch.empty((P, 4), dtype=torch.float64, device=dev)
+    ws = _ws(dev, P)
+    _ffi.call("m3_track_gn_ray_dist_batch", _ffi.ptr(Xf), _ffi.ptr(Xk), _ffi.ptr(Qk), _ffi.ptr(v), _ffi.ptr(Tf),
+              _ffi.ptr(Tk), _ffi.ptr(out_f), _ffi.ptr(out_rel), _ffi.ptr(info), _ffi.ptr(ws), P, n,
               int(c["max_iters"]), float(c["huber"]), float(c["sigma_ray"]), float(c["sigma_dist"]),
               float(c["rel_error"]), float(c["delta_norm"]), 1 if fixed_iters else 0, _ffi.stream_ptr())
-    return out_f, out_rel, info
+    if batched:
+        return out_f, out_rel, info
+    return out_f[0], out_rel[0], info[0]
 
 
 def normal_equations(Xf, Xk, T_CkCf, Qk, valid, cfg=None):

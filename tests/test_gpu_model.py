@@ -197,3 +197,24 @@ def test_operator_api_contract(tiny, dev):
     assert _rel(Xs[0, 0], X[0]) < 1e-6                                 # same decode, batched with others
     with pytest.raises(ValueError):
         mast3r_utils.load_mast3r("dunemast3r")
+
+
+@pytest.mark.parametrize("m_n_k", [(256, 192, 64), (2048, 3072, 1024)])   # 128-tile path and 256-tile path
+def test_gemm_with_fused_rope_epilogue(dev, m_n_k):
+    m, n, k = m_n_k
+    g = torch.Generator().manual_seed(m)
+    gh, gw = 8, 16
+    t = gh * gw
+    a = torch.randn(m, k, generator=g).bfloat16()
+    w = (torch.randn(n, k, generator=g) * 0.05).bfloat16()
+    b = torch.randn(n, generator=g)
+    rope_cols = n // 64 // 3 * 2 * 64                              # first two thirds are q|k heads
+    pos = OM.patch_positions(gh * 16, gw * 16)
+    cos, sin = OM.rope_tables(17)
+    ref = a.float() @ w.float().T + b
+    heads = rope_cols // 64
+    rot = OM.rope2d(ref[:, :rope_cols].reshape(m // t, t, heads, 64).transpose(1, 2), pos, cos, sin)
+    ref = torch.cat([rot.transpose(1, 2).reshape(m, rope_cols), ref[:, rope_cols:]], 1)
+    cs = torch.stack([cos, sin], -1).to(dev).contiguous()
+    out = ops.gemm_rope(a.to(dev), w.to(dev), b.to(dev), pos.to(torch.int32).to(dev), cs, t, rope_cols)
+    assert _rel(out, ref) < 3e-3

@@ -112,3 +112,24 @@ def test_track_gather_and_sim3_act(dev):
     T = np.concatenate([rng.normal(size=3), q, [1.2]]).astype(np.float32)
     out = tracker.sim3_act(_t(T, dev), _t(Xc, dev)).cpu().numpy()
     assert np.abs(out - S.sim3_act_mlx(T.astype(np.float64), Xc.astype(np.float64))).max() < 1e-5
+
+
+def test_batched_solve_equals_loop_of_single_solves(dev):
+    """P problems in one launch sequence == P separate calls, bit for bit (pairs are independent units)."""
+    prs = [_problem(32, 48, 20 + i) for i in range(3)]
+    st = lambda k: torch.stack([_t(p[k], dev) for p in prs])
+    Tf, Trel, info = tracker.opt_pose_ray_dist_sim3(st("Xf"), st("Xk"), st("T_WCf"), st("T_WCk"), st("Qk"), st("valid"))
+    assert Tf.shape == (3, 8) and info.shape == (3, 4)
+    for i, p in enumerate(prs):
+        a = [_t(p[k], dev) for k in ("Xf", "Xk", "T_WCf", "T_WCk", "Qk", "valid")]
+        Tf1, Trel1, info1 = tracker.opt_pose_ray_dist_sim3(*a)
+        assert torch.equal(Tf[i], Tf1) and torch.equal(Trel[i], Trel1) and torch.equal(info[i], info1)
+    # batched gather
+    rng = np.random.default_rng(3)
+    n = 1000
+    Xc = rng.normal(size=(2, n, 3)).astype(np.float32); C = rng.uniform(0, 2, (2, n)).astype(np.float32)
+    Q = rng.uniform(0.5, 4, (2, n)).astype(np.float32); idx = rng.integers(0, n, (2, n)); vm = rng.uniform(size=(2, n)) < 0.7
+    Xf, Qk, vo, vk, cnt = tracker.track_gather(_t(Xc, dev), _t(C, dev), _t(C, dev), _t(Q, dev), _t(Q, dev), _t(idx, dev), _t(vm, dev))
+    for b in range(2):
+        assert np.array_equal(Xf[b].cpu().numpy(), Xc[b][idx[b]])
+        assert cnt[b].cpu().tolist()[1] == int((vm[b] & (np.sqrt(Q[b][idx[b]] * Q[b]) > 1.5)).sum())

@@ -25,7 +25,8 @@ enum {
     M3_EPI_F32 = 2,        /* C(f32)  = acc + bias */
     M3_EPI_F32_ACCUM = 3,  /* C(f32)  = R(f32) + acc + bias   (residual stream; C may alias R) */
     M3_EPI_BF16_RELU = 4,  /* C(bf16) = relu(acc + bias) */
-    M3_EPI_BF16_ADD = 5    /* C(bf16) = R(bf16) + acc + bias  (C may alias R) */
+    M3_EPI_BF16_ADD = 5,   /* C(bf16) = R(bf16) + acc + bias  (C may alias R) */
+    M3_EPI_BF16_ROPE = 6   /* C(bf16) = rope2d(acc + bias) on the leading rope_cols columns */
 };
 
 /* C[M,N] = epi(A[M,K] . W[N,K]^T + bias): A, W bf16 K-major (torch nn.Linear layout), fp32
@@ -39,6 +40,14 @@ int m3_gemm_bf16(const void *A, const void *W, const float *bias, void *C, const
 int m3_gemm_bf16_rope(const void *A, const void *W, const float *bias, void *C, int M, int N, int K,
                       int ldc, const int32_t *pos_yx, const float *cos_sin, int tokens_per_image,
                       int rope_cols, void *stream);
+
+/* Two same-shape GEMMs in one launch (the two decoder branches have different weights): group g
+ * (0/1) computes C + g*c_gstride = epi((A + g*a_gstride) . W[g]^T + bias[g]); strides in elements.
+ * epilogue may be any M3_EPI_* including M3_EPI_BF16_ROPE (= 6; then the RoPE tables are required). */
+int m3_gemm_bf16_grouped2(const void *A, const void *W0, const void *W1, const float *bias0,
+                          const float *bias1, void *C, const void *R, int M, int N, int K, int ldc,
+                          int64_t a_gstride, int64_t c_gstride, int epilogue, const int32_t *pos_yx,
+                          const float *cos_sin, int tokens_per_image, int rope_cols, void *stream);
 
 /* 3x3 convolution, padding 1, stride 1 or 2, as an implicit GEMM: X bf16 NHWC [B,H,W,Cin],
  * W bf16 [Cout,3,3,Cin], Y NHWC [B,OH,OW,Cout].  Cin % 64 == 0, Cout % 4 == 0.  zero16: 16
@@ -66,6 +75,13 @@ int m3_rope2d_bf16(void *X, const int32_t *pos_yx, const float *cos_sin, int row
 /* y(bf16)[M,C] = LayerNorm(x(f32)[M,C]) * gamma + beta; C % 256 == 0, C <= 2048. */
 int m3_layernorm_bf16(const float *x, const float *gamma, const float *beta, void *y, int M, int C,
                       float eps, void *stream);
+
+/* Two-group LayerNorm in one launch: rows [0,M) use (gamma0,beta0), rows [M,2M) use (gamma1,beta1);
+ * output row r normalises input row (r + in_row_shift) % (2M) (in_row_shift = M swaps the halves:
+ * the decoder's norm_y of the OTHER view). */
+int m3_layernorm_bf16_grouped2(const float *x, const float *gamma0, const float *beta0, const float *gamma1,
+                               const float *beta1, void *y, int M, int C, int in_row_shift, float eps,
+                               void *stream);
 
 /* uint8 image [B,H,W,3] -> bf16 patch matrix [B*(H/16)*(W/16), 768] (column c*256+py*16+px),
  * normalised (v/255-0.5)/0.5 (resize_img, mast3r_utils.py:186-188). */

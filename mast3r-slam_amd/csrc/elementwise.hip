@@ -21,11 +21,15 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 template <int VPL /* float4 per lane */>
 __global__ void __launch_bounds__(kThreads)
 k_layernorm(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
-            bf16_t *__restrict__ y, int M, int C, float eps) {
+            const float *__restrict__ gamma2, const float *__restrict__ beta2, bf16_t *__restrict__ y, int M, int C,
+            int split, int in_shift, float eps) {
     const int row = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
     if (row >= M) return;
     const int lane = threadIdx.x & 63;
-    const float4 *xr = reinterpret_cast<const float4 *>(x + (size_t)row * C);
+    if (row >= split) { gamma = gamma2; beta = beta2; }
+    int in_row = row + in_shift;
+    in_row = in_row >= M ? in_row - M : in_row;
+    const float4 *xr = reinterpret_cast<const float4 *>(x + (size_t)in_row * C);
     float4 v[VPL];
     float s = 0.f;
 #pragma unroll
@@ -220,13 +224,29 @@ int m3_layernorm_bf16(const float *x, const float *gamma, const float *beta, voi
     M3_REQUIRE(x && gamma && beta && y && M > 0 && C > 0 && C % 256 == 0 && C <= 2048);
     dim3 grid(m3_cdiv(M, kThreads / 64)), blk(kThreads);
     hipStream_t st = (hipStream_t)stream;
-#define M3_LN(V) case V: hipLaunchKernelGGL(k_layernorm<V>, grid, blk, 0, st, x, gamma, beta, (bf16_t *)y, M, C, eps); break
+#define M3_LN(V) case V: hipLaunchKernelGGL(k_layernorm<V>, grid, blk, 0, st, x, gamma, beta, gamma, beta, (bf16_t *)y, M, C, M, 0, eps); break
     switch (C / 256) {
         M3_LN(1); M3_LN(2); M3_LN(3); M3_LN(4); M3_LN(5); M3_LN(6); M3_LN(7); M3_LN(8);
         default: return M3_ERR_UNSUPPORTED;
     }
 #undef M3_LN
     M3_CHECK_LAUNCH("m3_layernorm_bf16");
+    return M3_OK;
+}
+
+int m3_layernorm_bf16_grouped2(const float *x, const float *gamma0, const float *beta0, const float *gamma1,
+                               const float *beta1, void *y, int M, int C, int in_row_shift, float eps, void *stream) {
+    M3_REQUIRE(x && gamma0 && beta0 && gamma1 && beta1 && y && M > 0 && C > 0 && C % 256 == 0 && C <= 2048);
+    M3_REQUIRE(in_row_shift == 0 || in_row_shift == M);
+    dim3 grid(m3_cdiv(2 * M, kThreads / 64)), blk(kThreads);
+    hipStream_t st = (hipStream_t)stream;
+#define M3_LN(V) case V: hipLaunchKernelGGL(k_layernorm<V>, grid, blk, 0, st, x, gamma0, beta0, gamma1, beta1, (bf16_t *)y, 2 * M, C, M, in_row_shift, eps); break
+    switch (C / 256) {
+        M3_LN(1); M3_LN(2); M3_LN(3); M3_LN(4); M3_LN(5); M3_LN(6); M3_LN(7); M3_LN(8);
+        default: return M3_ERR_UNSUPPORTED;
+    }
+#undef M3_LN
+    M3_CHECK_LAUNCH("m3_layernorm_bf16_grouped2");
     return M3_OK;
 }
 

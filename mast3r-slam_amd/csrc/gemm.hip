@@ -30,7 +30,8 @@ constexpr int kLdsBytes = 2 * kStageBytes;               // 64 KiB
 
 template <int MODE /*0 dense, 1 conv3x3*/, int EPI>
 __global__ void __launch_bounds__(kThreads)
-k_gemm(const GemmArgs g) {
+k_gemm(const GemmArgs gin) {
+    const GemmArgs g = select_group<EPI>(gin, blockIdx.y);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;               // wave position in the 2x2 grid (M, N)
@@ -146,7 +147,7 @@ k_gemm(const GemmArgs g) {
 template <int MODE>
 int launch(const GemmArgs &a, int epi, hipStream_t st) {
     const int tiles = m3_cdiv(a.M, BM) * m3_cdiv(a.N, BN);
-    dim3 grid(tiles), blk(kThreads);
+    dim3 grid(tiles, a.groups > 1 ? a.groups : 1), blk(kThreads);
 #define M3_L(E) case E: hipLaunchKernelGGL((k_gemm<MODE, E>), grid, blk, kLdsBytes, st, a); break
     switch (epi) {
         M3_L(EPI_BF16); M3_L(EPI_BF16_GELU); M3_L(EPI_F32); M3_L(EPI_F32_ACCUM); M3_L(EPI_BF16_RELU); M3_L(EPI_BF16_ADD); M3_L(EPI_BF16_ROPE);
@@ -160,11 +161,11 @@ int launch(const GemmArgs &a, int epi, hipStream_t st) {
 // Tile choice: the 256x256 ping-pong kernel runs one workgroup per CU, the 128x128 kernel two.
 // Estimated cost = rounds over the 256 CUs x work per tile (the 256 kernel is ~1.4x more efficient
 // per FLOP once the grid fills the chip).  M3_GEMM_TILE=128|256 forces a path (experiments).
-bool use_256(int M, int N) {
+bool use_256(int M, int N, int groups = 1) {
     static const int forced = [] { const char *e = getenv("M3_GEMM_TILE"); return e ? atoi(e) : 0; }();
     if (forced == 128) return false;
     if (forced == 256) return true;
-    const long t256 = (long)m3_cdiv(M, 256) * m3_cdiv(N, 256), t128 = (long)m3_cdiv(M, 128) * m3_cdiv(N, 128);
+    const long t256 = (long)m3_cdiv(M, 256) * m3_cdiv(N, 256) * groups, t128 = (long)m3_cdiv(M, 128) * m3_cdiv(N, 128) * groups;
     const double c256 = (double)((t256 + 255) / 256) * 4.0 / 1.4, c128 = (double)((t128 + 511) / 512) * 2.0;
     return c256 < c128;
 }
@@ -199,6 +200,27 @@ int m3_gemm_bf16_rope(const void *A, const void *W, const float *bias, void *C, 
     a.pos_yx = pos_yx; a.cos_sin = cos_sin; a.tokens_per_image = tokens_per_image; a.rope_cols = rope_cols;
     if (use_256(M, N)) return m3_launch_gemm256_dense(a, EPI_BF16_ROPE, (hipStream_t)stream);
     return launch<0>(a, EPI_BF16_ROPE, (hipStream_t)stream);
+}
+
+// Two GEMMs of identical shape in one launch (the two decoder branches / the two heads):
+// group g reads A + g*a_gstride, weights W[g], bias[g] and writes C + g*c_gstride.
+int m3_gemm_bf16_grouped2(const void *A, const void *W0, const void *W1, const float *bias0, const float *bias1,
+                          void *C, const void *R, int M, int N, int K, int ldc, int64_t a_gstride,
+                          int64_t c_gstride, int epilogue, const int32_t *pos_yx, const float *cos_sin,
+                          int tokens_per_image, int rope_cols, void *stream) {
+    M3_REQUIRE(A && W0 && W1 && C && M > 0 && N > 0 && K > 0);
+    M3_REQUIRE(K % BK == 0 && N % 4 == 0 && ldc >= N && ldc % 4 == 0);
+    M3_REQUIRE(!((epilogue == EPI_F32_ACCUM || epilogue == EPI_BF16_ADD) && !R));
+    M3_REQUIRE((bias0 == nullptr) == (bias1 == nullptr));
+    if (epilogue == EPI_BF16_ROPE)
+        M3_REQUIRE(pos_yx && cos_sin && tokens_per_image > 0 && N % 64 == 0 && rope_cols % 64 == 0 && rope_cols <= N);
+    GemmArgs a{};
+    a.A = (const bf16_t *)A; a.W = (const bf16_t *)W0; a.W2 = (const bf16_t *)W1; a.bias = bias0; a.bias2 = bias1;
+    a.C = C; a.R = R; a.M = M; a.N = N; a.K = K; a.ldc = ldc;
+    a.a_gstride = a_gstride; a.c_gstride = c_gstride; a.groups = 2;
+    a.pos_yx = pos_yx; a.cos_sin = cos_sin; a.tokens_per_image = tokens_per_image; a.rope_cols = rope_cols;
+    if (use_256(M, N, 2)) return m3_launch_gemm256_dense(a, epilogue, (hipStream_t)stream);
+    return launch<0>(a, epilogue, (hipStream_t)stream);
 }
 
 int m3_conv3x3_bf16(const void *X, const void *W, const float *bias, void *Y, const void *R, const void *zero16,

@@ -26,7 +26,8 @@ constexpr int kLdsBytes = 2 * kStageBytes;               // 128 KiB
 
 template <int MODE /*0 dense, 1 conv3x3*/, int EPI>
 __global__ void __launch_bounds__(kThreads, 2)
-k_gemm256(const GemmArgs g) {
+k_gemm256(const GemmArgs gin) {
+    const GemmArgs g = select_group<EPI>(gin, blockIdx.y);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int group = wave >> 2;                            // 0 = ping (first wave of each SIMD), 1 = pong
@@ -187,7 +188,7 @@ k_gemm256(const GemmArgs g) {
 template <int MODE>
 int launch256(const GemmArgs &a, int epi, hipStream_t st) {
     const int tiles = m3_cdiv(a.M, BM) * m3_cdiv(a.N, BN);
-    dim3 grid(tiles), blk(kThreads);
+    dim3 grid(tiles, a.groups > 1 ? a.groups : 1), blk(kThreads);
 #define M3_L(E)                                                                                              \
     case E: {                                                                                                \
         static bool attr_set = false;                                                                        \

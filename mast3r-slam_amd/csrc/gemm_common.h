@@ -51,7 +51,27 @@ struct GemmArgs {
     const int *pos_yx;      // [tokens_per_image, 2]
     const float *cos_sin;   // [max_pos, 16, 2]
     int tokens_per_image, rope_cols;
+    // grouped launch (blockIdx.y = group): group 1 uses W2/bias2 and A/C/R advanced by the strides
+    const bf16_t *W2;
+    const float *bias2;
+    long long a_gstride, c_gstride;   // elements of A, elements of C/R
+    int groups;
 };
+
+// Per-group view of the arguments (group 1 of a 2-group launch).
+template <int EPI>
+__device__ __forceinline__ GemmArgs select_group(const GemmArgs &in, int grp) {
+    GemmArgs g = in;
+    if (grp == 1) {
+        constexpr long long esz = (EPI == 2 /*EPI_F32*/ || EPI == 3 /*EPI_F32_ACCUM*/) ? 4 : 2;
+        g.A = in.A + in.a_gstride;
+        g.W = in.W2;
+        g.bias = in.bias2;
+        g.C = reinterpret_cast<unsigned char *>(in.C) + in.c_gstride * esz;
+        if (in.R) g.R = reinterpret_cast<const unsigned char *>(in.R) + in.c_gstride * esz;
+    }
+    return g;
+}
 
 enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32 = 2, EPI_F32_ACCUM = 3, EPI_BF16_RELU = 4, EPI_BF16_ADD = 5,
        EPI_BF16_ROPE = 6 };

@@ -291,47 +291,58 @@ class Mast3rFull:
     # ------------------------------------------------------------------ decoder
     def decode_tokens(self, f1: torch.Tensor, f2: torch.Tensor, npairs: int, grid):
         """f1, f2 bf16 [P*T,1024] (enc_norm outputs of view 1 / view 2) -> two lists of DPT taps
-        (bf16 [P*T,C]) at hooks (0, 6, 9, 12)."""
+        (bf16 [P*T,C]) at the configured hooks.  The two decoder branches (different weights, same
+        shapes) run as 2-group launches: one GEMM / LayerNorm / attention launch serves both views."""
         P, c = self.P, self.cfg
         gh, gw = grid
         t = gh * gw
         pos, cs = self._rope(gh, gw)
         D, heads = c["dec_dim"], c["dec_heads"]
         m = npairs * t
-        xs = [ops.gemm(f, P["decoder_embed.w"], P["decoder_embed.b"], ops.EPI_F32) for f in (f1, f2)]
+        dev = f1.device
+        fcat = torch.stack([f1, f2])                                                     # [2,M,1024]
+        x = ops.gemm_grouped2(fcat, P["decoder_embed.w"], P["decoder_embed.w"], P["decoder_embed.b"],
+                              P["decoder_embed.b"], ops.EPI_F32)                         # fp32 residual streams [2,M,D]
         taps = [[f1], [f2]]
         hooks = set(c["hooks"])
+        W = lambda i, s: (P[f"dec_blocks.{i}.{s}"], P[f"dec_blocks2.{i}.{s}"])
         for i in range(c["dec_depth"]):
-            names = (f"dec_blocks.{i}", f"dec_blocks2.{i}")
-            # cross-attention memories come from the PREVIOUS layer's tokens of the other view
-            kvs = []
-            for v, p in enumerate(names):
-                yn = ops.layernorm(xs[1 - v], P[p + ".norm_y.g"], P[p + ".norm_y.b"])
-                kv = ops.gemm_rope(yn, P[p + ".cross_attn.kv.w"], P[p + ".cross_attn.kv.b"], pos, cs, t, D)  # [M,2D]
-                kvs.append(kv)
-            for v, p in enumerate(names):
-                x = xs[v]
-                xn = ops.layernorm(x, P[p + ".norm1.g"], P[p + ".norm1.b"])
-                a = self._self_attn(xn, p + ".attn", heads, npairs, t, pos, cs)
-                ops.gemm(a, P[p + ".attn.proj.w"], P[p + ".attn.proj.b"], ops.EPI_F32_ACCUM, out=x, resid=x)
-                xn = ops.layernorm(x, P[p + ".norm2.g"], P[p + ".norm2.b"])
-                q = ops.gemm_rope(xn, P[p + ".cross_attn.projq.w"], P[p + ".cross_attn.projq.b"], pos, cs, t, D)
-                kv = kvs[v]
-                a = torch.empty((m, D), dtype=torch.bfloat16, device=x.device)
-                ops.attention(q, kv, kv[:, D:], a, nbatch=npairs, heads=heads, tq=t, tk=t, q_row_stride=D,
-                              kv_row_stride=2 * D, o_row_stride=D, q_batch_stride=t * D,
-                              kv_batch_stride=t * 2 * D, o_batch_stride=t * D)
-                ops.gemm(a, P[p + ".cross_attn.proj.w"], P[p + ".cross_attn.proj.b"], ops.EPI_F32_ACCUM, out=x, resid=x)
-                xn = ops.layernorm(x, P[p + ".norm3.g"], P[p + ".norm3.b"])
-                hdn = ops.gemm(xn, P[p + ".mlp.fc1.w"], P[p + ".mlp.fc1.b"], ops.EPI_BF16_GELU)
-                ops.gemm(hdn, P[p + ".mlp.fc2.w"], P[p + ".mlp.fc2.b"], ops.EPI_F32_ACCUM, out=x, resid=x)
+            # cross-attention memory: norm_y of the OTHER view's previous-layer tokens, then k|v projection
+            yn = ops.layernorm_grouped2(x, *W(i, "norm_y.g")[:1], W(i, "norm_y.b")[0], W(i, "norm_y.g")[1],
+                                        W(i, "norm_y.b")[1], swap=True)
+            kv = ops.gemm_grouped2(yn, *W(i, "cross_attn.kv.w"), *W(i, "cross_attn.kv.b"), ops.EPI_BF16_ROPE,
+                                   rope=(pos, cs, t, D))                                  # [2,M,2D], k rotated
+            # self-attention
+            xn = ops.layernorm_grouped2(x, W(i, "norm1.g")[0], W(i, "norm1.b")[0], W(i, "norm1.g")[1], W(i, "norm1.b")[1])
+            qkv = ops.gemm_grouped2(xn, *W(i, "attn.qkv.w"), *W(i, "attn.qkv.b"), ops.EPI_BF16_ROPE,
+                                    rope=(pos, cs, t, 2 * D)).view(2 * m, 3 * D)
+            a = torch.empty((2, m, D), dtype=torch.bfloat16, device=dev)
+            ops.attention(qkv, qkv[:, D:], qkv[:, 2 * D:], a, nbatch=2 * npairs, heads=heads, tq=t, tk=t,
+                          q_row_stride=3 * D, kv_row_stride=3 * D, o_row_stride=D, q_batch_stride=t * 3 * D,
+                          kv_batch_stride=t * 3 * D, o_batch_stride=t * D)
+            ops.gemm_grouped2(a, *W(i, "attn.proj.w"), *W(i, "attn.proj.b"), ops.EPI_F32_ACCUM, out=x, resid=x)
+            # cross-attention
+            xn = ops.layernorm_grouped2(x, W(i, "norm2.g")[0], W(i, "norm2.b")[0], W(i, "norm2.g")[1], W(i, "norm2.b")[1])
+            q = ops.gemm_grouped2(xn, *W(i, "cross_attn.projq.w"), *W(i, "cross_attn.projq.b"), ops.EPI_BF16_ROPE,
+                                  rope=(pos, cs, t, D)).view(2 * m, D)
+            kvf = kv.view(2 * m, 2 * D)
+            a = torch.empty((2, m, D), dtype=torch.bfloat16, device=dev)
+            ops.attention(q, kvf, kvf[:, D:], a, nbatch=2 * npairs, heads=heads, tq=t, tk=t, q_row_stride=D,
+                          kv_row_stride=2 * D, o_row_stride=D, q_batch_stride=t * D, kv_batch_stride=t * 2 * D,
+                          o_batch_stride=t * D)
+            ops.gemm_grouped2(a, *W(i, "cross_attn.proj.w"), *W(i, "cross_attn.proj.b"), ops.EPI_F32_ACCUM, out=x, resid=x)
+            # MLP
+            xn = ops.layernorm_grouped2(x, W(i, "norm3.g")[0], W(i, "norm3.b")[0], W(i, "norm3.g")[1], W(i, "norm3.b")[1])
+            hdn = ops.gemm_grouped2(xn, *W(i, "mlp.fc1.w"), *W(i, "mlp.fc1.b"), ops.EPI_BF16_GELU)
+            ops.gemm_grouped2(hdn, *W(i, "mlp.fc2.w"), *W(i, "mlp.fc2.b"), ops.EPI_F32_ACCUM, out=x, resid=x)
             layer = i + 1
             if layer in hooks:
-                for v in range(2):
-                    if layer == c["dec_depth"]:
-                        taps[v].append(ops.layernorm(xs[v], P["dec_norm.g"], P["dec_norm.b"]))
-                    else:
-                        taps[v].append(ops.f32_to_bf16(xs[v]))
+                if layer == c["dec_depth"]:
+                    tap = ops.layernorm_grouped2(x, P["dec_norm.g"], P["dec_norm.b"], P["dec_norm.g"], P["dec_norm.b"])
+                else:
+                    tap = ops.f32_to_bf16(x)
+                taps[0].append(tap[0])
+                taps[1].append(tap[1])
         return taps
 
     # ------------------------------------------------------------------ heads

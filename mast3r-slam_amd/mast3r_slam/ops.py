@@ -9,7 +9,7 @@ import torch
 
 from . import _ffi
 
-EPI_BF16, EPI_BF16_GELU, EPI_F32, EPI_F32_ACCUM, EPI_BF16_RELU, EPI_BF16_ADD = range(6)
+EPI_BF16, EPI_BF16_GELU, EPI_F32, EPI_F32_ACCUM, EPI_BF16_RELU, EPI_BF16_ADD, EPI_BF16_ROPE = range(7)
 _F32_EPIS = (EPI_F32, EPI_F32_ACCUM)
 
 _zero16 = {}
@@ -212,4 +212,39 @@ def add(a, b):
     b = _ffi.check(b, torch.bfloat16, "b", tuple(a.shape))
     out = torch.empty_like(a)
     _ffi.call("m3_add_bf16", _ffi.ptr(a), _ffi.ptr(b), _ffi.ptr(out), a.numel(), _ffi.stream_ptr())
+    return out
+
+
+def gemm_grouped2(a, w0, w1, b0, b1, epi=EPI_BF16, out=None, resid=None, rope=None):
+    """Two same-shape GEMMs in one launch.  a [2,M,K] bf16, weights [N,K] x2 -> out [2,M,N].
+    rope = (pos_yx, cos_sin, tokens_per_image, rope_cols) with epi=EPI_BF16_ROPE."""
+    a = _ffi.check(a, torch.bfloat16, "a")
+    if a.dim() != 3 or a.shape[0] != 2:
+        raise ValueError(f"a must be [2,M,K], got {tuple(a.shape)}")
+    _, m, k = a.shape
+    w0 = _ffi.check(w0, torch.bfloat16, "w0")
+    w1 = _ffi.check(w1, torch.bfloat16, "w1", tuple(w0.shape))
+    n = w0.shape[0]
+    odt = torch.float32 if epi in _F32_EPIS else torch.bfloat16
+    if out is None:
+        out = torch.empty((2, m, n), dtype=odt, device=a.device)
+    elif out.dtype != odt or tuple(out.shape) != (2, m, n) or not out.is_contiguous():
+        raise ValueError("bad `out`")
+    if resid is not None and (resid.dtype != odt or tuple(resid.shape) != (2, m, n) or not resid.is_contiguous()):
+        raise ValueError("bad `resid`")
+    pos, cs, tpi, rc = rope if rope is not None else (None, None, 0, 0)
+    e0 = _prof_begin()
+    _ffi.call("m3_gemm_bf16_grouped2", _ffi.ptr(a), _ffi.ptr(w0), _ffi.ptr(w1), _ffi.ptr(b0), _ffi.ptr(b1), _ffi.ptr(out),
+              _ffi.ptr(resid), m, n, k, n, m * k, m * n, epi, _ffi.ptr(pos), _ffi.ptr(cs), tpi, rc, _ffi.stream_ptr())
+    _prof_end(e0, "gemm", 4.0 * m * n * k)
+    return out
+
+
+def layernorm_grouped2(x, g0, b0, g1, b1, swap=False, eps=1e-6):
+    """x f32 [2,M,C] -> bf16 [2,M,C]; group v uses (g_v, b_v); swap=True normalises the OTHER group's rows."""
+    x = _ffi.check(x, torch.float32, "x")
+    _, m, c = x.shape
+    out = torch.empty((2, m, c), dtype=torch.bfloat16, device=x.device)
+    _ffi.call("m3_layernorm_bf16_grouped2", _ffi.ptr(x), _ffi.ptr(g0), _ffi.ptr(b0), _ffi.ptr(g1), _ffi.ptr(b1),
+              _ffi.ptr(out), m, c, m if swap else 0, float(eps), _ffi.stream_ptr())
     return out

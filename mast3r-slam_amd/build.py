@@ -22,7 +22,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fhip-fp32-cor
           "-Wall", "-Wno-unused-function"]
 PER_FILE = {
     "matching.hip": ["-ffp-contract=off"],
-    "tracking.hip": ["-fno-slp-vectorize"],
+    "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
 }
 
 

@@ -132,7 +132,7 @@ k_attn(const AttnArgs a) {
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run[qt], mx);
-            const float alpha = exp2f((m_run[qt] - m_new) * a.scale_log2e);
+            const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * a.scale_log2e);
             const float mb = m_new * a.scale_log2e;
             m_run[qt] = m_new;
             float rs = 0.f;
@@ -140,15 +140,17 @@ k_attn(const AttnArgs a) {
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = exp2f(s[qt][kt][r] * a.scale_log2e - mb);
+                    const float p = __builtin_amdgcn_exp2f(s[qt][kt][r] * a.scale_log2e - mb);
                     s[qt][kt][r] = p;
                     rs += p;
                 }
             l_run[qt] = l_run[qt] * alpha + rs;
+            if (!__all(alpha == 1.0f)) {       // exact skip: no row of this wave raised its running max
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+                for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
+                    for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
+            }
             // P fragment for k-step kk: element j<4 -> key (2kk)*16 + g*4 + j, j>=4 -> key (2kk+1)*16 + g*4 + j-4
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {

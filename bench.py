@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs-per-gpu", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args()
 
@@ -116,8 +117,25 @@ def main():
                 timers[k] += a.elapsed_time(b)
         return out
 
+    # Capture the whole step (~1500 launches) into a hipGraph: replay removes the host launch path,
+    # which matters for small per-GPU batches (a B=1 step is launch-bound when issued eagerly).
+    graph = None
+    if not args.no_graph and world == 1:
+        try:
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                graph_out = step()
+            torch.cuda.synchronize()
+        except Exception as e:                                   # noqa: BLE001 - reported, never silent
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graph = None
+    run_step = (lambda: graph.replay()) if graph is not None else step
+
     for _ in range(args.warmup):
-        step()
+        run_step()
 
     def barrier():
         if dist is not None:
@@ -127,7 +145,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run_step()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -166,7 +184,7 @@ def main():
                                "two-view MASt3R ViT-L infer + iter_proj/refine match + 10-iter GN tracking"
                                + ("" if world == 1 else " + RCCL all-gather of results"),
                    "pairs_per_gpu": P, "global_pairs": world * P, "image": [H, W], "gn_iters": tcfg["max_iters"],
-                   "parallelism": f"pair-sharded x{world}"},
+                   "parallelism": f"pair-sharded x{world}", "launch": "hipGraph replay" if graph is not None else "eager"},
         "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
         "model_tflop_per_step": model_flops / 1e12,
         "roofline": {"bound": "mfma", "kernel": "k_gemm (bf16 MFMA GEMM, 128x128x64 tile)",

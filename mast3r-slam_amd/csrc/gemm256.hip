@@ -8,7 +8,7 @@
 //     4 global_load_lds and 12 ds_read_b128;
 //   * one workgroup per CU (128 KiB LDS, two stages), so the two waves that share a SIMD belong to
 //     the same workgroup: waves 0-3 ("ping") and 4-7 ("pong") run the SAME per-K-tile sequence
-//          READ(ks0)+LOADS(next tile) | MFMA(ks0) | READ(ks1) | MFMA(ks1)
+//          READ(ks0)+LOADS(A half of next tile) | MFMA(ks0) | READ(ks1)+LOADS(W half) | MFMA(ks1)
 //     one phase apart, a workgroup barrier between phases - while one wave of a SIMD issues its
 //     32 MFMAs the other one issues its LDS reads / global loads.  Each group has its own
 //     straight-line loop (register liveness stays per phase); both execute the same barrier count.
@@ -63,7 +63,8 @@ k_gemm256(const GemmArgs gin) {
     }
     const int nk = g.K / BK;
 
-    auto stage = [&](int kt, int buf) {
+    // K-tile staging in two halves (4 global_load_lds each) so the load issue is spread over phases
+    auto stage_a = [&](int kt, int buf) {
         unsigned char *base = lds + buf * kStageBytes;
         int ky = 0, kx = 0, c0 = 0;
         if (MODE == 1) {
@@ -83,10 +84,14 @@ k_gemm256(const GemmArgs gin) {
             }
             glds16(src, base + i * 8192 + wave * 1024);
         }
+    };
+    auto stage_w = [&](int kt, int buf) {
+        unsigned char *base = lds + buf * kStageBytes;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             glds16(w_src[i] + (size_t)kt * BK, base + BM * BK * 2 + i * 8192 + wave * 1024);
     };
+    auto stage = [&](int kt, int buf) { stage_a(kt, buf); stage_w(kt, buf); };
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -145,12 +150,13 @@ k_gemm256(const GemmArgs gin) {
         for (int kt = 0; kt < nk; ++kt) {
             const int buf = kt & 1;
             read_frags(buf, 0);                            // phase 0
-            if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+            if (kt + 1 < nk) stage_a(kt + 1, buf ^ 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             phase_end();
             mfma_all();                                    // phase 1
             phase_end();
             read_frags(buf, 1);                            // phase 2
+            if (kt + 1 < nk) stage_w(kt + 1, buf ^ 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             phase_end();
             mfma_all();                                    // phase 3
@@ -163,10 +169,11 @@ k_gemm256(const GemmArgs gin) {
             if (kt > 0) mfma_all();                        // phase 0: k-step 1 of the previous tile
             phase_end();
             read_frags(buf, 0);                            // phase 1
-            if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+            if (kt + 1 < nk) stage_a(kt + 1, buf ^ 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             phase_end();
-            mfma_all();                                    // phase 2
+            if (kt + 1 < nk) stage_w(kt + 1, buf ^ 1);     // phase 2: loads issue under this wave's own MFMAs
+            mfma_all();
             phase_end();
             read_frags(buf, 1);                            // phase 3
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

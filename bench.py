@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-b1", action="store_true", help="skip the extra batch=1 (BASELINE configs[1]) latency measurement")
     return ap.parse_args()
 
 
@@ -187,12 +188,43 @@ def main():
                    "parallelism": f"pair-sharded x{world}", "launch": "hipGraph replay" if graph is not None else "eager"},
         "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
         "model_tflop_per_step": model_flops / 1e12,
-        "roofline": {"bound": "mfma", "kernel": "k_gemm (bf16 MFMA GEMM, 128x128x64 tile)",
+        "roofline": {"bound": "mfma", "kernel": "k_gemm256 / k_gemm (bf16 MFMA GEMM, 256x256x64 ping-pong and 128x128x64 tiles)",
                      "achieved": gemm_tflops, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": gemm_tflops / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
                      "launches": g[2], "avg_launch_us": g[1] / max(g[2], 1) * 1e6,
                      "other_kernels_tflops": {k: v[0] / v[1] / 1e12 for k, v in by_kind.items() if k != "gemm"}},
     }
+
+    if world == 1 and not args.no_b1 and P != 1:
+        # BASELINE configs[1]: one pair per step (latency regime), same pipeline, graph-replayed
+        a1, b1 = im1[:1].contiguous(), im2[:1].contiguous()
+
+        def step1():
+            o1, o2 = net.reconstruct_batch(a1, b1)
+            idx, valid = matching.match(o1["pts3d"], o2["pts3d"], o1["desc"], o2["desc"])
+            Xf, Qk, vo, vk, cnt = tracker.track_gather(
+                o1["pts3d"].reshape(1, n, 3), o1["conf"].reshape(1, n), o2["conf"].reshape(1, n),
+                o1["desc_conf"].reshape(1, n), o2["desc_conf"].reshape(1, n), idx, valid.reshape(1, n),
+                tcfg["C_conf"], tcfg["Q_conf"])
+            return tracker.opt_pose_ray_dist_sim3(Xf, o2["pts3d"].reshape(1, n, 3), ident, ident, Qk, vo, tcfg,
+                                                  fixed_iters=True)
+        for _ in range(2):
+            step1()
+        torch.cuda.synchronize()
+        run1 = step1
+        if graph is not None:
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                keep = step1()
+            run1 = g1.replay
+        run1(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            run1()
+        torch.cuda.synchronize()
+        ms1 = (time.perf_counter() - t1) / 10 * 1e3
+        result["batch1"] = {"workload": "BASELINE configs[1]: 1 pair/step at 512x512, same pipeline", "pairs_per_s": 1e3 / ms1,
+                            "ms_per_pair": ms1}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, net)

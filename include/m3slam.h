@@ -145,12 +145,15 @@ int m3_sim3_act(const float *T, const float *X, float *out, int N, void *stream)
  * reduction gn_metal_runner.py:221-292).  Twc [K,8], Xs [K,P,3], Cs [K,P], ii,jj int32 [E],
  * idx int32 [E,P], valid uint8 [E,P], Q [E,P] -> blocks double [E,36] = (Hjj upper triangle
  * 28, gj 7, valid count 1).  With the reference's Ji = -Jj: Hii = Hjj, Hij = -Hjj, gi = -gj.
- * ws: double [E * m3_gn_rays_chunks(P) * 36]. */
+ * ws: double [E * m3_gn_rays_chunks(P) * 36].
+ * point_mode = 1 selects kernels.gauss_newton_points (kernels.py:396-460, numpy twin
+ * gauss_newton_points.py:17-207; Metal gn_points_jacobian_kernel gauss_newton_points.metal:65):
+ * the same residual with the extra scale-invariant weight 1/(|Xi| + 1e-6) and sigma = sigma_point. */
 int m3_gn_rays_chunks(int P);
 int m3_gn_rays_blocks(const float *Twc, const float *Xs, const float *Cs, const int32_t *ii,
                       const int32_t *jj, const int32_t *idx, const uint8_t *valid, const float *Q,
                       double *blocks, double *ws, int K, int P, int E, float sigma_ray,
-                      float C_thresh, float Q_thresh, void *stream);
+                      float C_thresh, float Q_thresh, int point_mode, void *stream);
 
 /* Dense normal equations from the per-edge blocks (gauss_newton.py:220-251): H double
  * [dim,dim], g double [dim], dim = 7*num_free (both zeroed by the call; the 1e-6 I
@@ -175,7 +178,7 @@ int m3_gn_rays_solve(float *Twc, const float *Xs, const float *Cs, const int32_t
                      const int32_t *jj, const int32_t *idx, const uint8_t *valid, const float *Q,
                      const int32_t *local, double *blocks, double *ws, double *Hbuf, double *info,
                      int K, int P, int E, int num_free, float sigma_ray, float C_thresh,
-                     float Q_thresh, int max_iter, float delta_thresh, void *stream);
+                     float Q_thresh, int max_iter, float delta_thresh, int point_mode, void *stream);
 
 #ifdef __cplusplus
 }

@@ -32,7 +32,7 @@ k_gn_blocks(const float *__restrict__ Twc, const float *__restrict__ Xs, const f
             const int32_t *__restrict__ ii, const int32_t *__restrict__ jj, const int32_t *__restrict__ idx,
             const uint8_t *__restrict__ valid, const float *__restrict__ Q, double *__restrict__ part,
             const double *__restrict__ done, int K, int P, int chunks, float inv_sigma, float C_thresh,
-            float Q_thresh) {
+            float Q_thresh, int point_mode) {
     if (done && done[0] != 0.0) return;
     const int e = blockIdx.y, chunk = blockIdx.x;
     const int ix = ii[e], jx = jj[e];
@@ -66,29 +66,28 @@ k_gn_blocks(const float *__restrict__ Twc, const float *__restrict__ Xs, const f
             const V3<float> Xj{Xj_base[3 * k], Xj_base[3 * k + 1], Xj_base[3 * k + 2]};
             const V3<float> Y = act(Tij, Xj);
             const float err[3] = {Y.x - Xi.x, Y.y - Xi.y, Y.z - Xi.z};
-            const float sqrt_w = inv_sigma * sqrtf(qc), w2 = sqrt_w * sqrt_w;
+            float sqrt_w = inv_sigma * sqrtf(qc);
+            if (point_mode)                                 // gauss_newton_points.py:103-107: 1/(|Xi| + 1e-6)
+                sqrt_w *= 1.0f / (sqrtf(dot(Xi, Xi)) + 1e-6f);
+            const float w2 = sqrt_w * sqrt_w;
             const V3<float> br[3] = {{0.f, Y.z, -Y.y}, {-Y.z, 0.f, Y.x}, {Y.y, -Y.x, 0.f}};
             const float Yc[3] = {Y.x, Y.y, Y.z};
-            float h[35];
-#pragma unroll
-            for (int i = 0; i < 35; ++i) h[i] = 0.f;
+            // accumulate straight into the float64 registers with a closed-form index (a temporary
+            // float h[] indexed by a running counter was mis-compiled in tracking.hip)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float we = fabsf(sqrt_w * err[c]);
                 const float w = ((we < 1.345f) ? 1.0f : 1.345f / we) * w2;
                 const V3<float> jr = qrot(qi_inv, br[c]);
                 const float J[7] = {jt[c].x, jt[c].y, jt[c].z, jr.x, jr.y, jr.z, Yc[c]};
-                int m = 0;
 #pragma unroll
                 for (int i = 0; i < 7; ++i) {
                     const float wj = w * J[i];
 #pragma unroll
-                    for (int j = i; j < 7; ++j) h[m++] += wj * J[j];
-                    h[28 + i] += wj * err[c];
+                    for (int j = i; j < 7; ++j) acc[i * 7 - (i * (i - 1)) / 2 + (j - i)] += (double)(wj * J[j]);
+                    acc[28 + i] += (double)(wj * err[c]);
                 }
             }
-#pragma unroll
-            for (int i = 0; i < 35; ++i) acc[i] += (double)h[i];
             acc[35] += 1.0;
         }
     }
@@ -245,11 +244,11 @@ __global__ void k_gn_info_init(double *info) {
 int launch_blocks(const float *Twc, const float *Xs, const float *Cs, const int32_t *ii, const int32_t *jj,
                   const int32_t *idx, const uint8_t *valid, const float *Q, double *blocks, double *ws,
                   const double *done, int K, int P, int E, float sigma_ray, float C_thresh, float Q_thresh,
-                  hipStream_t st) {
+                  int point_mode, hipStream_t st) {
     const int chunks = gn_chunks(P);
     const float inv_sigma = (float)(1.0 / (double)sigma_ray);
     hipLaunchKernelGGL(k_gn_blocks, dim3(chunks, E), dim3(kThreads), 0, st, Twc, Xs, Cs, ii, jj, idx, valid, Q,
-                       ws, done, K, P, chunks, inv_sigma, C_thresh, Q_thresh);
+                       ws, done, K, P, chunks, inv_sigma, C_thresh, Q_thresh, point_mode);
     hipLaunchKernelGGL(k_gn_reduce, dim3(E), dim3(64), 0, st, (const double *)ws, blocks, done, chunks);
     M3_CHECK_LAUNCH("m3_gn_rays_blocks");
     return M3_OK;
@@ -264,11 +263,11 @@ int m3_gn_rays_max_dim(void) { return kMaxDim; }
 
 int m3_gn_rays_blocks(const float *Twc, const float *Xs, const float *Cs, const int32_t *ii, const int32_t *jj,
                       const int32_t *idx, const uint8_t *valid, const float *Q, double *blocks, double *ws,
-                      int K, int P, int E, float sigma_ray, float C_thresh, float Q_thresh, void *stream) {
+                      int K, int P, int E, float sigma_ray, float C_thresh, float Q_thresh, int point_mode, void *stream) {
     M3_REQUIRE(Twc && Xs && Cs && ii && jj && idx && valid && Q && blocks && ws);
-    M3_REQUIRE(K > 0 && P > 0 && E > 0 && E <= 65535 && sigma_ray > 0.f);
+    M3_REQUIRE(K > 0 && P > 0 && E > 0 && E <= 65535 && sigma_ray > 0.f && (point_mode == 0 || point_mode == 1));
     return launch_blocks(Twc, Xs, Cs, ii, jj, idx, valid, Q, blocks, ws, nullptr, K, P, E, sigma_ray, C_thresh,
-                         Q_thresh, (hipStream_t)stream);
+                         Q_thresh, point_mode, (hipStream_t)stream);
 }
 
 int m3_gn_rays_assemble(const double *blocks, const int32_t *ii, const int32_t *jj, const int32_t *local,
@@ -296,7 +295,7 @@ int m3_gn_rays_solve(float *Twc, const float *Xs, const float *Cs, const int32_t
                      const int32_t *idx, const uint8_t *valid, const float *Q, const int32_t *local,
                      double *blocks, double *ws, double *Hbuf, double *info, int K, int P, int E, int num_free,
                      float sigma_ray, float C_thresh, float Q_thresh, int max_iter, float delta_thresh,
-                     void *stream) {
+                     int point_mode, void *stream) {
     M3_REQUIRE(Twc && Xs && Cs && ii && jj && idx && valid && Q && local && blocks && ws && Hbuf && info);
     M3_REQUIRE(K > 0 && P > 0 && E > 0 && E <= 65535 && num_free > 0 && max_iter >= 0 && sigma_ray > 0.f);
     const int dim = 7 * num_free;
@@ -308,7 +307,7 @@ int m3_gn_rays_solve(float *Twc, const float *Xs, const float *Cs, const int32_t
     const int64_t count = (int64_t)dim * dim + dim;
     for (int it = 0; it < max_iter; ++it) {
         int rc = launch_blocks(Twc, Xs, Cs, ii, jj, idx, valid, Q, blocks, ws, done, K, P, E, sigma_ray, C_thresh,
-                               Q_thresh, st);
+                               Q_thresh, point_mode, st);
         if (rc != M3_OK) return rc;
         hipLaunchKernelGGL(k_gn_zero, dim3(m3_cdiv(count, kThreads) > 1024 ? 1024 : m3_cdiv(count, kThreads)),
                            dim3(kThreads), 0, st, Hbuf, done, count);

@@ -116,7 +116,7 @@ def _local_map(ii, jj, num_kf: int, pin: int):
 
 
 def gn_rays_blocks(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray: float = 0.003,
-                   C_thresh: float = 0.0, Q_thresh: float = 1.5):
+                   C_thresh: float = 0.0, Q_thresh: float = 1.5, point_mode: bool = False):
     """Per-edge normal-equation blocks [E,36] float64 = (Hjj upper 28, gj 7, count)."""
     t = _prep_gn(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q)
     k, p, e = t["K"], t["P"], t["E"]
@@ -125,7 +125,8 @@ def gn_rays_blocks(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray: fl
     ws = torch.empty(e * chunks * 36, dtype=torch.float64, device=t["Twc"].device)
     _ffi.call("m3_gn_rays_blocks", _ffi.ptr(t["Twc"]), _ffi.ptr(t["Xs"]), _ffi.ptr(t["Cs"]), _ffi.ptr(t["ii"]),
               _ffi.ptr(t["jj"]), _ffi.ptr(t["idx"]), _ffi.ptr(t["valid"]), _ffi.ptr(t["Q"]), _ffi.ptr(blocks),
-              _ffi.ptr(ws), k, p, e, float(sigma_ray), float(C_thresh), float(Q_thresh), _ffi.stream_ptr())
+              _ffi.ptr(ws), k, p, e, float(sigma_ray), float(C_thresh), float(Q_thresh), 1 if point_mode else 0,
+              _ffi.stream_ptr())
     return _out(blocks, t["np_in"])
 
 
@@ -163,7 +164,7 @@ def _prep_gn(Twc, Xs, Cs, ii, jj, idx, valid, Q):
 def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray: float = 0.003,
                       sigma_dist: float = 10.0, C_thresh: float = 0.0, Q_thresh: float = 1.5,
                       max_iter: int = 10, delta_thresh: float = 1e-4, pin: int = 1, use_metal: bool = True,
-                      *, return_info: bool = False):
+                      *, return_info: bool = False, _point_mode: bool = False):
     """kernels.py:262-322 / gauss_newton.py:23-280.  Returns updated Twc [K,8] float32
     (input is not modified).  sigma_dist is accepted and ignored, as in the reference."""
     num_kf = Twc.shape[0]
@@ -195,7 +196,8 @@ def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray:
         _ffi.call("m3_gn_rays_solve", _ffi.ptr(twc), _ffi.ptr(t["Xs"]), _ffi.ptr(t["Cs"]), _ffi.ptr(t["ii"]),
                   _ffi.ptr(t["jj"]), _ffi.ptr(t["idx"]), _ffi.ptr(t["valid"]), _ffi.ptr(t["Q"]), _ffi.ptr(local),
                   _ffi.ptr(blocks), _ffi.ptr(ws), _ffi.ptr(hbuf), _ffi.ptr(info), k, p, e, num_free,
-                  float(sigma_ray), float(C_thresh), float(Q_thresh), int(max_iter), float(delta_thresh), st)
+                  float(sigma_ray), float(C_thresh), float(Q_thresh), int(max_iter), float(delta_thresh),
+                  1 if _point_mode else 0, st)
         result_info = None
         if return_info:
             i = info.cpu().numpy()
@@ -210,7 +212,7 @@ def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray:
             _ffi.call("m3_gn_rays_blocks", _ffi.ptr(twc), _ffi.ptr(t["Xs"]), _ffi.ptr(t["Cs"]), _ffi.ptr(t["ii"]),
                       _ffi.ptr(t["jj"]), _ffi.ptr(t["idx"]), _ffi.ptr(t["valid"]), _ffi.ptr(t["Q"]),
                       _ffi.ptr(blocks), _ffi.ptr(ws), k, p, e, float(sigma_ray), float(C_thresh),
-                      float(Q_thresh), st)
+                      float(Q_thresh), 1 if _point_mode else 0, st)
             _ffi.call("m3_gn_rays_assemble", _ffi.ptr(blocks), _ffi.ptr(t["ii"]), _ffi.ptr(t["jj"]),
                       _ffi.ptr(local), _ffi.ptr(H), _ffi.ptr(g), k, e, num_free, st)
             H.diagonal().add_(1e-6)
@@ -228,3 +230,13 @@ def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray:
         result_info = dict(iters=iters, last_dx=last, stopped=stopped, failed=failed)
     out = _out(twc, t["np_in"], np.float32)
     return (out, result_info) if return_info else out
+
+
+def gauss_newton_points(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_point: float = 0.01,
+                        C_thresh: float = 0.0, Q_thresh: float = 1.5, max_iter: int = 10,
+                        delta_thresh: float = 1e-4, pin: int = 1, use_metal: bool = True, *, return_info: bool = False):
+    """kernels.py:396-460 / gauss_newton_points.py:17-207: the 3-D point alignment with the extra
+    scale-invariant weight 1/(|Xi| + 1e-6).  Same device path as gauss_newton_rays."""
+    return gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray=sigma_point,
+                             C_thresh=C_thresh, Q_thresh=Q_thresh, max_iter=max_iter, delta_thresh=delta_thresh,
+                             pin=pin, return_info=return_info, _point_mode=True)

@@ -26,7 +26,7 @@ from . import sim3 as S
 
 
 def edge_blocks(t, q, s, Xs, Cs, ix, jx, idx_corr, valid, q_conf,
-                sigma_ray=0.003, C_thresh=0.0, Q_thresh=1.5):
+                sigma_ray=0.003, C_thresh=0.0, Q_thresh=1.5, point_mode=False):
     """One edge -> (Hjj[7,7], gj[7], n_valid) in float64."""
     tij, qij, sij = S.sim3_relative(t[ix], q[ix], s[ix], t[jx], q[jx], s[jx])
     ci = Cs[ix, idx_corr]
@@ -41,6 +41,8 @@ def edge_blocks(t, q, s, Xs, Cs, ix, jx, idx_corr, valid, q_conf,
     Y = S.quat_rotate(qij[None], Xj) * sij + tij
     err = Y - Xi
     sqrt_w = (1.0 / sigma_ray) * np.sqrt(conf)
+    if point_mode:                       # gauss_newton_points.py:103-107
+        sqrt_w = sqrt_w * (1.0 / (np.linalg.norm(Xi, axis=-1) + 1e-6))
     w = S.huber_weight(sqrt_w[:, None] * err) * (sqrt_w[:, None] ** 2)      # [n,3]
     qi_inv = S.quat_inv(q[ix])
     s_inv = 1.0 / s[ix]
@@ -64,8 +66,8 @@ def edge_blocks(t, q, s, Xs, Cs, ix, jx, idx_corr, valid, q_conf,
 
 def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q,
                       sigma_ray=0.003, sigma_dist=10.0, C_thresh=0.0, Q_thresh=1.5,
-                      max_iter=10, delta_thresh=1e-4, pin=1, return_info=False):
-    """gauss_newton.py:23-280.  Returns Twc_new [K,8] float32 (+ info dict)."""
+                      max_iter=10, delta_thresh=1e-4, pin=1, return_info=False, point_mode=False):
+    """gauss_newton.py:23-280 (point_mode=True: gauss_newton_points.py:17-207).  Returns Twc_new [K,8] float32 (+ info dict)."""
     Twc = np.asarray(Twc)
     num_kf, num_edges = Twc.shape[0], len(ii)
     info = dict(iters=0, dx_norms=[], first_H=None, first_g=None)
@@ -99,7 +101,7 @@ def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q,
             if il < 0 and jl < 0:
                 continue
             Hjj, gj, n = edge_blocks(t, q, s, Xs, Cs, ix, jx, idx_ii2jj[e], valid_match[e], Q[e],
-                                     sigma_ray, C_thresh, Q_thresh)
+                                     sigma_ray, C_thresh, Q_thresh, point_mode)
             if n == 0:
                 continue
             if il >= 0:
@@ -140,3 +142,11 @@ def cholesky_solve(H, g, reg=1e-6):
         return np.linalg.solve(Hr, g)
     except np.linalg.LinAlgError:
         return np.linalg.lstsq(Hr, g, rcond=None)[0]
+
+
+def gauss_newton_points(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_point=0.01, C_thresh=0.0,
+                        Q_thresh=1.5, max_iter=10, delta_thresh=1e-4, pin=1, return_info=False):
+    """gauss_newton_points.py:17-207: rays variant + scale-invariant weight 1/(|Xi| + 1e-6)."""
+    return gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray=sigma_point,
+                             C_thresh=C_thresh, Q_thresh=Q_thresh, max_iter=max_iter, delta_thresh=delta_thresh,
+                             pin=pin, return_info=return_info, point_mode=True)

@@ -8,6 +8,7 @@ box never sees /root/reference; tests read only the committed .npz files.
 Reference entry points exercised (paths under /root/reference/src/mlx_mast3r_slam):
   backends/mpsgraph/kernels.py      _iter_proj_numpy :151, _refine_matches_numpy :496
   backends/mpsgraph/gauss_newton.py gauss_newton_rays :23
+  backends/mpsgraph/gauss_newton_points.py gauss_newton_points :17
   backends/mpsgraph/sim3_ops.py     quat_multiply, quat_rotate, sim3_relative, exp_so3,
                                     exp_sim3, retract_sim3, huber_weight
   backends/mpsgraph/linalg.py       cholesky_solve :17
@@ -30,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 from mlx_mast3r_slam.backends.mpsgraph import kernels as rk            # noqa: E402
 from mlx_mast3r_slam.backends.mpsgraph import gauss_newton as rgn     # noqa: E402
+from mlx_mast3r_slam.backends.mpsgraph import gauss_newton_points as rgp  # noqa: E402
 from mlx_mast3r_slam.backends.mpsgraph import sim3_ops as rs          # noqa: E402
 from mlx_mast3r_slam.backends.mpsgraph import linalg as rl            # noqa: E402
 
@@ -94,6 +96,10 @@ def main():
     for it in (1, 3):
         out = rgn.gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx, valid, Q, max_iter=it, pin=1)
         np.savez_compressed(os.path.join(OUT, f"gn_rays_it{it}.npz"), Twc=Twc, Xs=Xs, Cs=Cs, ii=ii, jj=jj,
+                            idx=idx, valid=valid, Q=Q, Twc_ref=out, max_iter=it, pin=1)
+    for it in (1, 3):
+        out = rgp.gauss_newton_points(Twc, Xs, Cs, ii, jj, idx, valid, Q, max_iter=it, pin=1)
+        np.savez_compressed(os.path.join(OUT, f"gn_points_it{it}.npz"), Twc=Twc, Xs=Xs, Cs=Cs, ii=ii, jj=jj,
                             idx=idx, valid=valid, Q=Q, Twc_ref=out, max_iter=it, pin=1)
     # a solvable chain graph (converges), own generator
     Twc, Xs, Cs, ii, jj, idx, valid, Q = synthetic.gn_graph(6, 150, 0, seed=9, chain=True, pose_noise=0.02)

@@ -67,3 +67,18 @@ def test_device_tensors_and_large_graph_path_agree(dev):
     out = kernels.gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx, valid, Q, max_iter=5)
     ref = og.gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx, valid, Q, max_iter=5)
     assert np.abs(out - ref).max() < 2e-4
+
+
+@pytest.mark.parametrize("tag,tol", [("it1", 2e-5), ("it3", 5e-4)])
+def test_gauss_newton_points_golden(golden_dir, tag, tol):
+    """kernels.gauss_newton_points vs the reference's numpy twin (gauss_newton_points.py)."""
+    z = _load(golden_dir, f"gn_points_{tag}.npz")
+    out, info = kernels.gauss_newton_points(z["Twc"], z["Xs"], z["Cs"], z["ii"], z["jj"], z["idx"], z["valid"], z["Q"],
+                                            max_iter=int(z["max_iter"]), pin=int(z["pin"]), return_info=True)
+    assert not info["failed"]
+    assert np.abs(out - z["Twc_ref"]).max() <= tol, np.abs(out - z["Twc_ref"]).max()
+    blocks_r = kernels.gn_rays_blocks(z["Twc"], z["Xs"], z["Cs"], z["ii"], z["jj"], z["idx"], z["valid"], z["Q"], 0.01)
+    blocks_p = kernels.gn_rays_blocks(z["Twc"], z["Xs"], z["Cs"], z["ii"], z["jj"], z["idx"], z["valid"], z["Q"], 0.01,
+                                      point_mode=True)
+    assert not np.allclose(blocks_r[:, :28], blocks_p[:, :28])            # the extra weight is really applied
+    assert np.array_equal(blocks_r[:, 35], blocks_p[:, 35])

@@ -83,3 +83,12 @@ def test_cholesky_solve(golden_dir):
     z = _load(golden_dir, "cholesky_solve.npz")
     assert np.allclose(og.cholesky_solve(z["H"], z["g"]), z["x"], rtol=0, atol=1e-12)
     assert np.allclose(og.cholesky_solve(z["H32"], z["g32"]), z["x32"], rtol=1e-5, atol=1e-6)
+
+
+def test_gauss_newton_points_matches_reference(golden_dir):
+    for tag in ("it1", "it3"):
+        z = _load(golden_dir, f"gn_points_{tag}.npz")
+        out = og.gauss_newton_points(z["Twc"], z["Xs"], z["Cs"], z["ii"], z["jj"], z["idx"], z["valid"], z["Q"],
+                                     max_iter=int(z["max_iter"]), pin=int(z["pin"]))
+        assert np.abs(out - z["Twc_ref"]).max() <= 1e-6, tag
+        assert np.abs(z["Twc_ref"] - z["Twc"]).max() > 1e-3

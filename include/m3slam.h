@@ -148,12 +148,18 @@ int m3_sim3_act(const float *T, const float *X, float *out, int N, void *stream)
  * ws: double [E * m3_gn_rays_chunks(P) * 36].
  * point_mode = 1 selects kernels.gauss_newton_points (kernels.py:396-460, numpy twin
  * gauss_newton_points.py:17-207; Metal gn_points_jacobian_kernel gauss_newton_points.metal:65):
- * the same residual with the extra scale-invariant weight 1/(|Xi| + 1e-6) and sigma = sigma_point. */
+ * the same residual with the extra scale-invariant weight 1/(|Xi| + 1e-6) and sigma = sigma_point.
+ * point_mode = 2 selects kernels.gauss_newton_calib (kernels.py:325-393, numpy twin
+ * gauss_newton_calib.py:17-274; Metal gn_calib_jacobian_kernel gauss_newton_calib.metal:74): residual
+ * ((du, dv)/sigma_pixel, dlog z/sigma_depth) with depth and image-border gates; `calib` is a HOST
+ * array of 10 floats (fx, fy, cx, cy, width, height, border, z_eps, sigma_pixel, sigma_depth),
+ * NULL otherwise; sigma_ray is ignored in that mode (pass any positive value). */
 int m3_gn_rays_chunks(int P);
 int m3_gn_rays_blocks(const float *Twc, const float *Xs, const float *Cs, const int32_t *ii,
                       const int32_t *jj, const int32_t *idx, const uint8_t *valid, const float *Q,
                       double *blocks, double *ws, int K, int P, int E, float sigma_ray,
-                      float C_thresh, float Q_thresh, int point_mode, void *stream);
+                      float C_thresh, float Q_thresh, int point_mode, const float *calib,
+                      void *stream);
 
 /* Dense normal equations from the per-edge blocks (gauss_newton.py:220-251): H double
  * [dim,dim], g double [dim], dim = 7*num_free (both zeroed by the call; the 1e-6 I
@@ -178,7 +184,8 @@ int m3_gn_rays_solve(float *Twc, const float *Xs, const float *Cs, const int32_t
                      const int32_t *jj, const int32_t *idx, const uint8_t *valid, const float *Q,
                      const int32_t *local, double *blocks, double *ws, double *Hbuf, double *info,
                      int K, int P, int E, int num_free, float sigma_ray, float C_thresh,
-                     float Q_thresh, int max_iter, float delta_thresh, int point_mode, void *stream);
+                     float Q_thresh, int max_iter, float delta_thresh, int point_mode,
+                     const float *calib, void *stream);
 
 #ifdef __cplusplus
 }

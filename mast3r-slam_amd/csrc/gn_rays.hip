@@ -22,6 +22,12 @@ constexpr int kPtsPerChunk = 2048;
 constexpr int kSolveThreads = 1024;
 constexpr int kMaxDim = 448;      // 64 free keyframes in the single-workgroup Cholesky
 
+// residual_mode: 0 = "rays" (3-D point error), 1 = "points" (+ 1/(|Xi|+1e-6) weight), 2 = "calib"
+// (pixel + log-depth residual, gauss_newton_calib.py:17-274)
+struct CalibParams {
+    float fx, fy, cx, cy, width, height, border, z_eps, inv_sigma_pixel, inv_sigma_depth;
+};
+
 __host__ __device__ inline int gn_chunks(int P) {
     int c = (P + kPtsPerChunk - 1) / kPtsPerChunk;
     return c < 1 ? 1 : (c > kMaxChunks ? kMaxChunks : c);
@@ -32,7 +38,7 @@ k_gn_blocks(const float *__restrict__ Twc, const float *__restrict__ Xs, const f
             const int32_t *__restrict__ ii, const int32_t *__restrict__ jj, const int32_t *__restrict__ idx,
             const uint8_t *__restrict__ valid, const float *__restrict__ Q, double *__restrict__ part,
             const double *__restrict__ done, int K, int P, int chunks, float inv_sigma, float C_thresh,
-            float Q_thresh, int point_mode) {
+            float Q_thresh, int point_mode, const CalibParams cal) {
     if (done && done[0] != 0.0) return;
     const int e = blockIdx.y, chunk = blockIdx.x;
     const int ix = ii[e], jx = jj[e];
@@ -65,21 +71,50 @@ k_gn_blocks(const float *__restrict__ Twc, const float *__restrict__ Xs, const f
             const V3<float> Xi{Xi_base[3 * id], Xi_base[3 * id + 1], Xi_base[3 * id + 2]};
             const V3<float> Xj{Xj_base[3 * k], Xj_base[3 * k + 1], Xj_base[3 * k + 2]};
             const V3<float> Y = act(Tij, Xj);
-            const float err[3] = {Y.x - Xi.x, Y.y - Xi.y, Y.z - Xi.z};
+            float err[3] = {Y.x - Xi.x, Y.y - Xi.y, Y.z - Xi.z};
             float sqrt_w = inv_sigma * sqrtf(qc);
-            if (point_mode)                                 // gauss_newton_points.py:103-107: 1/(|Xi| + 1e-6)
+            if (point_mode == 1)                            // gauss_newton_points.py:103-107: 1/(|Xi| + 1e-6)
                 sqrt_w *= 1.0f / (sqrtf(dot(Xi, Xi)) + 1e-6f);
+            // rows of d(residual)/dX (identity for the 3-D residuals)
+            float d0x = 1.f, d0z = 0.f, d1y = 1.f, d1z = 0.f, d2z = 1.f;
+            if (point_mode == 2) {                          // gauss_newton_calib.py:118-176
+                if (!(Y.z > cal.z_eps) || !(Xi.z > cal.z_eps)) continue;
+                const float zj = 1.0f / Y.z, zi = 1.0f / Xi.z;
+                const float pju = cal.fx * Y.x * zj + cal.cx, pjv = cal.fy * Y.y * zj + cal.cy;
+                const float piu = cal.fx * Xi.x * zi + cal.cx, piv = cal.fy * Xi.y * zi + cal.cy;
+                if (!(pju >= cal.border && pju < cal.width - cal.border && pjv >= cal.border &&
+                      pjv < cal.height - cal.border)) continue;
+                err[0] = (pju - piu) * cal.inv_sigma_pixel;
+                err[1] = (pjv - piv) * cal.inv_sigma_pixel;
+                err[2] = (logf(Y.z) - logf(Xi.z)) * cal.inv_sigma_depth;
+                sqrt_w = sqrtf(qc);
+                d0x = cal.fx * zj * cal.inv_sigma_pixel; d0z = -cal.fx * Y.x * zj * zj * cal.inv_sigma_pixel;
+                d1y = cal.fy * zj * cal.inv_sigma_pixel; d1z = -cal.fy * Y.y * zj * zj * cal.inv_sigma_pixel;
+                d2z = zj * cal.inv_sigma_depth;
+            }
             const float w2 = sqrt_w * sqrt_w;
             const V3<float> br[3] = {{0.f, Y.z, -Y.y}, {-Y.z, 0.f, Y.x}, {Y.y, -Y.x, 0.f}};
             const float Yc[3] = {Y.x, Y.y, Y.z};
+            // pose Jacobian of the transformed point, row k: [R_i^T e_k / s_i | R_i^T br_k | Y_k]
+            float JX[3][7];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const V3<float> jr = qrot(qi_inv, br[k]);
+                JX[k][0] = jt[k].x; JX[k][1] = jt[k].y; JX[k][2] = jt[k].z;
+                JX[k][3] = jr.x; JX[k][4] = jr.y; JX[k][5] = jr.z; JX[k][6] = Yc[k];
+            }
             // accumulate straight into the float64 registers with a closed-form index (a temporary
             // float h[] indexed by a running counter was mis-compiled in tracking.hip)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float we = fabsf(sqrt_w * err[c]);
                 const float w = ((we < 1.345f) ? 1.0f : 1.345f / we) * w2;
-                const V3<float> jr = qrot(qi_inv, br[c]);
-                const float J[7] = {jt[c].x, jt[c].y, jt[c].z, jr.x, jr.y, jr.z, Yc[c]};
+                float J[7];
+#pragma unroll
+                for (int i = 0; i < 7; ++i)
+                    J[i] = (c == 0) ? d0x * JX[0][i] + d0z * JX[2][i]
+                         : (c == 1) ? d1y * JX[1][i] + d1z * JX[2][i]
+                                    : d2z * JX[2][i];
 #pragma unroll
                 for (int i = 0; i < 7; ++i) {
                     const float wj = w * J[i];
@@ -241,14 +276,24 @@ __global__ void k_gn_info_init(double *info) {
     if (threadIdx.x < 4) info[threadIdx.x] = 0.0;
 }
 
+// host: calib = 10 floats (fx, fy, cx, cy, width, height, border, z_eps, sigma_pixel, sigma_depth) or null
+CalibParams make_calib(const float *c) {
+    CalibParams p{};
+    if (c) {
+        p.fx = c[0]; p.fy = c[1]; p.cx = c[2]; p.cy = c[3]; p.width = c[4]; p.height = c[5]; p.border = c[6];
+        p.z_eps = c[7]; p.inv_sigma_pixel = 1.0f / c[8]; p.inv_sigma_depth = 1.0f / c[9];
+    }
+    return p;
+}
+
 int launch_blocks(const float *Twc, const float *Xs, const float *Cs, const int32_t *ii, const int32_t *jj,
                   const int32_t *idx, const uint8_t *valid, const float *Q, double *blocks, double *ws,
                   const double *done, int K, int P, int E, float sigma_ray, float C_thresh, float Q_thresh,
-                  int point_mode, hipStream_t st) {
+                  int point_mode, const CalibParams &cal, hipStream_t st) {
     const int chunks = gn_chunks(P);
     const float inv_sigma = (float)(1.0 / (double)sigma_ray);
     hipLaunchKernelGGL(k_gn_blocks, dim3(chunks, E), dim3(kThreads), 0, st, Twc, Xs, Cs, ii, jj, idx, valid, Q,
-                       ws, done, K, P, chunks, inv_sigma, C_thresh, Q_thresh, point_mode);
+                       ws, done, K, P, chunks, inv_sigma, C_thresh, Q_thresh, point_mode, cal);
     hipLaunchKernelGGL(k_gn_reduce, dim3(E), dim3(64), 0, st, (const double *)ws, blocks, done, chunks);
     M3_CHECK_LAUNCH("m3_gn_rays_blocks");
     return M3_OK;
@@ -263,11 +308,13 @@ int m3_gn_rays_max_dim(void) { return kMaxDim; }
 
 int m3_gn_rays_blocks(const float *Twc, const float *Xs, const float *Cs, const int32_t *ii, const int32_t *jj,
                       const int32_t *idx, const uint8_t *valid, const float *Q, double *blocks, double *ws,
-                      int K, int P, int E, float sigma_ray, float C_thresh, float Q_thresh, int point_mode, void *stream) {
+                      int K, int P, int E, float sigma_ray, float C_thresh, float Q_thresh, int point_mode, const float *calib,
+                      void *stream) {
     M3_REQUIRE(Twc && Xs && Cs && ii && jj && idx && valid && Q && blocks && ws);
-    M3_REQUIRE(K > 0 && P > 0 && E > 0 && E <= 65535 && sigma_ray > 0.f && (point_mode == 0 || point_mode == 1));
+    M3_REQUIRE(K > 0 && P > 0 && E > 0 && E <= 65535 && sigma_ray > 0.f && point_mode >= 0 && point_mode <= 2);
+    M3_REQUIRE(point_mode != 2 || calib);
     return launch_blocks(Twc, Xs, Cs, ii, jj, idx, valid, Q, blocks, ws, nullptr, K, P, E, sigma_ray, C_thresh,
-                         Q_thresh, point_mode, (hipStream_t)stream);
+                         Q_thresh, point_mode, make_calib(calib), (hipStream_t)stream);
 }
 
 int m3_gn_rays_assemble(const double *blocks, const int32_t *ii, const int32_t *jj, const int32_t *local,
@@ -295,9 +342,11 @@ int m3_gn_rays_solve(float *Twc, const float *Xs, const float *Cs, const int32_t
                      const int32_t *idx, const uint8_t *valid, const float *Q, const int32_t *local,
                      double *blocks, double *ws, double *Hbuf, double *info, int K, int P, int E, int num_free,
                      float sigma_ray, float C_thresh, float Q_thresh, int max_iter, float delta_thresh,
-                     int point_mode, void *stream) {
+                     int point_mode, const float *calib, void *stream) {
     M3_REQUIRE(Twc && Xs && Cs && ii && jj && idx && valid && Q && local && blocks && ws && Hbuf && info);
     M3_REQUIRE(K > 0 && P > 0 && E > 0 && E <= 65535 && num_free > 0 && max_iter >= 0 && sigma_ray > 0.f);
+    M3_REQUIRE(point_mode >= 0 && point_mode <= 2 && (point_mode != 2 || calib));
+    const CalibParams cal = make_calib(calib);
     const int dim = 7 * num_free;
     if (dim > kMaxDim) return M3_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
@@ -307,7 +356,7 @@ int m3_gn_rays_solve(float *Twc, const float *Xs, const float *Cs, const int32_t
     const int64_t count = (int64_t)dim * dim + dim;
     for (int it = 0; it < max_iter; ++it) {
         int rc = launch_blocks(Twc, Xs, Cs, ii, jj, idx, valid, Q, blocks, ws, done, K, P, E, sigma_ray, C_thresh,
-                               Q_thresh, point_mode, st);
+                               Q_thresh, point_mode, cal, st);
         if (rc != M3_OK) return rc;
         hipLaunchKernelGGL(k_gn_zero, dim3(m3_cdiv(count, kThreads) > 1024 ? 1024 : m3_cdiv(count, kThreads)),
                            dim3(kThreads), 0, st, Hbuf, done, count);

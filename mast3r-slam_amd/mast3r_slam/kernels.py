@@ -115,6 +115,19 @@ def _local_map(ii, jj, num_kf: int, pin: int):
     return uniq, local, max(len(uniq) - pin, 0)
 
 
+_calib_keep = []
+
+
+def _calib_ptr(calib):
+    """10 host floats -> pointer (ctypes array kept alive for the duration of the call sequence)."""
+    if calib is None:
+        return None
+    import ctypes
+    arr = (ctypes.c_float * 10)(*[float(v) for v in calib])
+    _calib_keep[:] = [arr]
+    return ctypes.cast(arr, ctypes.c_void_p)
+
+
 def gn_rays_blocks(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray: float = 0.003,
                    C_thresh: float = 0.0, Q_thresh: float = 1.5, point_mode: bool = False):
     """Per-edge normal-equation blocks [E,36] float64 = (Hjj upper 28, gj 7, count)."""
@@ -125,7 +138,7 @@ def gn_rays_blocks(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray: fl
     ws = torch.empty(e * chunks * 36, dtype=torch.float64, device=t["Twc"].device)
     _ffi.call("m3_gn_rays_blocks", _ffi.ptr(t["Twc"]), _ffi.ptr(t["Xs"]), _ffi.ptr(t["Cs"]), _ffi.ptr(t["ii"]),
               _ffi.ptr(t["jj"]), _ffi.ptr(t["idx"]), _ffi.ptr(t["valid"]), _ffi.ptr(t["Q"]), _ffi.ptr(blocks),
-              _ffi.ptr(ws), k, p, e, float(sigma_ray), float(C_thresh), float(Q_thresh), 1 if point_mode else 0,
+              _ffi.ptr(ws), k, p, e, float(sigma_ray), float(C_thresh), float(Q_thresh), int(point_mode), None,
               _ffi.stream_ptr())
     return _out(blocks, t["np_in"])
 
@@ -164,7 +177,7 @@ def _prep_gn(Twc, Xs, Cs, ii, jj, idx, valid, Q):
 def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray: float = 0.003,
                       sigma_dist: float = 10.0, C_thresh: float = 0.0, Q_thresh: float = 1.5,
                       max_iter: int = 10, delta_thresh: float = 1e-4, pin: int = 1, use_metal: bool = True,
-                      *, return_info: bool = False, _point_mode: bool = False):
+                      *, return_info: bool = False, _point_mode: int = 0, _calib=None):
     """kernels.py:262-322 / gauss_newton.py:23-280.  Returns updated Twc [K,8] float32
     (input is not modified).  sigma_dist is accepted and ignored, as in the reference."""
     num_kf = Twc.shape[0]
@@ -197,7 +210,7 @@ def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray:
                   _ffi.ptr(t["jj"]), _ffi.ptr(t["idx"]), _ffi.ptr(t["valid"]), _ffi.ptr(t["Q"]), _ffi.ptr(local),
                   _ffi.ptr(blocks), _ffi.ptr(ws), _ffi.ptr(hbuf), _ffi.ptr(info), k, p, e, num_free,
                   float(sigma_ray), float(C_thresh), float(Q_thresh), int(max_iter), float(delta_thresh),
-                  1 if _point_mode else 0, st)
+                  int(_point_mode), _calib_ptr(_calib), st)
         result_info = None
         if return_info:
             i = info.cpu().numpy()
@@ -212,7 +225,7 @@ def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray:
             _ffi.call("m3_gn_rays_blocks", _ffi.ptr(twc), _ffi.ptr(t["Xs"]), _ffi.ptr(t["Cs"]), _ffi.ptr(t["ii"]),
                       _ffi.ptr(t["jj"]), _ffi.ptr(t["idx"]), _ffi.ptr(t["valid"]), _ffi.ptr(t["Q"]),
                       _ffi.ptr(blocks), _ffi.ptr(ws), k, p, e, float(sigma_ray), float(C_thresh),
-                      float(Q_thresh), 1 if _point_mode else 0, st)
+                      float(Q_thresh), int(_point_mode), _calib_ptr(_calib), st)
             _ffi.call("m3_gn_rays_assemble", _ffi.ptr(blocks), _ffi.ptr(t["ii"]), _ffi.ptr(t["jj"]),
                       _ffi.ptr(local), _ffi.ptr(H), _ffi.ptr(g), k, e, num_free, st)
             H.diagonal().add_(1e-6)
@@ -239,4 +252,19 @@ def gauss_newton_points(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_po
     scale-invariant weight 1/(|Xi| + 1e-6).  Same device path as gauss_newton_rays."""
     return gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray=sigma_point,
                              C_thresh=C_thresh, Q_thresh=Q_thresh, max_iter=max_iter, delta_thresh=delta_thresh,
-                             pin=pin, return_info=return_info, _point_mode=True)
+                             pin=pin, return_info=return_info, _point_mode=1)
+
+
+def gauss_newton_calib(Twc, Xs, Cs, K, ii, jj, idx_ii2jj, valid_match, Q, img_size, pixel_border: int = 0,
+                       z_eps: float = 0.0, sigma_pixel: float = 1.0, sigma_depth: float = 0.1, C_thresh: float = 0.0,
+                       Q_thresh: float = 1.5, max_iter: int = 10, delta_thresh: float = 1e-4, pin: int = 1,
+                       use_metal: bool = True, *, return_info: bool = False):
+    """kernels.py:325-393 / gauss_newton_calib.py:17-274: calibrated projection residual
+    ((du, dv)/sigma_pixel, dlog z/sigma_depth).  K is [3,3] or (fx, fy, cx, cy); img_size = (width, height)."""
+    Kh = K.cpu().numpy() if isinstance(K, torch.Tensor) else np.asarray(K)
+    fx, fy, cx, cy = (Kh[0, 0], Kh[1, 1], Kh[0, 2], Kh[1, 2]) if Kh.shape == (3, 3) else Kh.flatten()[:4]
+    w, h = img_size
+    calib = (fx, fy, cx, cy, w, h, pixel_border, z_eps, sigma_pixel, sigma_depth)
+    return gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray=1.0, C_thresh=C_thresh,
+                             Q_thresh=Q_thresh, max_iter=max_iter, delta_thresh=delta_thresh, pin=pin,
+                             return_info=return_info, _point_mode=2, _calib=calib)

@@ -116,7 +116,7 @@ def tracking_problem(h: int, w: int, seed: int = 0, noise: float = 1e-3, perm_fr
                 T_true=np.concatenate([t, q, [s]]).astype(np.float32))
 
 
-def gn_graph(num_kf=10, num_pts=500, num_edges=15, seed=42, chain=False, pose_noise=0.0):
+def gn_graph(num_kf=10, num_pts=500, num_edges=15, seed=42, chain=False, pose_noise=0.0, poses=None):
     """Random pose graph with the array layout of benchmark_all_kernels.py:16-42.
 
     chain=True: edges connect each keyframe to its previous <=3 (slam.py:302-303) and the
@@ -128,6 +128,8 @@ def gn_graph(num_kf=10, num_pts=500, num_edges=15, seed=42, chain=False, pose_no
         q = rng.normal(size=4)
         Twc[i, 3:7] = q / np.linalg.norm(q)
         Twc[i, 7] = 1.0 + rng.uniform() * 0.1
+    if poses is not None:
+        Twc = np.asarray(poses, dtype=np.float32).copy()
     if not chain:
         Xs = rng.normal(size=(num_kf, num_pts, 3)).astype(np.float32)
         ii = rng.integers(0, num_kf, num_edges).astype(np.int32)

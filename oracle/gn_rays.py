@@ -26,8 +26,9 @@ from . import sim3 as S
 
 
 def edge_blocks(t, q, s, Xs, Cs, ix, jx, idx_corr, valid, q_conf,
-                sigma_ray=0.003, C_thresh=0.0, Q_thresh=1.5, point_mode=False):
-    """One edge -> (Hjj[7,7], gj[7], n_valid) in float64."""
+                sigma_ray=0.003, C_thresh=0.0, Q_thresh=1.5, point_mode=0, calib=None):
+    """One edge -> (Hjj[7,7], gj[7], n_valid) in float64.  point_mode 0 rays / 1 points / 2 calib
+    (calib = dict fx, fy, cx, cy, width, height, border, z_eps, sigma_pixel, sigma_depth)."""
     tij, qij, sij = S.sim3_relative(t[ix], q[ix], s[ix], t[jx], q[jx], s[jx])
     ci = Cs[ix, idx_corr]
     cj = Cs[jx]
@@ -41,8 +42,34 @@ def edge_blocks(t, q, s, Xs, Cs, ix, jx, idx_corr, valid, q_conf,
     Y = S.quat_rotate(qij[None], Xj) * sij + tij
     err = Y - Xi
     sqrt_w = (1.0 / sigma_ray) * np.sqrt(conf)
-    if point_mode:                       # gauss_newton_points.py:103-107
+    if point_mode == 1:                  # gauss_newton_points.py:103-107
         sqrt_w = sqrt_w * (1.0 / (np.linalg.norm(Xi, axis=-1) + 1e-6))
+    dproj = None
+    if point_mode == 2:                  # gauss_newton_calib.py:118-190
+        c = calib
+        keep = (Y[:, 2] > c["z_eps"]) & (Xi[:, 2] > c["z_eps"])
+        Xi, Y, conf = Xi[keep], Y[keep], conf[keep]
+        if len(Xi) == 0:
+            return np.zeros((7, 7)), np.zeros(7), 0
+        zj, zi = 1.0 / Y[:, 2], 1.0 / Xi[:, 2]
+        pju, pjv = c["fx"] * Y[:, 0] * zj + c["cx"], c["fy"] * Y[:, 1] * zj + c["cy"]
+        piu, piv = c["fx"] * Xi[:, 0] * zi + c["cx"], c["fy"] * Xi[:, 1] * zi + c["cy"]
+        inb = ((pju >= c["border"]) & (pju < c["width"] - c["border"]) & (pjv >= c["border"])
+               & (pjv < c["height"] - c["border"]))
+        if not inb.any():
+            return np.zeros((7, 7)), np.zeros(7), 0
+        Xi, Y, conf, zj = Xi[inb], Y[inb], conf[inb], zj[inb]
+        isp, isd = 1.0 / c["sigma_pixel"], 1.0 / c["sigma_depth"]
+        err = np.stack([(pju[inb] - piu[inb]) * isp, (pjv[inb] - piv[inb]) * isp,
+                        (np.log(Y[:, 2]) - np.log(Xi[:, 2])) * isd], axis=-1)
+        sqrt_w = np.sqrt(conf)
+        dproj = np.zeros((len(Xi), 3, 3))
+        dproj[:, 0, 0] = c["fx"] * zj * isp
+        dproj[:, 0, 2] = -c["fx"] * Y[:, 0] * zj ** 2 * isp
+        dproj[:, 1, 1] = c["fy"] * zj * isp
+        dproj[:, 1, 2] = -c["fy"] * Y[:, 1] * zj ** 2 * isp
+        dproj[:, 2, 2] = zj * isd
+        vi = vi[:len(Xi)]                # only the count is used below
     w = S.huber_weight(sqrt_w[:, None] * err) * (sqrt_w[:, None] ** 2)      # [n,3]
     qi_inv = S.quat_inv(q[ix])
     s_inv = 1.0 / s[ix]
@@ -58,6 +85,8 @@ def edge_blocks(t, q, s, Xs, Cs, ix, jx, idx_corr, valid, q_conf,
         Jj[:, c, :3] = s_inv * S.quat_rotate(qi_inv, eye[c])[None, :]
         Jj[:, c, 3:6] = S.quat_rotate(qi_inv[None], base_rot[:, c, :])
         Jj[:, c, 6] = Y[:, c]
+    if dproj is not None:
+        Jj = np.einsum("nrc,nck->nrk", dproj, Jj)
     wJ = w[:, :, None] * Jj
     Hjj = np.einsum("nci,ncj->ij", Jj, wJ)
     gj = np.einsum("nci,nc->i", wJ, err)
@@ -66,7 +95,7 @@ def edge_blocks(t, q, s, Xs, Cs, ix, jx, idx_corr, valid, q_conf,
 
 def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q,
                       sigma_ray=0.003, sigma_dist=10.0, C_thresh=0.0, Q_thresh=1.5,
-                      max_iter=10, delta_thresh=1e-4, pin=1, return_info=False, point_mode=False):
+                      max_iter=10, delta_thresh=1e-4, pin=1, return_info=False, point_mode=0, calib=None):
     """gauss_newton.py:23-280 (point_mode=True: gauss_newton_points.py:17-207).  Returns Twc_new [K,8] float32 (+ info dict)."""
     Twc = np.asarray(Twc)
     num_kf, num_edges = Twc.shape[0], len(ii)
@@ -101,7 +130,7 @@ def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q,
             if il < 0 and jl < 0:
                 continue
             Hjj, gj, n = edge_blocks(t, q, s, Xs, Cs, ix, jx, idx_ii2jj[e], valid_match[e], Q[e],
-                                     sigma_ray, C_thresh, Q_thresh, point_mode)
+                                     sigma_ray, C_thresh, Q_thresh, point_mode, calib)
             if n == 0:
                 continue
             if il >= 0:
@@ -149,4 +178,17 @@ def gauss_newton_points(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_po
     """gauss_newton_points.py:17-207: rays variant + scale-invariant weight 1/(|Xi| + 1e-6)."""
     return gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray=sigma_point,
                              C_thresh=C_thresh, Q_thresh=Q_thresh, max_iter=max_iter, delta_thresh=delta_thresh,
-                             pin=pin, return_info=return_info, point_mode=True)
+                             pin=pin, return_info=return_info, point_mode=1)
+
+
+def gauss_newton_calib(Twc, Xs, Cs, K, ii, jj, idx_ii2jj, valid_match, Q, img_size, pixel_border=0, z_eps=0.0,
+                       sigma_pixel=1.0, sigma_depth=0.1, C_thresh=0.0, Q_thresh=1.5, max_iter=10,
+                       delta_thresh=1e-4, pin=1, return_info=False):
+    """gauss_newton_calib.py:17-274: pixel + log-depth residual; img_size = (width, height)."""
+    K = np.asarray(K)
+    fx, fy, cx, cy = (K[0, 0], K[1, 1], K[0, 2], K[1, 2]) if K.shape == (3, 3) else K.flatten()[:4]
+    calib = dict(fx=float(fx), fy=float(fy), cx=float(cx), cy=float(cy), width=img_size[0], height=img_size[1],
+                 border=pixel_border, z_eps=z_eps, sigma_pixel=sigma_pixel, sigma_depth=sigma_depth)
+    return gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray=1.0, C_thresh=C_thresh,
+                             Q_thresh=Q_thresh, max_iter=max_iter, delta_thresh=delta_thresh, pin=pin,
+                             return_info=return_info, point_mode=2, calib=calib)

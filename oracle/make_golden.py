@@ -9,6 +9,7 @@ Reference entry points exercised (paths under /root/reference/src/mlx_mast3r_sla
   backends/mpsgraph/kernels.py      _iter_proj_numpy :151, _refine_matches_numpy :496
   backends/mpsgraph/gauss_newton.py gauss_newton_rays :23
   backends/mpsgraph/gauss_newton_points.py gauss_newton_points :17
+  backends/mpsgraph/gauss_newton_calib.py gauss_newton_calib :17
   backends/mpsgraph/sim3_ops.py     quat_multiply, quat_rotate, sim3_relative, exp_so3,
                                     exp_sim3, retract_sim3, huber_weight
   backends/mpsgraph/linalg.py       cholesky_solve :17
@@ -32,6 +33,7 @@ sys.path.insert(0, ROOT)
 from mlx_mast3r_slam.backends.mpsgraph import kernels as rk            # noqa: E402
 from mlx_mast3r_slam.backends.mpsgraph import gauss_newton as rgn     # noqa: E402
 from mlx_mast3r_slam.backends.mpsgraph import gauss_newton_points as rgp  # noqa: E402
+from mlx_mast3r_slam.backends.mpsgraph import gauss_newton_calib as rgc   # noqa: E402
 from mlx_mast3r_slam.backends.mpsgraph import sim3_ops as rs          # noqa: E402
 from mlx_mast3r_slam.backends.mpsgraph import linalg as rl            # noqa: E402
 
@@ -101,6 +103,23 @@ def main():
         out = rgp.gauss_newton_points(Twc, Xs, Cs, ii, jj, idx, valid, Q, max_iter=it, pin=1)
         np.savez_compressed(os.path.join(OUT, f"gn_points_it{it}.npz"), Twc=Twc, Xs=Xs, Cs=Cs, ii=ii, jj=jj,
                             idx=idx, valid=valid, Q=Q, Twc_ref=out, max_iter=it, pin=1)
+    # calibrated variant: inputs as in benchmark_all_kernels.py:215-227 (positive depth, K, 640x480)
+    Kmat = np.array([[500, 0, 320], [0, 500, 240], [0, 0, 1]], dtype=np.float32)
+    Xs_pos = np.abs(Xs) + 0.1
+    for it in (1, 3):
+        out = rgc.gauss_newton_calib(Twc.copy(), Xs_pos, Cs, Kmat, ii, jj, idx, valid, Q, (640, 480), max_iter=it, pin=1)
+        np.savez_compressed(os.path.join(OUT, f"gn_calib_it{it}.npz"), Twc=Twc, Xs=Xs_pos, Cs=Cs, K=Kmat, ii=ii, jj=jj,
+                            idx=idx, valid=valid, Q=Q, Twc_ref=out, max_iter=it, pin=1, img_size=np.array([640, 480]))
+    # calibrated, well-conditioned: chain graph seen by perturbed poses, all points in front of the cameras
+    Tc, Xc, Cc, iic, jjc, idxc, validc, Qc = synthetic.gn_graph(6, 150, 0, seed=13, chain=True, pose_noise=0.01)
+    Tc[:, :3] *= 0.2                                    # keep the cloud (z ~ 4) inside every 640x480 view
+    Tc[:, 3:7] = np.array([0, 0, 0, 1]) + 0.02 * np.random.default_rng(3).normal(size=(6, 4))
+    Tc[:, 3:7] /= np.linalg.norm(Tc[:, 3:7], axis=1, keepdims=True)
+    _, Xc, _, _, _, _, _, _ = synthetic.gn_graph(6, 150, 0, seed=13, chain=True, pose_noise=0.0, poses=Tc)
+    Tn = Tc.copy(); Tn[1:, :3] += 0.01 * np.random.default_rng(4).normal(size=(5, 3)).astype(np.float32)
+    out = rgc.gauss_newton_calib(Tn.copy(), Xc, Cc, Kmat, iic, jjc, idxc, validc, Qc, (640, 480), max_iter=8, pin=1)
+    np.savez_compressed(os.path.join(OUT, "gn_calib_chain.npz"), Twc=Tn, Xs=Xc, Cs=Cc, K=Kmat, ii=iic, jj=jjc, idx=idxc,
+                        valid=validc, Q=Qc, Twc_ref=out, max_iter=8, pin=1, img_size=np.array([640, 480]))
     # a solvable chain graph (converges), own generator
     Twc, Xs, Cs, ii, jj, idx, valid, Q = synthetic.gn_graph(6, 150, 0, seed=9, chain=True, pose_noise=0.02)
     out = rgn.gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx, valid, Q, max_iter=10, pin=1)

@@ -82,3 +82,49 @@ def test_gauss_newton_points_golden(golden_dir, tag, tol):
                                       point_mode=True)
     assert not np.allclose(blocks_r[:, :28], blocks_p[:, :28])            # the extra weight is really applied
     assert np.array_equal(blocks_r[:, 35], blocks_p[:, 35])
+
+
+def test_gauss_newton_calib_golden(golden_dir):
+    """kernels.gauss_newton_calib vs the reference's numpy twin (gauss_newton_calib.py).
+    (a) a well-conditioned chain graph (cond(H) ~ 3e4, converges): tight comparison;
+    (b) the reference benchmark's own random recipe: one keyframe there is constrained by 2 points only
+        (cond(H) ~ 4e11, |dx| ~ 80-170 - the reference's doc reports NaN/divergence for this kernel), so
+        only the well-observed keyframes are compared and the rest must stay finite."""
+    zc = _load(golden_dir, "gn_calib_chain.npz")
+    size = tuple(int(v) for v in zc["img_size"])
+    out, info = kernels.gauss_newton_calib(zc["Twc"], zc["Xs"], zc["Cs"], zc["K"], zc["ii"], zc["jj"], zc["idx"],
+                                           zc["valid"], zc["Q"], size, max_iter=int(zc["max_iter"]), pin=1, return_info=True)
+    assert not info["failed"]
+    assert np.abs(out - zc["Twc_ref"]).max() <= 2e-5, np.abs(out - zc["Twc_ref"]).max()
+    assert np.abs(zc["Twc_ref"] - zc["Twc"]).max() > 1e-3
+    z = _load(golden_dir, "gn_calib_it1.npz")
+    args = (z["Twc"], z["Xs"], z["Cs"], z["K"], z["ii"], z["jj"], z["idx"], z["valid"], z["Q"], size)
+    blocks = kernels.gn_rays_blocks(z["Twc"], z["Xs"], z["Cs"], z["ii"], z["jj"], z["idx"], z["valid"], z["Q"], 1.0)
+    out, info = kernels.gauss_newton_calib(*args, max_iter=1, pin=1, return_info=True)
+    assert not info["failed"] and np.isfinite(out).all()
+    assert np.abs(out[4] - z["Twc_ref"][4]).max() <= 2e-5                  # keyframe 4: 54 valid observations
+    assert np.array_equal(out[[0, 1, 3]], z["Twc"][[0, 1, 3]])              # pinned / unobserved keyframes untouched
+    # per-edge blocks of the calibrated residual against the float64 oracle
+    t = z["Twc"][:, :3].astype(np.float64); q = z["Twc"][:, 3:7].astype(np.float64); s = z["Twc"][:, 7].astype(np.float64)
+    calib = dict(fx=500.0, fy=500.0, cx=320.0, cy=240.0, width=640, height=480, border=0, z_eps=0.0, sigma_pixel=1.0,
+                 sigma_depth=0.1)
+    import ctypes  # noqa: F401
+    from mast3r_slam import _ffi
+    tt = kernels._prep_gn(z["Twc"], z["Xs"], z["Cs"], z["ii"], z["jj"], z["idx"], z["valid"], z["Q"])
+    e, p, k = tt["E"], tt["P"], tt["K"]
+    bl = torch.empty((e, 36), dtype=torch.float64, device=tt["Twc"].device)
+    ws = torch.empty(e * _ffi.lib().m3_gn_rays_chunks(p) * 36, dtype=torch.float64, device=tt["Twc"].device)
+    _ffi.call("m3_gn_rays_blocks", _ffi.ptr(tt["Twc"]), _ffi.ptr(tt["Xs"]), _ffi.ptr(tt["Cs"]), _ffi.ptr(tt["ii"]),
+              _ffi.ptr(tt["jj"]), _ffi.ptr(tt["idx"]), _ffi.ptr(tt["valid"]), _ffi.ptr(tt["Q"]), _ffi.ptr(bl), _ffi.ptr(ws),
+              k, p, e, 1.0, 0.0, 1.5, 2,
+              kernels._calib_ptr((500, 500, 320, 240, 640, 480, 0, 0.0, 1.0, 0.1)), _ffi.stream_ptr())
+    bl = bl.cpu().numpy()
+    iu = np.triu_indices(7)
+    for ei in range(e):
+        Hjj, gj, n = og.edge_blocks(t, q, s, z["Xs"], z["Cs"], int(z["ii"][ei]), int(z["jj"][ei]), z["idx"][ei],
+                                    z["valid"][ei], z["Q"][ei], 1.0, 0.0, 1.5, 2, calib)
+        assert bl[ei, 35] == n
+        if n:
+            assert np.abs(bl[ei, :28] - Hjj[iu]).max() <= 1e-4 * np.abs(Hjj).max()
+            assert np.abs(bl[ei, 28:35] - gj).max() <= 1e-4 * np.abs(gj).max()
+    assert not np.allclose(blocks[:, :28], bl[:, :28])

@@ -92,3 +92,14 @@ def test_gauss_newton_points_matches_reference(golden_dir):
                                      max_iter=int(z["max_iter"]), pin=int(z["pin"]))
         assert np.abs(out - z["Twc_ref"]).max() <= 1e-6, tag
         assert np.abs(z["Twc_ref"] - z["Twc"]).max() > 1e-3
+
+
+def test_gauss_newton_calib_matches_reference(golden_dir):
+    for tag in ("it1", "it3"):
+        z = _load(golden_dir, f"gn_calib_{tag}.npz")
+        out = og.gauss_newton_calib(z["Twc"], z["Xs"], z["Cs"], z["K"], z["ii"], z["jj"], z["idx"], z["valid"], z["Q"],
+                                    tuple(int(v) for v in z["img_size"]), max_iter=int(z["max_iter"]), pin=int(z["pin"]))
+        ref = z["Twc_ref"]
+        assert np.isfinite(ref).all()
+        assert np.abs(out - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), tag
+        assert np.abs(ref - z["Twc"]).max() > 1e-3

@@ -69,6 +69,21 @@ k_prep(const float *__restrict__ X11, const float *__restrict__ X21, const int64
 }
 
 // ---------------------------------------------------------------- iter_proj
+// 4-byte aligned vector loads: pixels are 36 B apart, so a pixel pair (72 B) is fetched with
+// four dwordx4 + one dwordx2 instead of 18 dword requests (global loads only need dword alignment)
+struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };
+struct __attribute__((packed, aligned(4))) F2u { float x, y; };
+
+__device__ __forceinline__ void load_pair(const float *__restrict__ p, float *a /*9*/, float *b /*9*/) {
+    const F4u v0 = *reinterpret_cast<const F4u *>(p);
+    const F4u v1 = *reinterpret_cast<const F4u *>(p + 4);
+    const F4u v2 = *reinterpret_cast<const F4u *>(p + 8);
+    const F4u v3 = *reinterpret_cast<const F4u *>(p + 12);
+    const F2u v4 = *reinterpret_cast<const F2u *>(p + 16);
+    a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w; a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w; a[8] = v2.x;
+    b[0] = v2.y; b[1] = v2.z; b[2] = v2.w; b[3] = v3.x; b[4] = v3.y; b[5] = v3.z; b[6] = v3.w; b[7] = v4.x; b[8] = v4.y;
+}
+
 __device__ __forceinline__ float clipf(float v, float hi) {
     v = (v < 0.0f) ? 0.0f : v;     // NaN stays NaN, like np.clip
     v = (v > hi) ? hi : v;
@@ -87,6 +102,7 @@ k_iter_proj(const float *__restrict__ rwg, const float *__restrict__ tgt, const 
             float *__restrict__ p_out, uint8_t *__restrict__ valid_out, uint32_t *__restrict__ stepmax,
             const uint32_t *__restrict__ limit, int H, int W, int N, int max_iter, float lam,
             float xhi, float yhi) {
+    __shared__ unsigned wmax[kThreads / 64];
     const int b = blockIdx.y;
     int n_iter = max_iter;
     if (!FIRST) {
@@ -108,15 +124,20 @@ k_iter_proj(const float *__restrict__ rwg, const float *__restrict__ tgt, const 
         const double fx = (double)cx - (double)x0, fy = (double)cy - (double)y0;
         const double w00 = (1.0 - fx) * (1.0 - fy), w01 = (1.0 - fx) * fy;
         const double w10 = fx * (1.0 - fy), w11 = fx * fy;
-        const float *q00 = img + ((size_t)y0 * W + x0) * 9;
-        const float *q01 = img + ((size_t)y1 * W + x0) * 9;
-        const float *q10 = img + ((size_t)y0 * W + x1) * 9;
-        const float *q11 = img + ((size_t)y1 * W + x1) * 9;
+        float c00[9], c10[9], c01[9], c11[9];             // corner (x0,y0), (x1,y0), (x0,y1), (x1,y1)
+        const float *row0 = img + ((size_t)y0 * W + x0) * 9, *row1 = img + ((size_t)y1 * W + x0) * 9;
+        if (x1 == x0 + 1) {                                // the two corners of a row are 72 contiguous bytes
+            load_pair(row0, c00, c10);
+            load_pair(row1, c01, c11);
+        } else {                                           // x0 clamped at the last column: both corners coincide
+#pragma unroll
+            for (int c = 0; c < 9; ++c) { c00[c] = row0[c]; c10[c] = row0[c]; c01[c] = row1[c]; c11[c] = row1[c]; }
+        }
         float s[9];
 #pragma unroll
         for (int c = 0; c < 9; ++c) {
-            double v = ((w00 * (double)q00[c] + w01 * (double)q01[c]) + w10 * (double)q10[c])
-                       + w11 * (double)q11[c];
+            double v = ((w00 * (double)c00[c] + w01 * (double)c01[c]) + w10 * (double)c10[c])
+                       + w11 * (double)c11[c];
             s[c] = (float)v;
         }
         const float r0 = s[0] - t0, r1 = s[1] - t1, r2 = s[2] - t2;
@@ -134,10 +155,21 @@ k_iter_proj(const float *__restrict__ rwg, const float *__restrict__ tgt, const 
         px = px + dx;
         py = py + dy;
         if (FIRST) {
+            // per-block maximum of the step norm (as uint bits), one plain store per block and iteration:
+            // thousands of atomics on ONE address per iteration serialise (~12 ns each) and used to cost 10x
+            // the arithmetic of this kernel
             const float dn = sqrtf(dx * dx + dy * dy);
             unsigned bits = live ? (__float_as_uint(dn) & 0x7fffffffu) : 0u;
             bits = m3_wave_max(bits);
-            if ((threadIdx.x & 63) == 0) atomicMax(&stepmax[b * max_iter + it], bits);
+            if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = bits;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                unsigned m = wmax[0];
+#pragma unroll
+                for (int w = 1; w < kThreads / 64; ++w) m = max(m, wmax[w]);
+                stepmax[((size_t)b * max_iter + it) * gridDim.x + blockIdx.x] = m;
+            }
+            __syncthreads();
         }
     }
     if (live) {
@@ -147,22 +179,35 @@ k_iter_proj(const float *__restrict__ rwg, const float *__restrict__ tgt, const 
     }
 }
 
-// one thread: first LM iteration whose max step norm is < thresh -> iterations to run
-__global__ void k_iter_limit(const uint32_t *__restrict__ stepmax, uint32_t *__restrict__ limit, int B,
-                             int max_iter, float thresh, int per_batch) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// One workgroup: reduce the per-block maxima to one value per (batch item, iteration), then find the first
+// LM iteration whose max step norm is < thresh -> number of iterations to run.
+__global__ void __launch_bounds__(kThreads)
+k_iter_limit(const uint32_t *__restrict__ stepmax, uint32_t *__restrict__ limit, int B, int max_iter, int nblk,
+             float thresh, int per_batch) {
+    extern __shared__ unsigned red[];                      // [B * max_iter]
+    const int total = B * max_iter;
+    for (int i = threadIdx.x; i < total; i += kThreads) red[i] = 0u;
+    __syncthreads();
+    for (int i = threadIdx.x >> 6; i < total; i += kThreads / 64) {        // one wave per (b, it)
+        unsigned m = 0u;
+        for (int k = threadIdx.x & 63; k < nblk; k += 64) m = max(m, stepmax[(size_t)i * nblk + k]);
+        m = m3_wave_max(m);
+        if ((threadIdx.x & 63) == 0) red[i] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     if (per_batch) {
         for (int b = 0; b < B; ++b) {
             int lim = max_iter;
             for (int it = 0; it < max_iter; ++it)
-                if (__uint_as_float(stepmax[b * max_iter + it]) < thresh) { lim = it + 1; break; }
+                if (__uint_as_float(red[b * max_iter + it]) < thresh) { lim = it + 1; break; }
             limit[b] = (uint32_t)lim;
         }
     } else {
         int lim = max_iter;
         for (int it = 0; it < max_iter; ++it) {
             unsigned m = 0;
-            for (int b = 0; b < B; ++b) m = max(m, stepmax[b * max_iter + it]);
+            for (int b = 0; b < B; ++b) m = max(m, red[b * max_iter + it]);
             if (__uint_as_float(m) < thresh) { lim = it + 1; break; }
         }
         for (int b = 0; b < B; ++b) limit[b] = (uint32_t)lim;
@@ -325,23 +370,29 @@ int m3_prep_iter_proj(const float *X11, const float *X21, const int64_t *idx_ini
     return M3_OK;
 }
 
+int64_t m3_iter_proj_ws_words(int B, int N, int max_iter) {
+    if (B <= 0 || N <= 0 || max_iter < 0) return 0;
+    return (int64_t)B * max_iter * m3_cdiv(N, kThreads) + B;
+}
+
 int m3_iter_proj(const float *rwg, const float *tgt, const float *p_init, float *p_out,
                  uint8_t *valid_out, uint32_t *ws, int B, int H, int W, int N, int max_iter,
                  float lambda_init, float convergence_thresh, int stop_scope, void *stream) {
     M3_REQUIRE(rwg && tgt && p_init && p_out && valid_out && ws);
     M3_REQUIRE(B > 0 && H > 0 && W > 0 && N > 0 && max_iter >= 0 && B <= 65535);
     M3_REQUIRE((int64_t)H * W < (1ll << 31) && (stop_scope == 0 || stop_scope == 1));
+    M3_REQUIRE((int64_t)B * max_iter * 4 <= 60000);         // the limit kernel keeps B*max_iter words in LDS
     hipStream_t st = (hipStream_t)stream;
-    uint32_t *stepmax = ws, *limit = ws + (size_t)B * max_iter;
-    M3_CHECK_HIP(hipMemsetAsync(ws, 0, sizeof(uint32_t) * ((size_t)B * max_iter + B), st), "m3_iter_proj/memset");
+    const int nblk = m3_cdiv(N, kThreads);
+    uint32_t *stepmax = ws, *limit = ws + (size_t)B * max_iter * nblk;
     const float xhi = (float)((double)W - 1.001), yhi = (float)((double)H - 1.001);
-    dim3 grid(m3_cdiv(N, kThreads), B);
+    dim3 grid(nblk, B);
     hipLaunchKernelGGL(k_iter_proj<true>, grid, dim3(kThreads), 0, st, rwg, tgt, p_init, p_out, valid_out,
                        stepmax, (const uint32_t *)limit, H, W, N, max_iter, lambda_init, xhi, yhi);
     M3_CHECK_LAUNCH("m3_iter_proj/pass1");
     if (max_iter > 1) {
-        hipLaunchKernelGGL(k_iter_limit, dim3(1), dim3(64), 0, st, (const uint32_t *)stepmax, limit, B,
-                           max_iter, convergence_thresh, stop_scope);
+        hipLaunchKernelGGL(k_iter_limit, dim3(1), dim3(kThreads), sizeof(unsigned) * B * max_iter, st,
+                           (const uint32_t *)stepmax, limit, B, max_iter, nblk, convergence_thresh, stop_scope);
         M3_CHECK_LAUNCH("m3_iter_proj/limit");
         hipLaunchKernelGGL(k_iter_proj<false>, grid, dim3(kThreads), 0, st, rwg, tgt, p_init, p_out,
                            valid_out, stepmax, (const uint32_t *)limit, H, W, N, max_iter, lambda_init, xhi, yhi);

@@ -213,11 +213,17 @@ k_track_gather(const float *__restrict__ Xf_canon, const float *__restrict__ Cf_
         valid_opt[n] = (uint8_t)vo;
         valid_kf[n] = (uint8_t)vk;
     }
+    // one atomic pair per BLOCK (same-address atomics serialise at ~12 ns each)
+    __shared__ int cnt[2];
+    if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+    __syncthreads();
     const unsigned long long bo = __ballot(vo), bk = __ballot(vk);
     if ((threadIdx.x & 63) == 0) {
-        if (bo) atomicAdd(&counts[0], __popcll(bo));
-        if (bk) atomicAdd(&counts[1], __popcll(bk));
+        if (bo) atomicAdd(&cnt[0], __popcll(bo));
+        if (bk) atomicAdd(&cnt[1], __popcll(bk));
     }
+    __syncthreads();
+    if (threadIdx.x < 2 && cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], cnt[threadIdx.x]);
 }
 
 __global__ void __launch_bounds__(kThreads)

@@ -67,7 +67,8 @@ def iter_proj(rays_with_grad, pts3d_norm, p_init, max_iter: int = 10, lambda_ini
     valid = torch.empty((b, n), dtype=torch.uint8, device=rays.device)
     if n == 0:
         return _out(p_out, np_in), _out(valid.bool(), np_in)
-    ws = torch.empty(b * max(max_iter, 0) + b, dtype=torch.int32, device=rays.device)
+    ws = torch.empty(int(_ffi.lib().m3_iter_proj_ws_words(b, n, max(int(max_iter), 0))), dtype=torch.int32,
+                     device=rays.device)
     _ffi.call("m3_iter_proj", _ffi.ptr(rays), _ffi.ptr(tgt), _ffi.ptr(p0), _ffi.ptr(p_out), _ffi.ptr(valid),
               _ffi.ptr(ws), b, h, w, n, int(max_iter), float(lambda_init), float(convergence_thresh),
               0 if stop_scope == "global" else 1, _ffi.stream_ptr())

@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) and run the result all-gather even with one rank")
     ap.add_argument("--no-b1", action="store_true", help="skip the extra batch=1 (BASELINE configs[1]) latency measurement")
     return ap.parse_args()
 
@@ -67,9 +69,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from mast3r_slam import _ffi, config, matching, model as model_mod, ops, synthetic, tracker
@@ -109,7 +112,7 @@ def main():
         if timers is not None:
             marks.append(ev()); marks[-1].record()
         out = (o1["pts3d"], o2["pts3d"], o1["conf"], o2["conf"], idx, valid, poses)
-        if world > 1:
+        if dist is not None:
             out = m3dist.all_gather_results(out)
         if timers is not None:
             marks.append(ev()); marks[-1].record()
@@ -121,7 +124,7 @@ def main():
     # Capture the whole step (~1500 launches) into a hipGraph: replay removes the host launch path,
     # which matters for small per-GPU batches (a B=1 step is launch-bound when issued eagerly).
     graph = None
-    if not args.no_graph and world == 1:
+    if not args.no_graph and dist is None:
         try:
             for _ in range(2):
                 step()

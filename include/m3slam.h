@@ -130,6 +130,23 @@ int m3_track_gn_ray_dist(const float *Xf, const float *Xk, const float *Qk, cons
                          int N, int max_iters, float huber_k, float sigma_ray, float sigma_dist,
                          float rel_error, float delta_norm, int fixed_iters, void *stream);
 
+/* FrameTracker._opt_pose_calib_sim3 (tracker.py:326-406) with project_calib (geometry.py:156-227):
+ * residual (u, v, log z) of keyframe pixel n = (n % W, n / W) minus the projection of T . Xf[n], gated by
+ * valid & Xk.z > depth_eps & projection inside the image.  Xf/Xk must already be ray-constrained
+ * (m3_constrain_points_to_ray).  K4 = HOST array (fx, fy, cx, cy).  Batched over P problems like
+ * m3_track_gn_ray_dist_batch; same outputs and workspace. */
+int m3_track_gn_calib_batch(const float *Xf, const float *Xk, const float *Qk, const uint8_t *valid,
+                            const float *T_WCf, const float *T_WCk, float *T_WCf_out,
+                            float *T_CkCf_out, double *info, double *ws, int P, int N, int H, int W,
+                            const float *K4, int max_iters, float huber_k, float sigma_pixel,
+                            float sigma_depth, float pixel_border, float depth_eps, float rel_error,
+                            float delta_norm, int fixed_iters, void *stream);
+
+/* constrain_points_to_ray (geometry.py:273-302): out[n] = ((u-cx)/fx z, (v-cy)/fy z, z) with z = X[n].z
+ * and (u, v) the pixel of n; X, out [P,H*W,3]; K4 = HOST (fx, fy, cx, cy). */
+int m3_constrain_points_to_ray(const float *X, float *out, int P, int H, int W, const float *K4,
+                               void *stream);
+
 /* One Gauss-Newton normal-equation build at a given relative pose (the JTJ/JTr
  * reduction of tracker.py:239-244): out double[36] = H upper triangle (28, row-major),
  * g (7), cost (1).  ws as above. */

@@ -48,6 +48,24 @@ __global__ void k_track_init(const float *__restrict__ T_WCf, const float *__res
     ws[WS_DONE] = 0.0; ws[WS_ITERS] = 0.0; ws[WS_TAUN] = 0.0; ws[WS_COST] = 0.0; ws[WS_CONV] = 0.0;
 }
 
+// wave shuffle + LDS reduction of the 36 per-thread sums -> one partial row of this workgroup
+__device__ __forceinline__ void block_reduce_store(const double *acc, double *__restrict__ out) {
+    __shared__ double red[kThreads / 64][kSums];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < kSums; ++i) {
+        const double s = m3_wave_sum(acc[i]);
+        if (lane == 0) red[wv][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kSums) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) s += red[w][threadIdx.x];
+        out[threadIdx.x] = s;
+    }
+}
+
 __global__ void __launch_bounds__(kThreads)
 k_track_accum(const float *__restrict__ Xf, const float *__restrict__ Xk, const float *__restrict__ Qk,
               const uint8_t *__restrict__ valid, double *__restrict__ ws, int N, float huber_k,
@@ -101,20 +119,77 @@ k_track_accum(const float *__restrict__ Xf, const float *__restrict__ Xk, const 
         }
     }
 
-    __shared__ double red[kThreads / 64][kSums];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < kSums; ++i) {
-        const double s = m3_wave_sum(acc[i]);
-        if (lane == 0) red[wv][i] = s;
+    block_reduce_store(acc, ws + WS_PART + blockIdx.x * kSums);
+}
+
+// Calibrated variant (tracker.py:326-406, project_calib geometry.py:156-227): residual
+// (u, v, log z)_keyframe-pixel - project(T . Xf), rows weighted 1/sigma_pixel (x2), 1/sigma_depth.
+struct TrackCalib { float fx, fy, cx, cy; int W, H; float border, z_eps; };
+
+__global__ void __launch_bounds__(kThreads)
+k_track_accum_calib(const float *__restrict__ Xf, const float *__restrict__ Xk, const float *__restrict__ Qk,
+                    const uint8_t *__restrict__ valid, double *__restrict__ ws, int N, float huber_k,
+                    float inv_sigma_pixel, float inv_sigma_depth, const TrackCalib cal) {
+    {
+        const size_t pb = blockIdx.y;
+        Xf += pb * N * 3; Xk += pb * N * 3; Qk += pb * N; valid += pb * N; ws += pb * WS_STRIDE;
     }
-    __syncthreads();
-    if (threadIdx.x < kSums) {
-        double s = 0.0;
+    if (ws[WS_DONE] != 0.0) return;
+    const Pose<float> T = load_pose<float>(ws + WS_T);
+    double acc[kSums];
 #pragma unroll
-        for (int w = 0; w < kThreads / 64; ++w) s += red[w][threadIdx.x];
-        ws[WS_PART + blockIdx.x * kSums + threadIdx.x] = s;
+    for (int i = 0; i < kSums; ++i) acc[i] = 0.0;
+    for (int n = blockIdx.x * kThreads + threadIdx.x; n < N; n += kBlocks * kThreads) {
+        if (!valid[n]) continue;
+        const float zk = Xk[3 * n + 2];
+        if (!(zk > cal.z_eps)) continue;                    // valid_meas_k (tracker.py:207)
+        const V3<float> p = act(T, V3<float>{Xf[3 * n], Xf[3 * n + 1], Xf[3 * n + 2]});
+        const float zi = 1.0f / (p.z + 1e-10f);
+        const float u = cal.fx * p.x * zi + cal.cx, v = cal.fy * p.y * zi + cal.cy;   // K p / (z + 1e-10)
+        const bool vp = (u > cal.border) && (u < (float)(cal.W - 1) - cal.border) && (v > cal.border) &&
+                        (v < (float)(cal.H - 1) - cal.border) && (p.z > cal.z_eps);
+        if (!vp) continue;                                  // valid_proj (geometry.py:186-190)
+        const float sq = sqrtf(Qk[n]);
+        const float si_px = inv_sigma_pixel * sq, si_d = inv_sigma_depth * sq;
+        const int py = n / cal.W, px = n - py * cal.W;
+        const float res[3] = {(float)px - u, (float)py - v, logf(zk + 1e-10f) - logf(p.z + 1e-10f)};
+        // a_c = -(row c of d(u,v,log z)/dP); J_row = [a, p x a, a . p]
+        const V3<float> a[3] = {{-cal.fx * zi, 0.f, cal.fx * p.x * zi * zi},
+                                {0.f, -cal.fy * zi, cal.fy * p.y * zi * zi},
+                                {0.f, 0.f, -zi}};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float si = (c < 2) ? si_px : si_d;
+            const float wr = fabsf(si * res[c]);
+            const float hub = (wr < huber_k) ? 1.0f : huber_k / wr;
+            const float rsi = si * sqrtf(hub);
+            const V3<float> pa = cross(p, a[c]);
+            const float J[7] = {rsi * a[c].x, rsi * a[c].y, rsi * a[c].z, rsi * pa.x, rsi * pa.y,
+                                rsi * pa.z, rsi * dot(a[c], p)};
+            const float bb = rsi * res[c];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+#pragma unroll
+                for (int j = i; j < 7; ++j) acc[i * 7 - (i * (i - 1)) / 2 + (j - i)] += (double)(J[i] * J[j]);
+                acc[28 + i] -= (double)(J[i] * bb);
+            }
+            acc[35] += (double)(0.5f * bb * bb);
+        }
     }
+    block_reduce_store(acc, ws + WS_PART + blockIdx.x * kSums);
+}
+
+// constrain_points_to_ray (geometry.py:273-302): keep z, move the point onto its pixel's ray
+__global__ void __launch_bounds__(kThreads)
+k_constrain_to_ray(const float *__restrict__ X, float *__restrict__ out, int N, int W, float fx, float fy, float cx,
+                   float cy) {
+    const size_t pb = blockIdx.y;
+    const int n = blockIdx.x * kThreads + threadIdx.x;
+    if (n >= N) return;
+    const float z = X[(pb * N + n) * 3 + 2];
+    const int py = n / W, px = n - py * W;
+    float *o = out + (pb * N + n) * 3;
+    o[0] = ((float)px - cx) / fx * z; o[1] = ((float)py - cy) / fy * z; o[2] = z;
 }
 
 // Fixed-order final reduction of the kBlocks partial rows: wave w owns sums 9w..9w+8,
@@ -293,6 +368,38 @@ int m3_track_gn_ray_dist(const float *Xf, const float *Xk, const float *Qk, cons
     return m3_track_gn_ray_dist_batch(Xf, Xk, Qk, valid, T_WCf, T_WCk, T_WCf_out, T_CkCf_out, info, ws, 1, N,
                                       max_iters, huber_k, sigma_ray, sigma_dist, rel_error, delta_norm, fixed_iters,
                                       stream);
+}
+
+int m3_track_gn_calib_batch(const float *Xf, const float *Xk, const float *Qk, const uint8_t *valid,
+                            const float *T_WCf, const float *T_WCk, float *T_WCf_out, float *T_CkCf_out,
+                            double *info, double *ws, int P, int N, int H, int W, const float *K4, int max_iters,
+                            float huber_k, float sigma_pixel, float sigma_depth, float pixel_border, float depth_eps,
+                            float rel_error, float delta_norm, int fixed_iters, void *stream) {
+    M3_REQUIRE(Xf && Xk && Qk && valid && T_WCf && T_WCk && T_WCf_out && T_CkCf_out && info && ws && K4);
+    M3_REQUIRE(N > 0 && P > 0 && P <= 65535 && H > 0 && W > 0 && (int64_t)H * W == N && max_iters >= 0);
+    M3_REQUIRE(sigma_pixel > 0.f && sigma_depth > 0.f && huber_k > 0.f);
+    hipStream_t st = (hipStream_t)stream;
+    TrackCalib cal{K4[0], K4[1], K4[2], K4[3], W, H, pixel_border, depth_eps};
+    hipLaunchKernelGGL(k_track_init, dim3(P), dim3(64), 0, st, T_WCf, T_WCk, (const float *)nullptr, ws);
+    const float isp = (float)(1.0 / (double)sigma_pixel), isd = (float)(1.0 / (double)sigma_depth);
+    for (int it = 0; it < max_iters; ++it) {
+        hipLaunchKernelGGL(k_track_accum_calib, dim3(kBlocks, P), dim3(kThreads), 0, st, Xf, Xk, Qk, valid, ws, N,
+                           huber_k, isp, isd, cal);
+        hipLaunchKernelGGL(k_track_solve, dim3(P), dim3(kThreads), 0, st, ws, rel_error, delta_norm, fixed_iters);
+    }
+    M3_CHECK_LAUNCH("m3_track_gn_calib/loop");
+    hipLaunchKernelGGL(k_track_final, dim3(P), dim3(64), 0, st, (const double *)ws, T_WCk, T_WCf_out, T_CkCf_out, info);
+    M3_CHECK_LAUNCH("m3_track_gn_calib/final");
+    return M3_OK;
+}
+
+int m3_constrain_points_to_ray(const float *X, float *out, int P, int H, int W, const float *K4, void *stream) {
+    M3_REQUIRE(X && out && K4 && P > 0 && P <= 65535 && H > 0 && W > 0 && K4[0] != 0.f && K4[1] != 0.f);
+    const int N = H * W;
+    hipLaunchKernelGGL(k_constrain_to_ray, dim3(m3_cdiv(N, kThreads), P), dim3(kThreads), 0, (hipStream_t)stream, X, out,
+                       N, W, K4[0], K4[1], K4[2], K4[3]);
+    M3_CHECK_LAUNCH("m3_constrain_points_to_ray");
+    return M3_OK;
 }
 
 int m3_track_normal_eq(const float *Xf, const float *Xk, const float *Qk, const uint8_t *valid,

@@ -35,6 +35,10 @@ DEFAULT_CONFIG: dict[str, Any] = {
         "huber": 1.345,
         "sigma_ray": 0.003,
         "sigma_dist": 10.0,
+        "sigma_pixel": 1.0,
+        "sigma_depth": 10.0,
+        "pixel_border": 0,
+        "depth_eps": 0.0,
         "match_frac_thresh": 0.333,
     },
     "local_opt": {

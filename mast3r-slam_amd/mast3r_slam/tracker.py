@@ -91,6 +91,63 @@ def opt_pose_ray_dist_sim3(Xf, Xk, T_WCf, T_WCk, Qk, valid, cfg=None, fixed_iter
     return out_f[0], out_rel[0], info[0]
 
 
+def _k4(K):
+    """[3,3] or (fx, fy, cx, cy) -> ctypes float[4] (host)."""
+    import ctypes
+
+    import numpy as np
+    Kh = K.detach().cpu().numpy() if isinstance(K, torch.Tensor) else np.asarray(K)
+    vals = (Kh[0, 0], Kh[1, 1], Kh[0, 2], Kh[1, 2]) if Kh.shape == (3, 3) else tuple(Kh.reshape(-1)[:4])
+    return (ctypes.c_float * 4)(*[float(v) for v in vals])
+
+
+def constrain_points_to_ray(img_size, Xs, K):
+    """geometry.py:273-302.  img_size = (height, width); Xs [P,H*W,3] or [H*W,3] -> same shape."""
+    import ctypes
+    h, w = img_size
+    X = _ffi.check(Xs.reshape(-1, h * w, 3), torch.float32, "Xs")
+    out = torch.empty_like(X)
+    k4 = _k4(K)
+    _ffi.call("m3_constrain_points_to_ray", _ffi.ptr(X), _ffi.ptr(out), X.shape[0], h, w,
+              ctypes.cast(k4, ctypes.c_void_p), _ffi.stream_ptr())
+    return out.reshape(Xs.shape)
+
+
+def opt_pose_calib_sim3(Xf, Xk, T_WCf, T_WCk, Qk, valid, K, img_size, cfg=None, fixed_iters: bool = False):
+    """tracker.py:326-406.  Xf [N,3] / [P,N,3] ray-constrained frame points gathered at idx_f2k, Xk the
+    ray-constrained keyframe points in pixel order, K [3,3] or (fx,fy,cx,cy), img_size = (height, width).
+    Returns (T_WCf, T_CkCf, info) like opt_pose_ray_dist_sim3."""
+    import ctypes
+    c = dict(get_config()["tracking"])
+    c.setdefault("sigma_pixel", 1.0); c.setdefault("sigma_depth", 10.0)
+    c.setdefault("pixel_border", 0); c.setdefault("depth_eps", 0.0)
+    c.update(cfg or {})
+    h, w = img_size
+    batched = Xf.dim() == 3
+    P = Xf.shape[0] if batched else 1
+    n = h * w
+    Xf = _ffi.check(Xf.reshape(P, n, 3), torch.float32, "Xf", (P, n, 3))
+    Xk = _ffi.check(Xk.reshape(P, n, 3), torch.float32, "Xk", (P, n, 3))
+    Qk = _ffi.check(Qk.reshape(P, n), torch.float32, "Qk", (P, n))
+    v = _ffi.check(valid.reshape(P, n).to(torch.uint8), torch.uint8, "valid", (P, n))
+    Tf = _ffi.check(T_WCf.reshape(-1, 8).expand(P, 8).contiguous(), torch.float32, "T_WCf", (P, 8))
+    Tk = _ffi.check(T_WCk.reshape(-1, 8).expand(P, 8).contiguous(), torch.float32, "T_WCk", (P, 8))
+    dev = Xf.device
+    out_f = torch.empty((P, 8), dtype=torch.float32, device=dev)
+    out_rel = torch.empty((P, 8), dtype=torch.float32, device=dev)
+    info = torch.empty((P, 4), dtype=torch.float64, device=dev)
+    ws = _ws(dev, P)
+    k4 = _k4(K)
+    _ffi.call("m3_track_gn_calib_batch", _ffi.ptr(Xf), _ffi.ptr(Xk), _ffi.ptr(Qk), _ffi.ptr(v), _ffi.ptr(Tf), _ffi.ptr(Tk),
+              _ffi.ptr(out_f), _ffi.ptr(out_rel), _ffi.ptr(info), _ffi.ptr(ws), P, n, h, w,
+              ctypes.cast(k4, ctypes.c_void_p), int(c["max_iters"]), float(c["huber"]), float(c["sigma_pixel"]),
+              float(c["sigma_depth"]), float(c["pixel_border"]), float(c["depth_eps"]), float(c["rel_error"]),
+              float(c["delta_norm"]), 1 if fixed_iters else 0, _ffi.stream_ptr())
+    if batched:
+        return out_f, out_rel, info
+    return out_f[0], out_rel[0], info[0]
+
+
 def normal_equations(Xf, Xk, T_CkCf, Qk, valid, cfg=None):
     """The J^T W J / J^T W r reduction of tracker.py:239-244 at pose T_CkCf.
     Returns (H [7,7] float64, g [7] float64, cost float64 scalar tensor)."""
@@ -150,15 +207,25 @@ class FrameTracker:
         vm = valid_match_k[0].reshape(-1)
         n = idx.numel()
         frame.update_pointmap(Xff.reshape(n, 3), Cff.reshape(n, 1))
+        use_calib = bool(get_config().get("use_calib", False)) and keyframe.K is not None
+        img = frame.img
+        img_size = (img.shape[1], img.shape[2]) if img.shape[0] == 3 else (img.shape[0], img.shape[1])
+        Xf_canon, Xk_canon = frame.X_canon, keyframe.X_canon
+        if use_calib:                                        # tracker.py:196-199
+            Xf_canon = constrain_points_to_ray(img_size, Xf_canon, keyframe.K)
+            Xk_canon = constrain_points_to_ray(img_size, Xk_canon, keyframe.K)
         Xf, Qk, valid_opt, valid_kf, counts = track_gather(
-            frame.X_canon, frame.get_average_conf(), keyframe.get_average_conf(), Qff, Qkf, idx, vm,
+            Xf_canon, frame.get_average_conf(), keyframe.get_average_conf(), Qff, Qkf, idx, vm,
             self.cfg["C_conf"], self.cfg["Q_conf"])
         cnt = counts.cpu()                       # the one host sync of the frame (match_frac gate, :116)
         if float(cnt[0]) / n < self.cfg["min_match_frac"]:
             print(f"Skipped frame {frame.frame_id}")
             return False, [], True
-        T_WCf, T_CkCf, _ = opt_pose_ray_dist_sim3(Xf, keyframe.X_canon, frame.T_WC, keyframe.T_WC, Qk, valid_opt,
-                                                  self.cfg)
+        if use_calib:
+            T_WCf, T_CkCf, _ = opt_pose_calib_sim3(Xf, Xk_canon, frame.T_WC, keyframe.T_WC, Qk, valid_opt, keyframe.K,
+                                                   img_size, self.cfg)
+        else:
+            T_WCf, T_CkCf, _ = opt_pose_ray_dist_sim3(Xf, Xk_canon, frame.T_WC, keyframe.T_WC, Qk, valid_opt, self.cfg)
         frame.T_WC = T_WCf.reshape(1, 8)
         keyframe.update_pointmap(sim3_act(T_CkCf, Xkf.reshape(n, 3)), Ckf.reshape(n, 1))
         self.keyframes[len(self.keyframes) - 1] = keyframe

@@ -129,3 +129,85 @@ def opt_pose_ray_dist_sim3(Xf, Xk, T_WCf, T_WCk, Qk, valid, cfg=None, dtype=np.f
             break
         old_cost = new_cost
     return S.sim3_mul_mlx(T_WCk, T), T, dict(iters=len(costs), costs=costs, taus=taus)
+
+
+# ------------------------------------------------------------------ calibrated tracking (tracker.py:326-406)
+def project_calib(P, K, img_size, jacobian=False, border=0, z_eps=0.0):
+    """geometry.py:156-227.  P [...,3], K [3,3], img_size = (height, width).
+    Returns (pz [...,3] = (u, v, log z), valid [...,1]) or (pz, dpz_dP [...,3,3], valid)."""
+    h, w = img_size
+    p = np.einsum("ij,...j->...i", K, P)
+    z = p[..., 2:3]
+    uv = (p / (z + 1e-10))[..., :2]
+    u, v = uv[..., 0:1], uv[..., 1:2]
+    valid_z = P[..., 2:3] > z_eps
+    valid = (u > border) & (u < w - 1 - border) & (v > border) & (v < h - 1 - border) & valid_z
+    with np.errstate(invalid="ignore", divide="ignore"):
+        logz = np.where(valid_z, np.log(P[..., 2:3] + 1e-10), 0.0)
+    pz = np.concatenate([uv, logz], axis=-1)
+    if not jacobian:
+        return pz, valid
+    fx, fy = K[0, 0], K[1, 1]
+    x, y, zp = P[..., 0], P[..., 1], P[..., 2]
+    zi = 1.0 / (zp + 1e-10)
+    J = np.zeros(P.shape[:-1] + (3, 3), dtype=P.dtype)
+    J[..., 0, 0] = fx * zi
+    J[..., 0, 2] = -fx * x * zi * zi
+    J[..., 1, 1] = fy * zi
+    J[..., 1, 2] = -fy * y * zi * zi
+    J[..., 2, 2] = zi
+    return pz, J, valid
+
+
+def constrain_points_to_ray(img_size, X, K):
+    """geometry.py:273-302 + backproject :229-245: keep z, put the point on its pixel's ray.  X [H*W,3]."""
+    h, w = img_size
+    vv, uu = np.meshgrid(np.arange(h, dtype=X.dtype), np.arange(w, dtype=X.dtype), indexing="ij")
+    u, v = uu.reshape(-1), vv.reshape(-1)
+    z = X[..., 2]
+    return np.stack([(u - K[0, 2]) / K[0, 0] * z, (v - K[1, 2]) / K[1, 1] * z, z], axis=-1)
+
+
+def calib_measurements(Xk, img_size, depth_eps=0.0):
+    """tracker.py:203-212: meas_k = (u, v, log(z + 1e-10)) zeroed where z <= depth_eps; valid_meas_k."""
+    h, w = img_size
+    vv, uu = np.meshgrid(np.arange(h, dtype=Xk.dtype), np.arange(w, dtype=Xk.dtype), indexing="ij")
+    valid = Xk[..., 2:3] > depth_eps
+    with np.errstate(invalid="ignore", divide="ignore"):
+        meas = np.concatenate([uu.reshape(-1, 1), vv.reshape(-1, 1), np.log(Xk[..., 2:3] + 1e-10)], axis=-1)
+    return np.where(valid, meas, 0.0), valid
+
+
+def opt_pose_calib_sim3(Xf, Xk, T_WCf, T_WCk, Qk, valid, K, img_size, cfg=None, dtype=np.float64, fixed_iters=None):
+    """tracker.py:326-406.  Xf [N,3] (ray-constrained frame points gathered at idx_f2k), Xk [N,3]
+    (ray-constrained keyframe points, pixel order), K [3,3], img_size = (height, width)."""
+    c = dict(DEFAULT_CFG, sigma_pixel=1.0, sigma_depth=10.0, pixel_border=0, depth_eps=0.0)
+    c.update(cfg or {})
+    Xf = np.asarray(Xf, dtype=dtype).reshape(-1, 3)
+    Xk = np.asarray(Xk, dtype=dtype).reshape(-1, 3)
+    K = np.asarray(K, dtype=dtype)
+    Qk = np.asarray(Qk, dtype=dtype).reshape(-1, 1)
+    v = np.asarray(valid).reshape(-1, 1).astype(dtype)
+    T_WCf = np.asarray(T_WCf, dtype=dtype).reshape(8)
+    T_WCk = np.asarray(T_WCk, dtype=dtype).reshape(8)
+    meas_k, valid_meas = calib_measurements(Xk, img_size, c["depth_eps"])
+    si_px = dtype(1.0 / c["sigma_pixel"]) * v * np.sqrt(Qk)
+    si_d = dtype(1.0 / c["sigma_depth"]) * v * np.sqrt(Qk)
+    sqrt_info = np.concatenate([np.broadcast_to(si_px, si_px.shape[:-1] + (2,)), si_d], axis=-1)
+    T = S.sim3_mul_mlx(S.sim3_inv_mlx(T_WCk), T_WCf)
+    old_cost = float("inf")
+    n_it = c["max_iters"] if fixed_iters is None else fixed_iters
+    costs = []
+    for _ in range(n_it):
+        Xf_Ck, dX_dT = act_sim3(T, Xf, jacobian=True)
+        pz, dpz, valid_proj = project_calib(Xf_Ck, K, img_size, True, c["pixel_border"], c["depth_eps"])
+        si2 = np.where(valid_proj & valid_meas, sqrt_info, 0.0)
+        r = meas_k - pz
+        J = -dpz @ dX_dT
+        tau, new_cost, _, _ = solve_step(si2, r, J, c["huber"])
+        T = S.sim3_retr_mlx(T, tau.astype(dtype))
+        costs.append(new_cost)
+        if fixed_iters is None and check_convergence(c["rel_error"], c["delta_norm"], old_cost, new_cost, tau):
+            break
+        old_cost = new_cost
+    return S.sim3_mul_mlx(T_WCk, T), T, dict(iters=len(costs), costs=costs)

@@ -133,3 +133,26 @@ def test_batched_solve_equals_loop_of_single_solves(dev):
     for b in range(2):
         assert np.array_equal(Xf[b].cpu().numpy(), Xc[b][idx[b]])
         assert cnt[b].cpu().tolist()[1] == int((vm[b] & (np.sqrt(Q[b][idx[b]] * Q[b]) > 1.5)).sum())
+
+
+def test_calibrated_tracking_matches_oracle(dev):
+    """opt_pose_calib_sim3 (tracker.py:326-406) vs the float64 oracle; also constrain_points_to_ray."""
+    h, w = 48, 64
+    K = np.array([[float(w), 0, w / 2], [0, float(w), h / 2], [0, 0, 1]], dtype=np.float32)
+    pr = synthetic.tracking_problem(h, w, seed=8)
+    Xk_c = ot.constrain_points_to_ray((h, w), pr["Xk"].astype(np.float64), K.astype(np.float64))
+    out = tracker.constrain_points_to_ray((h, w), _t(pr["Xk"], dev), K)
+    assert np.abs(out.cpu().numpy() - Xk_c).max() < 1e-5
+    Xf = pr["Xf_canon"][pr["idx"]]
+    Tf, Trel, info = tracker.opt_pose_calib_sim3(_t(Xf, dev), _t(pr["Xk"], dev), _t(pr["T_WCf"], dev), _t(pr["T_WCk"], dev),
+                                                 _t(pr["Qk"], dev), _t(pr["valid"], dev), K, (h, w))
+    To, Trel_o, io = ot.opt_pose_calib_sim3(Xf, pr["Xk"], pr["T_WCf"], pr["T_WCk"], pr["Qk"], pr["valid"], K, (h, w))
+    info = info.cpu().numpy()
+    assert int(info[0]) == io["iters"]
+    assert np.abs(Trel.cpu().numpy() - Trel_o).max() < 1e-4          # float32 per-point terms, pixel-scale residuals
+    assert abs(info[1] - io["costs"][-1]) <= 2e-3 * io["costs"][-1]
+    # batched == single
+    st = lambda a: torch.stack([_t(a, dev)] * 2)
+    Tb, Trb, ib = tracker.opt_pose_calib_sim3(st(Xf), st(pr["Xk"]), st(pr["T_WCf"]), st(pr["T_WCk"]), st(pr["Qk"]),
+                                              st(pr["valid"]), K, (h, w))
+    assert torch.equal(Trb[0], Trel) and torch.equal(Trb[1], Trel)

@@ -74,3 +74,33 @@ def test_validity_and_match_quality():
     assert np.allclose(Qk, [3.0, 4.0, 0.5])
     vo, vk = ot.validity(np.array([True, True, True]), np.array([1.0, -1.0, 1.0]), np.ones(3), Qk)
     assert vo.tolist() == [True, False, False] and vk.tolist() == [True, True, False]
+
+
+def test_project_calib_jacobian_fd_and_gates():
+    rng = np.random.default_rng(4)
+    K = np.array([[400.0, 0, 160], [0, 420.0, 120], [0, 0, 1]])
+    P = rng.normal(size=(40, 3)) * 0.3 + np.array([0, 0, 3.0])
+    pz, J, valid = ot.project_calib(P, K, (240, 320), jacobian=True)
+    eps = 1e-6
+    for k in range(3):
+        d = np.zeros(3); d[k] = eps
+        fd = (ot.project_calib(P + d, K, (240, 320))[0] - ot.project_calib(P - d, K, (240, 320))[0]) / (2 * eps)
+        assert np.allclose(J[:, :, k], fd, atol=1e-5)
+    assert valid.all()
+    Pb = np.array([[0.0, 0.0, -1.0], [50.0, 0.0, 1.0]])
+    pz2, v2 = ot.project_calib(Pb, K, (240, 320))
+    assert not v2.any() and pz2[0, 2] == 0.0                              # behind the camera / outside the image
+
+
+def test_calibrated_tracking_recovers_known_sim3():
+    h, w = 24, 32
+    K = np.array([[float(w), 0, w / 2], [0, float(w), h / 2], [0, 0, 1]])
+    pr = synthetic.tracking_problem(h, w, seed=6, noise=0.0, perm_frac=0.0, valid_p=1.0)
+    Xk = ot.constrain_points_to_ray((h, w), pr["Xk"].astype(np.float64), K)
+    assert np.allclose(Xk, pr["Xk"], atol=1e-6)                            # the synthetic surface is back-projected with f = w
+    Xf = pr["Xf_canon"][pr["idx"]]
+    _, T_rel, info = ot.opt_pose_calib_sim3(Xf, Xk, pr["T_WCf"], pr["T_WCk"], pr["Qk"] + 1.0, pr["valid"], K, (h, w),
+                                            cfg=dict(max_iters=60, rel_error=0, delta_norm=1e-10))
+    assert np.allclose(T_rel[:3], pr["T_true"][:3], atol=5e-4)
+    assert abs(T_rel[7] - pr["T_true"][7]) < 5e-4
+    assert info["costs"][-1] < 1e-4 * info["costs"][0]

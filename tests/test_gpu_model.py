@@ -218,3 +218,42 @@ def test_gemm_with_fused_rope_epilogue(dev, m_n_k):
     cs = torch.stack([cos, sin], -1).to(dev).contiguous()
     out = ops.gemm_rope(a.to(dev), w.to(dev), b.to(dev), pos.to(torch.int32).to(dev), cs, t, rope_cols)
     assert _rel(out, ref) < 3e-3
+
+
+def test_frame_tracker_end_to_end(tiny, dev):
+    """The reference's per-frame flow (slam.py:159-214): mono-init a keyframe, then FrameTracker.track a new
+    frame against it through the injected operator (tracker.py:51-175).  Random weights give meaningless
+    geometry, so only the contract is checked: types, shapes, the relocalisation gate and pose bookkeeping."""
+    from mast3r_slam import config
+    from mast3r_slam.frame import Keyframes
+    from mast3r_slam.tracker import FrameTracker
+    cfg, w, net = tiny
+    h, wd = 128, 256
+    kf = create_frame(0, torch.from_numpy(synthetic.textured_image(h, wd, 0)).to(dev))
+    X, C, feat, pos = mast3r_utils.mast3r_inference_mono(net, kf)
+    kf.update_pointmap(X, C)
+    keyframes = Keyframes()
+    keyframes.append(kf)
+    fr = create_frame(1, torch.from_numpy(synthetic.textured_image(h, wd, 1)).to(dev))
+    tr = FrameTracker(net, keyframes)
+    for simple in (True, False):
+        # Q_conf / C_conf lowered so that the random-weight confidences pass the validity masks
+        config.set_config({"matching": {"use_simple": simple, "dist_thresh": 1e9},
+                           "tracking": {"Q_conf": -1.0, "C_conf": -1.0, "min_match_frac": 0.0}})
+        try:
+            tr.cfg = config.get_config()["tracking"]
+            tr.reset_idx_f2k()
+            new_kf, match_info, try_reloc = tr.track(fr, mast3r_match_fn=mast3r_utils.mast3r_match_asymmetric)
+        finally:
+            config.reset_config()
+        assert try_reloc is False and isinstance(new_kf, bool) and len(match_info) == 6
+        assert fr.T_WC.shape == (1, 8) and torch.isfinite(fr.T_WC).all()
+        assert tr.idx_f2k is None or tr.idx_f2k.shape == (1, h * wd)
+        assert keyframes.last_keyframe().N >= 2                         # keyframe pointmap was fused again
+    # the min_match_frac gate (tracker.py:116-119): impossible thresholds -> relocalise
+    config.set_config({"tracking": {"Q_conf": 1e9}})
+    try:
+        tr.cfg = config.get_config()["tracking"]
+        assert tr.track(fr, mast3r_match_fn=mast3r_utils.mast3r_match_asymmetric) == (False, [], True)
+    finally:
+        config.reset_config()

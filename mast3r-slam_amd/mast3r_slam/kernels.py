@@ -116,17 +116,13 @@ def _local_map(ii, jj, num_kf: int, pin: int):
     return uniq, local, max(len(uniq) - pin, 0)
 
 
-_calib_keep = []
-
-
 def _calib_ptr(calib):
-    """10 host floats -> pointer (ctypes array kept alive for the duration of the call sequence)."""
+    """10 host floats -> ctypes float[10] (the C side copies it during the call; ctypes passes the
+    array by reference and keeps it alive for the duration of the call)."""
     if calib is None:
         return None
     import ctypes
-    arr = (ctypes.c_float * 10)(*[float(v) for v in calib])
-    _calib_keep[:] = [arr]
-    return ctypes.cast(arr, ctypes.c_void_p)
+    return (ctypes.c_float * 10)(*[float(v) for v in calib])
 
 
 def gn_rays_blocks(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray: float = 0.003,

@@ -138,6 +138,11 @@ def so3_exp_mlx(omega):
     return np.concatenate([sinc_half * omega, cos_half], axis=-1)
 
 
+def _safe_div(a, b):
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return a / b
+
+
 def sim3_exp_mlx(tau):
     """sim3.py:107-154: t = v + B w x v + C w x (w x v), s = exp(sigma)."""
     v, omega, sigma = tau[..., :3], tau[..., 3:6], tau[..., 6:7]
@@ -146,9 +151,9 @@ def sim3_exp_mlx(tau):
     small = th2 < 1e-8
     s = np.exp(sigma)
     A = np.where(small, 1.0 - th2 / 6.0, np.sin(th) / th)
-    B = np.where(small, 0.5 - th2 / 24.0, (1.0 - np.cos(th)) / th2)
+    B = np.where(small, 0.5 - th2 / 24.0, _safe_div(1.0 - np.cos(th), th2))
     wv = cross(omega, v)
-    C = np.where(small, 1.0 / 6.0 - th2 / 120.0, (1.0 - A) / th2)
+    C = np.where(small, 1.0 / 6.0 - th2 / 120.0, _safe_div(1.0 - A, th2))
     t = v + B * wv + C * cross(omega, wv)
     return np.concatenate([t, so3_exp_mlx(omega), s], axis=-1)
 

@@ -49,7 +49,7 @@ struct AttnArgs {
     float scale_log2e;                                    // softmax scale * log2(e)
 };
 
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads, 4)
 k_attn(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kLds];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

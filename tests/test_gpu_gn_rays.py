@@ -128,3 +128,38 @@ def test_gauss_newton_calib_golden(golden_dir):
             assert np.abs(bl[ei, :28] - Hjj[iu]).max() <= 1e-4 * np.abs(Hjj).max()
             assert np.abs(bl[ei, 28:35] - gj).max() <= 1e-4 * np.abs(gj).max()
     assert not np.allclose(blocks[:, :28], bl[:, :28])
+
+
+def test_config5_scale_blocks_and_solve(dev):
+    """BASELINE configs[4] at reduced scale: 32 keyframes x 65 536 points, each keyframe linked to its previous
+    three (slam.py:302-303) in both directions (186 directed edges).  Checks the per-edge blocks against the
+    float64 oracle on a sample of edges, size-independent properties (edge-order equivariance, bitwise
+    reproducibility) and a 2-iteration on-device solve (217-dim Cholesky) against the float64 oracle."""
+    K_, P_ = 32, 65536
+    Twc, Xs, Cs, ii, jj, idx, valid, Q = synthetic.gn_graph(K_, P_, 0, seed=17, chain=True, pose_noise=0.0)
+    rng = np.random.default_rng(0)
+    noisy = Twc.copy()
+    noisy[1:, :3] += rng.normal(size=(K_ - 1, 3)).astype(np.float32) * 0.01
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    args = [t(a) for a in (noisy, Xs, Cs, ii, jj, idx, valid, Q)]
+    blocks = kernels.gn_rays_blocks(*args).cpu().numpy()
+    assert blocks.shape == (len(ii), 36)
+    tt = noisy[:, :3].astype(np.float64); qq = noisy[:, 3:7].astype(np.float64); ss = noisy[:, 7].astype(np.float64)
+    iu = np.triu_indices(7)
+    for e in (0, 57, len(ii) - 1):
+        Hjj, gj, n = og.edge_blocks(tt, qq, ss, Xs, Cs, int(ii[e]), int(jj[e]), idx[e], valid[e], Q[e])
+        assert blocks[e, 35] == n
+        # float32 per-point terms (pose, residual, Huber weight) summed over 45k points in float64
+        assert np.abs(blocks[e, :28] - Hjj[iu]).max() <= 2e-4 * np.abs(Hjj).max()
+        assert np.abs(blocks[e, 28:35] - gj).max() <= 2e-3 * np.abs(gj).max() + 1e-3
+    # equivariance: permuting the edge list permutes the blocks, bit for bit
+    perm = rng.permutation(len(ii))
+    pa = [args[0], args[1], args[2]] + [t(a[perm]) for a in (ii, jj, idx, valid, Q)]
+    assert np.array_equal(kernels.gn_rays_blocks(*pa).cpu().numpy(), blocks[perm])
+    assert np.array_equal(kernels.gn_rays_blocks(*args).cpu().numpy(), blocks)       # reproducible
+    out, info = kernels.gauss_newton_rays(*args, max_iter=2, return_info=True)
+    out = out.cpu().numpy()
+    assert not info["failed"] and info["iters"] == 2
+    assert np.array_equal(out[0], noisy[0])                                           # pinned keyframe
+    ref = og.gauss_newton_rays(noisy, Xs, Cs, ii, jj, idx, valid, Q, max_iter=2)       # float64 oracle, same graph
+    assert np.isfinite(out).all() and np.abs(out - ref).max() < 5e-4

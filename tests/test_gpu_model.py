@@ -257,3 +257,22 @@ def test_frame_tracker_end_to_end(tiny, dev):
         assert tr.track(fr, mast3r_match_fn=mast3r_utils.mast3r_match_asymmetric) == (False, [], True)
     finally:
         config.reset_config()
+
+
+def test_non_square_512x384_pair(tiny, dev):
+    """BASELINE configs[0] image shape on the device path: 512x384 (T = 768 tokens) through network + matcher."""
+    from mast3r_slam import config, matching
+    cfg, w, net = tiny
+    h, wd = 384, 512
+    im1 = synthetic.textured_image(h, wd, 4)[None]
+    im2 = synthetic.textured_image(h, wd, 5)[None]
+    o1, o2 = net.reconstruct_batch(im1, im2)
+    r1, r2 = OM.reconstruct(w, torch.from_numpy(im1), torch.from_numpy(im2), cfg)
+    assert o1["pts3d"].shape == (1, h, wd, 3)
+    assert _rel(o1["pts3d"], r1["pts3d"]) < 1e-3 and _rel(o2["pts3d"], r2["pts3d"]) < 1e-3
+    config.set_config({"matching": {"use_simple": False}})
+    try:
+        idx, valid = matching.match(o1["pts3d"], o2["pts3d"], o1["desc"], o2["desc"])
+    finally:
+        config.reset_config()
+    assert idx.shape == (1, h * wd) and valid.shape == (1, h * wd, 1)

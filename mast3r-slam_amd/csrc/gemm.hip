@@ -134,14 +134,8 @@ k_gemm(const GemmArgs gin) {
         __builtin_amdgcn_s_barrier();      // all waves done reading `buf` before it is restaged
     }
 
-    // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] --------------
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (EPI == EPI_BF16_ROPE) rope_strip(g, acc[i], m0 + wr * 64 + i * 16 + (lane & 15), n0 + wc * 64, lane);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            store_tile<EPI>(g, acc[i][j], m0 + wr * 64 + i * 16 + (lane & 15), n0 + wc * 64 + j * 16 + (lane >> 4) * 4);
-    }
+    // ---- epilogue: row-contiguous stores through a per-wave LDS scratch (gemm_common.h) --------
+    epilogue_rows<EPI, 4>(g, acc, lds + wave * 9216, m0 + wr * 64, n0 + wc * 64, lane);
 }
 
 template <int MODE>

@@ -183,13 +183,9 @@ k_gemm256(const GemmArgs gin) {
         phase_end();
     }
 
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        if (EPI == EPI_BF16_ROPE) rope_strip(g, acc[i], m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 64, lane);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            store_tile<EPI>(g, acc[i][j], m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 64 + j * 16 + (lane >> 4) * 4);
-    }
+    // epilogue: the operand stages are dead after the last barrier; each wave transposes its 128x64
+    // sub-tile through a private 9 KiB LDS scratch and stores full rows (gemm_common.h)
+    epilogue_rows<EPI, 8>(g, acc, lds + wave * 9216, m0 + wr * 128, n0 + wc * 64, lane);
 }
 
 template <int MODE>

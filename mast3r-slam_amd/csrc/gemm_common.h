@@ -17,19 +17,35 @@ __device__ __forceinline__ bf16_t f2bf(float f) {        // round-to-nearest-eve
     if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
     return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
-// GELU (erf form).  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16 output
-// rounding of 2^-9): one v_rcp, one v_exp and a 5-term Horner chain instead of libm's erff.
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
-    const float erf_abs = 1.0f - p * t * e;
-    const float erf = x < 0.f ? -erf_abs : erf_abs;
-    return 0.5f * x * (1.0f + erf);
+// GELU (erf form), two elements per lane at a time so the chain maps to v_pk_mul/v_pk_fma_f32.
+// erf(z) = z * P(z^2) on |z| <= 3 (clamped; 1 - erf(3) = 2.2e-5), P = degree-8 minimax fit, max abs
+// error 2.5e-5 in erf, 6e-5 in gelu(x) (at |x| ~ 4.2 where one bf16 ulp is 1.6e-2) - far below the
+// 2^-9 rounding of the bf16 output.  No transcendental: ~8 VALU issues per element instead of the
+// 16 + rcp + exp of the Abramowitz-Stegun form, which cost 10 us per 256x256 tile (fc1 epilogue).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+    f32x2 z = x * 0.70710678118654752f;
+    z.x = __builtin_amdgcn_fmed3f(z.x, -3.0f, 3.0f);
+    z.y = __builtin_amdgcn_fmed3f(z.y, -3.0f, 3.0f);
+    const f32x2 u = z * z;
+    f32x2 p = (f32x2)(4.074053805e-08f);
+    p = __builtin_elementwise_fma(p, u, (f32x2)(-1.944763426e-06f));
+    p = __builtin_elementwise_fma(p, u, (f32x2)(4.105960033e-05f));
+    p = __builtin_elementwise_fma(p, u, (f32x2)(-5.110292695e-04f));
+    p = __builtin_elementwise_fma(p, u, (f32x2)(4.235391971e-03f));
+    p = __builtin_elementwise_fma(p, u, (f32x2)(-2.510276809e-02f));
+    p = __builtin_elementwise_fma(p, u, (f32x2)(1.110792086e-01f));
+    p = __builtin_elementwise_fma(p, u, (f32x2)(-3.753148019e-01f));
+    p = __builtin_elementwise_fma(p, u, (f32x2)(1.128268361e+00f));
+    const f32x2 hx = x * 0.5f;
+    return __builtin_elementwise_fma(hx, z * p, hx);
+}
+
+// two fp32 -> packed bf16x2 (round to nearest even), lo in bits 0..15
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
 }
 
 __device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
@@ -95,8 +111,8 @@ __device__ __forceinline__ void store_tile(const GemmArgs &g, f32x4 v, int m, in
         *reinterpret_cast<float4 *>(C) = make_float4(v[0], v[1], v[2], v[3]);
     } else {
         if (EPI == EPI_BF16_GELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            const f32x2 lo = gelu_erf2(f32x2{v[0], v[1]}), hi = gelu_erf2(f32x2{v[2], v[3]});
+            v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
         }
         if (EPI == EPI_BF16_ADD) {
             const ushort4 r = *reinterpret_cast<const ushort4 *>(reinterpret_cast<const bf16_t *>(g.R) + off);
@@ -139,6 +155,133 @@ __device__ __forceinline__ void rope_strip(const GemmArgs &g, f32x4 *t, int m, i
             const float x1 = a[e], x2 = b[e];
             a[e] = x1 * cc[e] - x2 * ss[e];
             b[e] = x2 * cc[e] + x1 * ss[e];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row-contiguous epilogue through LDS.
+//
+// In the accumulator layout a store instruction of one 16x16 tile touches 16 rows x 32 bytes: the
+// write path is then limited by the number of partial-line requests, not by bytes (measured with
+// s_memtime on 16384x3072x1024: 13.8 us of store issue per 256x256 tile against a 22 us K loop,
+// 24 us with the fp32 residual read-modify-write).  After the K loop the operand stages are dead,
+// so every wave transposes its own sub-tile through a private LDS scratch (padded rows, no
+// workgroup barrier needed) and writes/reads global memory 16 bytes per lane with 8 (bf16) or 16
+// (fp32) consecutive lanes per row: full 128-byte lines, 2x fewer instructions.
+//   wave sub-tile = (16*NI) rows x 64 columns at (m_base, n_base); wlds = >= 9216 bytes per wave.
+// Bias / activation / RoPE are applied in the accumulator layout before the transpose, residuals
+// (fp32 accumulate, bf16 add) on the row-contiguous side.  Falls back to store_tile when the
+// output is not 16-byte aligned.
+template <int EPI, int NI>
+__device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI][4], unsigned char *wlds,
+                                              int m_base, int n_base, int lane) {
+    constexpr bool F32OUT = (EPI == EPI_F32 || EPI == EPI_F32_ACCUM);
+    constexpr bool F32LDS = F32OUT || EPI == EPI_BF16_ADD;        // keep one rounding for the bf16 residual add
+    const int r = lane & 15, gq = lane >> 4;
+    const bool aligned = ((reinterpret_cast<size_t>(g.C) & 15) == 0) && (g.ldc % (F32OUT ? 4 : 8) == 0) &&
+                         (F32OUT || g.N % 8 == 0) &&
+                         (!(EPI == EPI_F32_ACCUM || EPI == EPI_BF16_ADD) || (reinterpret_cast<size_t>(g.R) & 15) == 0);
+    if (!aligned) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (EPI == EPI_BF16_ROPE) rope_strip(g, acc[i], m_base + i * 16 + r, n_base, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) store_tile<EPI>(g, acc[i][j], m_base + i * 16 + r, n_base + j * 16 + gq * 4);
+        }
+        return;
+    }
+    float4 bj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n_base + j * 16 + gq * 4;
+        bj[j] = (EPI != EPI_BF16_ROPE && g.bias && n < g.N) ? *reinterpret_cast<const float4 *>(g.bias + n)
+                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (F32LDS) {
+        constexpr int RS = 272;                                   // 64 fp32 + 16 bytes of padding
+#pragma unroll
+        for (int pass = 0; pass < NI / 2; ++pass) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = acc[pass * 2 + ii][j];
+                    *reinterpret_cast<float4 *>(wlds + (ii * 16 + r) * RS + (j * 16 + gq * 4) * 4) =
+                        make_float4(v[0] + bj[j].x, v[1] + bj[j].y, v[2] + bj[j].z, v[3] + bj[j].w);
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (F32OUT) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int rl = it * 4 + (lane >> 4), ch = lane & 15;
+                    float4 v = *reinterpret_cast<const float4 *>(wlds + rl * RS + ch * 16);
+                    const int m = m_base + pass * 32 + rl, n = n_base + ch * 4;
+                    if (m < g.M && n < g.N) {
+                        const size_t off = (size_t)m * g.ldc + n;
+                        if (EPI == EPI_F32_ACCUM) {
+                            const float4 q = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(g.R) + off);
+                            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+                        }
+                        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(g.C) + off) = v;
+                    }
+                }
+            } else {                                              // EPI_BF16_ADD: 8 columns per lane
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int rl = it * 8 + (lane >> 3), ch = lane & 7;
+                    const float4 a = *reinterpret_cast<const float4 *>(wlds + rl * RS + ch * 32);
+                    const float4 b = *reinterpret_cast<const float4 *>(wlds + rl * RS + ch * 32 + 16);
+                    const int m = m_base + pass * 32 + rl, n = n_base + ch * 8;
+                    if (m < g.M && n < g.N) {
+                        const size_t off = (size_t)m * g.ldc + n;
+                        const uint4 q = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16_t *>(g.R) + off);
+                        uint4 o;
+                        o.x = pack_bf16(a.x + __uint_as_float(q.x << 16), a.y + __uint_as_float(q.x & 0xffff0000u));
+                        o.y = pack_bf16(a.z + __uint_as_float(q.y << 16), a.w + __uint_as_float(q.y & 0xffff0000u));
+                        o.z = pack_bf16(b.x + __uint_as_float(q.z << 16), b.y + __uint_as_float(q.z & 0xffff0000u));
+                        o.w = pack_bf16(b.z + __uint_as_float(q.w << 16), b.w + __uint_as_float(q.w & 0xffff0000u));
+                        *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(g.C) + off) = o;
+                    }
+                }
+            }
+            asm volatile("" ::: "memory");
+        }
+    } else {
+        constexpr int RS = 144;                                   // 64 bf16 + 16 bytes of padding
+#pragma unroll
+        for (int pass = 0; pass < NI / 4; ++pass) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = pass * 4 + ii;
+                if (EPI == EPI_BF16_ROPE) rope_strip(g, acc[i], m_base + i * 16 + r, n_base, lane);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = acc[i][j];
+                    v[0] += bj[j].x; v[1] += bj[j].y; v[2] += bj[j].z; v[3] += bj[j].w;
+                    if (EPI == EPI_BF16_GELU) {
+                        const f32x2 lo = gelu_erf2(f32x2{v[0], v[1]}), hi = gelu_erf2(f32x2{v[2], v[3]});
+                        v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
+                    }
+                    if (EPI == EPI_BF16_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    }
+                    uint2 pk;
+                    pk.x = pack_bf16(v[0], v[1]); pk.y = pack_bf16(v[2], v[3]);
+                    *reinterpret_cast<uint2 *>(wlds + (ii * 16 + r) * RS + (j * 16 + gq * 4) * 2) = pk;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int rl = it * 8 + (lane >> 3), ch = lane & 7;
+                const uint4 v = *reinterpret_cast<const uint4 *>(wlds + rl * RS + ch * 16);
+                const int m = m_base + pass * 64 + rl, n = n_base + ch * 8;
+                if (m < g.M && n < g.N)
+                    *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(g.C) + (size_t)m * g.ldc + n) = v;
+            }
+            asm volatile("" ::: "memory");
         }
     }
 }

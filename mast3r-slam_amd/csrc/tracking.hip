@@ -18,7 +18,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kBlocks = 256;          // one partial row per CU
+constexpr int kBlocks = 256;          // most partial rows a problem can have (workspace size)
 constexpr int kSums = 36;             // 28 (H upper) + 7 (g) + 1 (cost)
 // workspace layout (doubles)
 constexpr int WS_T = 0;               // T_CkCf [8]
@@ -31,6 +31,14 @@ constexpr int WS_CONV = 13;
 constexpr int WS_PART = 16;           // partials [kBlocks][kSums]
 
 constexpr int WS_STRIDE = WS_PART + kBlocks * kSums;   // doubles per problem
+
+// Partial rows (= workgroups) per problem: ~2 workgroups per CU over the whole batch, so a thread sees
+// enough points to amortise the 36-value block reduction (at 256 rows x 8 problems it saw 4 points
+// and the reduction dominated: 62 us per iteration for 8 x 262144 points, HBM time 10 us).
+static inline int track_blocks(int P) {
+    int b = 512 / (P > 0 ? P : 1);
+    return b < 16 ? 16 : (b > kBlocks ? kBlocks : b);
+}
 
 __global__ void k_track_init(const float *__restrict__ T_WCf, const float *__restrict__ T_WCk,
                              const float *__restrict__ T_rel, double *__restrict__ ws) {
@@ -80,7 +88,7 @@ k_track_accum(const float *__restrict__ Xf, const float *__restrict__ Xk, const 
 #pragma unroll
     for (int i = 0; i < kSums; ++i) acc[i] = 0.0;
 
-    for (int n = blockIdx.x * kThreads + threadIdx.x; n < N; n += kBlocks * kThreads) {
+    for (int n = blockIdx.x * kThreads + threadIdx.x; n < N; n += gridDim.x * kThreads) {
         if (!valid[n]) continue;
         const float sq = sqrtf(Qk[n]);
         const float si_ray = inv_sigma_ray * sq, si_dist = inv_sigma_dist * sq;
@@ -139,7 +147,7 @@ k_track_accum_calib(const float *__restrict__ Xf, const float *__restrict__ Xk, 
     double acc[kSums];
 #pragma unroll
     for (int i = 0; i < kSums; ++i) acc[i] = 0.0;
-    for (int n = blockIdx.x * kThreads + threadIdx.x; n < N; n += kBlocks * kThreads) {
+    for (int n = blockIdx.x * kThreads + threadIdx.x; n < N; n += gridDim.x * kThreads) {
         if (!valid[n]) continue;
         const float zk = Xk[3 * n + 2];
         if (!(zk > cal.z_eps)) continue;                    // valid_meas_k (tracker.py:207)
@@ -194,12 +202,12 @@ k_constrain_to_ray(const float *__restrict__ X, float *__restrict__ out, int N, 
 
 // Fixed-order final reduction of the kBlocks partial rows: wave w owns sums 9w..9w+8,
 // every lane adds rows lane, lane+64, lane+128, lane+192, then a shuffle tree.
-__device__ __forceinline__ void reduce_partials(const double *__restrict__ part, double *sums /*LDS[36]*/) {
+__device__ __forceinline__ void reduce_partials(const double *__restrict__ part, double *sums /*LDS[36]*/, int nblk) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int c = 0; c < 9; ++c) {
         const int col = wv * 9 + c;
         double s = 0.0;
-        for (int r = lane; r < kBlocks; r += 64) s += part[r * kSums + col];
+        for (int r = lane; r < nblk; r += 64) s += part[r * kSums + col];
         s = m3_wave_sum(s);
         if (lane == 0) sums[col] = s;
     }
@@ -207,11 +215,11 @@ __device__ __forceinline__ void reduce_partials(const double *__restrict__ part,
 }
 
 __global__ void __launch_bounds__(kThreads)
-k_track_solve(double *__restrict__ ws, float rel_error, float delta_norm, int fixed_iters) {
+k_track_solve(double *__restrict__ ws, float rel_error, float delta_norm, int fixed_iters, int nblk) {
     ws += (size_t)blockIdx.x * WS_STRIDE;
     if (ws[WS_DONE] != 0.0) return;
     __shared__ double sums[kSums];
-    reduce_partials(ws + WS_PART, sums);
+    reduce_partials(ws + WS_PART, sums, nblk);
     if (threadIdx.x != 0) return;
     double H[7][7], g[7];
     int k = 0;
@@ -253,10 +261,10 @@ __global__ void k_track_final(const double *__restrict__ ws, const float *__rest
 }
 
 __global__ void __launch_bounds__(kThreads)
-k_track_export(const double *__restrict__ ws, double *__restrict__ out) {
+k_track_export(const double *__restrict__ ws, double *__restrict__ out, int nblk) {
     ws += (size_t)blockIdx.x * WS_STRIDE; out += (size_t)blockIdx.x * kSums;
     __shared__ double sums[kSums];
-    reduce_partials(ws + WS_PART, sums);
+    reduce_partials(ws + WS_PART, sums, nblk);
     if (threadIdx.x < kSums) out[threadIdx.x] = sums[threadIdx.x];
 }
 
@@ -349,10 +357,11 @@ int m3_track_gn_ray_dist_batch(const float *Xf, const float *Xk, const float *Qk
     hipLaunchKernelGGL(k_track_init, dim3(P), dim3(64), 0, st, T_WCf, T_WCk, (const float *)nullptr, ws);
     M3_CHECK_LAUNCH("m3_track_gn/init");
     const float isr = (float)(1.0 / (double)sigma_ray), isd = (float)(1.0 / (double)sigma_dist);
+    const int nblk = track_blocks(P);
     for (int it = 0; it < max_iters; ++it) {
-        hipLaunchKernelGGL(k_track_accum, dim3(kBlocks, P), dim3(kThreads), 0, st, Xf, Xk, Qk, valid, ws, N,
+        hipLaunchKernelGGL(k_track_accum, dim3(nblk, P), dim3(kThreads), 0, st, Xf, Xk, Qk, valid, ws, N,
                            huber_k, isr, isd);
-        hipLaunchKernelGGL(k_track_solve, dim3(P), dim3(kThreads), 0, st, ws, rel_error, delta_norm, fixed_iters);
+        hipLaunchKernelGGL(k_track_solve, dim3(P), dim3(kThreads), 0, st, ws, rel_error, delta_norm, fixed_iters, nblk);
     }
     M3_CHECK_LAUNCH("m3_track_gn/loop");
     hipLaunchKernelGGL(k_track_final, dim3(P), dim3(64), 0, st, (const double *)ws, T_WCk, T_WCf_out,
@@ -382,10 +391,11 @@ int m3_track_gn_calib_batch(const float *Xf, const float *Xk, const float *Qk, c
     TrackCalib cal{K4[0], K4[1], K4[2], K4[3], W, H, pixel_border, depth_eps};
     hipLaunchKernelGGL(k_track_init, dim3(P), dim3(64), 0, st, T_WCf, T_WCk, (const float *)nullptr, ws);
     const float isp = (float)(1.0 / (double)sigma_pixel), isd = (float)(1.0 / (double)sigma_depth);
+    const int nblk = track_blocks(P);
     for (int it = 0; it < max_iters; ++it) {
-        hipLaunchKernelGGL(k_track_accum_calib, dim3(kBlocks, P), dim3(kThreads), 0, st, Xf, Xk, Qk, valid, ws, N,
+        hipLaunchKernelGGL(k_track_accum_calib, dim3(nblk, P), dim3(kThreads), 0, st, Xf, Xk, Qk, valid, ws, N,
                            huber_k, isp, isd, cal);
-        hipLaunchKernelGGL(k_track_solve, dim3(P), dim3(kThreads), 0, st, ws, rel_error, delta_norm, fixed_iters);
+        hipLaunchKernelGGL(k_track_solve, dim3(P), dim3(kThreads), 0, st, ws, rel_error, delta_norm, fixed_iters, nblk);
     }
     M3_CHECK_LAUNCH("m3_track_gn_calib/loop");
     hipLaunchKernelGGL(k_track_final, dim3(P), dim3(64), 0, st, (const double *)ws, T_WCk, T_WCf_out, T_CkCf_out, info);
@@ -413,7 +423,7 @@ int m3_track_normal_eq(const float *Xf, const float *Xk, const float *Qk, const 
     const float isr = (float)(1.0 / (double)sigma_ray), isd = (float)(1.0 / (double)sigma_dist);
     hipLaunchKernelGGL(k_track_accum, dim3(kBlocks), dim3(kThreads), 0, st, Xf, Xk, Qk, valid, ws, N, huber_k,
                        isr, isd);
-    hipLaunchKernelGGL(k_track_export, dim3(1), dim3(kThreads), 0, st, (const double *)ws, out);
+    hipLaunchKernelGGL(k_track_export, dim3(1), dim3(kThreads), 0, st, (const double *)ws, out, kBlocks);
     M3_CHECK_LAUNCH("m3_track_normal_eq");
     return M3_OK;
 }

@@ -354,9 +354,12 @@ class Mast3rFull:
     def _fusion(self, q, x0, x1=None):
         P = self.P
         out = x0 if x1 is None else ops.add(x0, self._rcu(x1, q + ".resConfUnit1"))
-        out = ops.upsample2x(self._rcu(out, q + ".resConfUnit2"))
+        # out_conv is 1x1 and the align_corners bilinear weights sum to one, so conv(upsample(x)) ==
+        # upsample(conv(x)): run the GEMM on the low-resolution map (4x fewer rows), then upsample.
+        out = self._rcu(out, q + ".resConfUnit2")
         b, h, w, ch = out.shape
-        return ops.gemm(out.view(-1, ch), P[q + ".out_conv.w"], P[q + ".out_conv.b"], ops.EPI_BF16).view(b, h, w, -1)
+        out = ops.gemm(out.view(-1, ch), P[q + ".out_conv.w"], P[q + ".out_conv.b"], ops.EPI_BF16).view(b, h, w, -1)
+        return ops.upsample2x(out)
 
     def head(self, hname: str, taps, npairs: int, grid):
         """taps: 4 bf16 [P*T,C] tensors -> dict(pts3d [P,H,W,3], conf [P,H,W], desc [P,H,W,24], desc_conf [P,H,W])."""

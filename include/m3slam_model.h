@@ -52,9 +52,16 @@ int m3_gemm_bf16_grouped2(const void *A, const void *W0, const void *W1, const f
 /* 3x3 convolution, padding 1, stride 1 or 2, as an implicit GEMM: X bf16 NHWC [B,H,W,Cin],
  * W bf16 [Cout,3,3,Cin], Y NHWC [B,OH,OW,Cout].  Cin % 64 == 0, Cout % 4 == 0.  zero16: 16
  * zero bytes in device memory (source of the padding taps). */
+/* Split-K scratch of m3_conv3x3_bf16: small feature maps with a long K (the 16x16 / 32x32 DPT maps,
+ * K = 9*Cin up to 6912) cannot fill the chip with output tiles, so they are multiplied in K-slices
+ * into fp32 partial planes which a second kernel sums in a fixed order before applying the epilogue.
+ * The slice count depends on the per-image geometry only (not on B): a pair's result does not depend
+ * on the batch it is computed in.  Returns the scratch bytes the call needs (0: direct path). */
+int64_t m3_conv3x3_splitk_bytes(int B, int H, int Wd, int Cin, int Cout, int stride);
+
 int m3_conv3x3_bf16(const void *X, const void *W, const float *bias, void *Y, const void *R,
                     const void *zero16, int B, int H, int Wd, int Cin, int Cout, int stride,
-                    int epilogue, void *stream);
+                    int epilogue, void *splitk_ws, int64_t splitk_ws_bytes, void *stream);
 
 /* Fused multi-head attention, head dim 64: O = softmax(scale * Q K^T) V, bf16 in/out, fp32
  * softmax.  Q/K/V/O are addressed as base + batch*batch_stride + token*row_stride + head*64

@@ -10,7 +10,7 @@ void m3_set_hip_error(hipError_t e, const char *where) {
 
 extern "C" {
 
-int m3_abi_version(void) { return 1000; }
+int m3_abi_version(void) { return 1001; }
 
 const char *m3_status_string(int status) {
     switch (status) {

@@ -31,10 +31,18 @@ constexpr int kLdsBytes = 2 * kStageBytes;               // 64 KiB
 template <int MODE /*0 dense, 1 conv3x3*/, int EPI>
 __global__ void __launch_bounds__(kThreads)
 k_gemm(const GemmArgs gin) {
-    const GemmArgs g = select_group<EPI>(gin, blockIdx.y);
+    GemmArgs g = select_group<EPI>(gin, blockIdx.y);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;               // wave position in the 2x2 grid (M, N)
+    // split-K: this workgroup multiplies K-tiles [kt0, kt0 + nk) into its own fp32 partial plane
+    int kt0 = 0, nk = g.K / BK;
+    if (EPI == EPI_F32 && g.splits > 1) {
+        const int all = nk, s = blockIdx.z;
+        kt0 = (int)((long long)all * s / g.splits);
+        nk = (int)((long long)all * (s + 1) / g.splits) - kt0;
+        g.C = reinterpret_cast<float *>(g.C) + (size_t)s * g.M * g.ldc;
+    }
 
     // XCD-aware tile order: consecutive tiles of one M-panel land on one XCD (shared A panel in L2)
     const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
@@ -67,9 +75,8 @@ k_gemm(const GemmArgs gin) {
             a_img[i] = g.A + (size_t)b * g.H * g.Wd * g.Cin + sch * 8;
         }
     }
-    const int nk = g.K / BK;
-
     auto stage = [&](int kt, int buf) {
+        kt += kt0;
         unsigned char *base = lds + buf * kStageBytes;
         int ky = 0, kx = 0, c0 = 0;
         if (MODE == 1) {
@@ -141,7 +148,7 @@ k_gemm(const GemmArgs gin) {
 template <int MODE>
 int launch(const GemmArgs &a, int epi, hipStream_t st) {
     const int tiles = m3_cdiv(a.M, BM) * m3_cdiv(a.N, BN);
-    dim3 grid(tiles, a.groups > 1 ? a.groups : 1), blk(kThreads);
+    dim3 grid(tiles, a.groups > 1 ? a.groups : 1, a.splits > 1 ? a.splits : 1), blk(kThreads);
 #define M3_L(E) case E: hipLaunchKernelGGL((k_gemm<MODE, E>), grid, blk, kLdsBytes, st, a); break
     switch (epi) {
         M3_L(EPI_BF16); M3_L(EPI_BF16_GELU); M3_L(EPI_F32); M3_L(EPI_F32_ACCUM); M3_L(EPI_BF16_RELU); M3_L(EPI_BF16_ADD); M3_L(EPI_BF16_ROPE);
@@ -162,6 +169,57 @@ bool use_256(int M, int N, int groups = 1) {
     const long t256 = (long)m3_cdiv(M, 256) * m3_cdiv(N, 256) * groups, t128 = (long)m3_cdiv(M, 128) * m3_cdiv(N, 128) * groups;
     const double c256 = (double)((t256 + 255) / 256) * 4.0 / 1.4, c128 = (double)((t128 + 511) / 512) * 2.0;
     return c256 < c128;
+}
+
+
+// ---- split-K for problems that cannot fill the chip with output tiles (small feature maps, long K:
+// the stride-2 / 768-channel DPT convolutions have 96 tiles and 108 K-tiles).  Each split writes an
+// fp32 partial plane, a second kernel adds the planes in a FIXED order and applies the real epilogue.
+// The split count is a function of the PER-IMAGE geometry only (never of the batch size), so a pair
+// gives bitwise the same result alone, in a batch of 8 or in another rank's shard.  64 / tiles aims
+// at ~512 workgroups for the 8-image batches of the benchmark shard.
+int pick_splits(int pix_per_image, int N, int K) {
+    const long tiles = (long)m3_cdiv(pix_per_image, BM) * m3_cdiv(N, BN);
+    const int nk = K / BK;
+    if (nk < 8) return 1;
+    long s = 64 / tiles;
+    if (s > nk / 4) s = nk / 4;
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : (int)s;
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(256)
+k_splitk_finish(const GemmArgs g, const float *__restrict__ part, int S) {
+    const int nq = g.N / 4;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    const int m = (int)(q / nq), n = (int)(q - (long)m * nq) * 4;
+    if (m >= g.M) return;
+    const size_t plane = (size_t)g.M * g.N;
+    const float *p = part + (size_t)m * g.N + n;
+    float4 a = *reinterpret_cast<const float4 *>(p);
+    for (int s = 1; s < S; ++s) {
+        const float4 b = *reinterpret_cast<const float4 *>(p + s * plane);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    store_tile<EPI>(g, f32x4{a.x, a.y, a.z, a.w}, m, n);
+}
+
+template <int MODE>
+int run_split(const GemmArgs &a, int S, int epi, void *ws, hipStream_t st) {
+    GemmArgs p = a;
+    p.C = ws; p.ldc = a.N; p.bias = nullptr; p.R = nullptr; p.splits = S;
+    const int rc = launch<MODE>(p, EPI_F32, st);
+    if (rc != M3_OK) return rc;
+    const dim3 grid((unsigned)m3_cdiv((long)a.M * (a.N / 4), 256L));
+#define M3_F(E) case E: hipLaunchKernelGGL((k_splitk_finish<E>), grid, dim3(256), 0, st, a, (const float *)ws, S); break
+    switch (epi) {
+        M3_F(EPI_BF16); M3_F(EPI_BF16_GELU); M3_F(EPI_F32); M3_F(EPI_F32_ACCUM); M3_F(EPI_BF16_RELU); M3_F(EPI_BF16_ADD);
+        default: return M3_ERR_INVALID_ARG;
+    }
+#undef M3_F
+    M3_CHECK_LAUNCH("m3_gemm/splitk_finish");
+    return M3_OK;
 }
 
 }  // namespace
@@ -217,8 +275,16 @@ int m3_gemm_bf16_grouped2(const void *A, const void *W0, const void *W1, const f
     return launch<0>(a, epilogue, (hipStream_t)stream);
 }
 
+int64_t m3_conv3x3_splitk_bytes(int B, int H, int Wd, int Cin, int Cout, int stride) {
+    if (B <= 0 || H <= 0 || Wd <= 0 || Cin <= 0 || Cout <= 0 || (stride != 1 && stride != 2)) return 0;
+    const int OH = (H + 2 - 3) / stride + 1, OW = (Wd + 2 - 3) / stride + 1;
+    const int S = pick_splits(OH * OW, Cout, 9 * Cin);
+    return S > 1 ? (int64_t)S * B * OH * OW * Cout * 4 : 0;
+}
+
 int m3_conv3x3_bf16(const void *X, const void *W, const float *bias, void *Y, const void *R, const void *zero16,
-                    int B, int H, int Wd, int Cin, int Cout, int stride, int epilogue, void *stream) {
+                    int B, int H, int Wd, int Cin, int Cout, int stride, int epilogue, void *splitk_ws,
+                    int64_t splitk_ws_bytes, void *stream) {
     M3_REQUIRE(X && W && Y && zero16 && B > 0 && H > 0 && Wd > 0 && Cin > 0 && Cout > 0);
     M3_REQUIRE(Cin % BK == 0 && Cout % 4 == 0 && (stride == 1 || stride == 2) && epilogue != EPI_BF16_ROPE);
     M3_REQUIRE(!((epilogue == EPI_F32_ACCUM || epilogue == EPI_BF16_ADD) && !R));
@@ -228,6 +294,13 @@ int m3_conv3x3_bf16(const void *X, const void *W, const float *bias, void *Y, co
     a.H = H; a.Wd = Wd; a.Cin = Cin; a.stride = stride;
     a.OH = (H + 2 - 3) / stride + 1; a.OW = (Wd + 2 - 3) / stride + 1;
     a.M = B * a.OH * a.OW; a.N = Cout; a.K = 9 * Cin; a.ldc = Cout;
+    // split-K is decided by the per-image geometry alone; a shape that wants it must be given its scratch
+    const int S = pick_splits(a.OH * a.OW, Cout, a.K);
+    if (S > 1) {
+        M3_REQUIRE(splitk_ws && (reinterpret_cast<size_t>(splitk_ws) & 15) == 0 &&
+                   splitk_ws_bytes >= (int64_t)S * a.M * a.N * 4);
+        return run_split<1>(a, S, epilogue, splitk_ws, (hipStream_t)stream);
+    }
     if (use_256(a.M, a.N)) return m3_launch_gemm256_conv(a, epilogue, (hipStream_t)stream);
     return launch<1>(a, epilogue, (hipStream_t)stream);
 }

@@ -72,6 +72,8 @@ struct GemmArgs {
     const float *bias2;
     long long a_gstride, c_gstride;   // elements of A, elements of C/R
     int groups;
+    // split-K (128x128 kernel, EPI_F32 only): blockIdx.z = split, C = fp32 partials [splits][M][ldc]
+    int splits;
 };
 
 // Per-group view of the arguments (group 1 of a 2-group launch).

@@ -100,9 +100,13 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, epi: int = EPI_BF16, st
         bias = _ffi.check(bias, torch.float32, "bias", (cout,))
     if resid is not None:
         resid = _ffi.check(resid, odt, "resid", (b, oh, ow, cout))
+    ws_bytes = int(_ffi.lib().m3_conv3x3_splitk_bytes(b, h, wd, cin, cout, stride))
+    # fp32 partial planes of the split-K path, from torch's caching allocator: stream-ordered, capture-safe
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes > 0 else None
     e0 = _prof_begin()
     _ffi.call("m3_conv3x3_bf16", _ffi.ptr(x), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(out), _ffi.ptr(resid),
-              _ffi.ptr(zero_page(x.device)), b, h, wd, cin, cout, stride, epi, _ffi.stream_ptr())
+              _ffi.ptr(zero_page(x.device)), b, h, wd, cin, cout, stride, epi, _ffi.ptr(ws), ws_bytes,
+              _ffi.stream_ptr())
     _prof_end(e0, "conv3x3", 2.0 * b * oh * ow * cout * 9 * cin)
     return out
 

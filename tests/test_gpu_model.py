@@ -44,6 +44,26 @@ def test_gemm_epilogues(dev, epi, shape):
     assert _rel(out, ref) < (2e-6 if f32 else 3e-3)            # fp32 accumulate; bf16 output rounding 2^-9
 
 
+def test_conv_splitk_is_batch_invariant(dev):
+    """A 16x16 map with K = 9*256 takes the split-K path (fp32 partial planes, fixed-order sum, epilogue in
+    the finishing kernel).  The slice count depends on the per-image geometry only, so an image gives the
+    same bits alone and inside a batch, and the result matches the fp32 reference."""
+    from mast3r_slam import _ffi
+    L = _ffi.lib()
+    assert L.m3_conv3x3_splitk_bytes(1, 16, 16, 256, 256, 1) == 9 * 256 * 256 * 4        # 4 tiles, 36 K-tiles -> 9 slices
+    assert L.m3_conv3x3_splitk_bytes(8, 16, 16, 256, 256, 1) == 8 * 9 * 256 * 256 * 4    # same slices for any batch
+    assert L.m3_conv3x3_splitk_bytes(8, 128, 128, 256, 256, 1) == 0                      # fills the chip: direct
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(3, 16, 16, 256, generator=g).bfloat16()
+    w = (torch.randn(256, 3, 3, 256, generator=g) * 0.03).bfloat16()
+    b = torch.randn(256, generator=g)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b, padding=1).permute(0, 2, 3, 1)
+    out = ops.conv3x3(x.to(dev), w.to(dev), b.to(dev), ops.EPI_F32)
+    assert _rel(out, ref) < 2e-6
+    one = ops.conv3x3(x[1:2].to(dev), w.to(dev), b.to(dev), ops.EPI_F32)
+    assert torch.equal(one[0], out[1])
+
+
 def test_gemm_layout_identity_asymmetric(dev):
     """A = I with an asymmetric W catches a transposed C write (guide: 'A=I-check with ASYMMETRIC B')."""
     eye = torch.eye(128, device=dev).bfloat16()

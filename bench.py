@@ -52,6 +52,20 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic_per_launch(prefixes):
+    """HBM bytes per launch of the dense GEMM kernels, from the committed PMC summary of this command
+    (FETCH_SIZE and WRITE_SIZE cannot be collected inside the timed run: separate rocprofv3 passes,
+    tools/prof_summary.py).  None when the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        kern = json.load(open(path))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    sel = [v for k, v in kern.items() if k.startswith(prefixes)]
+    n = sum(v["launches"] for v in sel)
+    return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / n if n else None
+
+
 def make_inputs(model_mod, synthetic, pairs, rank, dev):
     base = rank * pairs
     im1 = np.stack([synthetic.textured_image(H, W, 2 * (base + p)) for p in range(pairs)])
@@ -164,10 +178,11 @@ def main():
     torch.cuda.synchronize()
     prof, ops.PROFILE = ops.PROFILE, None
     by_kind = {}
-    for kind, flops, e0, e1 in prof:
-        d = by_kind.setdefault(kind, [0.0, 0.0, 0])
-        d[0] += flops; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1
-    g = by_kind.get("gemm", [0.0, 1.0, 1])
+    for kind, flops, e0, e1, nbytes in prof:
+        d = by_kind.setdefault(kind, [0.0, 0.0, 0, 0.0])
+        d[0] += flops; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1; d[3] += nbytes
+    g = by_kind.get("gemm", [0.0, 1.0, 1, 0.0])
+    traffic = pmc_traffic_per_launch(("k_gemm256<0", "k_gemm<0"))
     gemm_tflops = g[0] / g[1] / 1e12
     model_flops = net.flops_per_pair(H, W) * P
 
@@ -193,7 +208,10 @@ def main():
         "model_tflop_per_step": model_flops / 1e12,
         "roofline": {"bound": "mfma", "kernel": "k_gemm256 / k_gemm (bf16 MFMA GEMM, 256x256x64 ping-pong and 128x128x64 tiles)",
                      "achieved": gemm_tflops, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": gemm_tflops / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                     "frac": gemm_tflops / MFMA_BF16_PEAK_TFLOPS,
+                     "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE passes "
+                                                         "of this command, profiles/r01_pmc_traffic.json)",
+                     "algorithmic_bytes_per_launch": g[3] / max(g[2], 1),
                      "launches": g[2], "avg_launch_us": g[1] / max(g[2], 1) * 1e6,
                      "other_kernels_tflops": {k: v[0] / v[1] / 1e12 for k, v in by_kind.items() if k != "gemm"}},
     }

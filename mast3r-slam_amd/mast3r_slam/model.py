@@ -23,6 +23,8 @@ from __future__ import annotations
 import math
 from typing import Optional
 
+import os
+
 import numpy as np
 import torch
 
@@ -139,6 +141,8 @@ class Mast3rFull:
         self.host_weights = weights if weights is not None else init_random_weights(self.cfg, seed)
         self._prepare(self.host_weights)
         self._rope_cache = {}
+        self.concurrent_heads = os.environ.get("M3_CONCURRENT_HEADS", "1") != "0"
+        self._side = None
 
     @classmethod
     def from_pretrained(cls, resolution: int = 512, precision: str = "bf16", weights_path: Optional[str] = None,
@@ -419,8 +423,22 @@ class Mast3rFull:
     def decode_heads(self, f1, f2, npairs, grid):
         """Decoder + both heads from cached encoder tokens (bf16 [P*T,1024] each)."""
         taps = self.decode_tokens(f1.reshape(-1, self.embed_dim), f2.reshape(-1, self.embed_dim), npairs, grid)
-        return (self.head("downstream_head1", taps[0], npairs, grid),
-                self.head("downstream_head2", taps[1], npairs, grid))
+        if not self.concurrent_heads:
+            return (self.head("downstream_head1", taps[0], npairs, grid),
+                    self.head("downstream_head2", taps[1], npairs, grid))
+        # The two heads are independent chains with many small-map kernels that cannot fill 256 CUs on
+        # their own: fork head 2 onto a side stream (a parallel branch when the step is graph-captured).
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            o2 = self.head("downstream_head2", taps[1], npairs, grid)
+        o1 = self.head("downstream_head1", taps[0], npairs, grid)
+        main.wait_stream(self._side)
+        for t in o2.values():
+            t.record_stream(main)
+        return o1, o2
 
     def reconstruct(self, img1, img2):
         """model.reconstruct(img1, img2) (mast3r_utils.py:281,355): uint8 [H,W,3] x2 -> two dicts with

@@ -15,8 +15,9 @@ _F32_EPIS = (EPI_F32, EPI_F32_ACCUM)
 _zero16 = {}
 
 # When set to a list, every MFMA GEMM / implicit-GEMM conv launch appends
-# (kind, algorithmic_flops, start_event, end_event): events are recorded on the current stream,
-# i.e. the stream the kernel is launched on (bench.py's roofline measurement).
+# (kind, algorithmic_flops, start_event, end_event, algorithmic_bytes): events are recorded on the
+# current stream, i.e. the stream the kernel is launched on (bench.py's roofline measurement);
+# algorithmic bytes = operands read once + output written once (+ residual read once).
 PROFILE = None
 
 
@@ -28,11 +29,11 @@ def _prof_begin():
     return e
 
 
-def _prof_end(e0, kind, flops):
+def _prof_end(e0, kind, flops, nbytes=0.0):
     if e0 is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        PROFILE.append((kind, flops, e0, e1))
+        PROFILE.append((kind, flops, e0, e1, nbytes))
 
 
 def zero_page(dev):
@@ -66,7 +67,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, epi: int = EPI_BF16, out=N
     e0 = _prof_begin()
     _ffi.call("m3_gemm_bf16", _ffi.ptr(a), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(out), _ffi.ptr(resid),
               m, n, k, ldc, epi, _ffi.stream_ptr())
-    _prof_end(e0, "gemm", 2.0 * m * n * k)
+    esz = out.element_size()
+    _prof_end(e0, "gemm", 2.0 * m * n * k, 2.0 * (m * k + n * k) + esz * m * n * (1 if resid is None else 2))
     return out
 
 
@@ -80,7 +82,7 @@ def gemm_rope(a, w, bias, pos_yx, cos_sin, tokens_per_image: int, rope_cols: int
     e0 = _prof_begin()
     _ffi.call("m3_gemm_bf16_rope", _ffi.ptr(a), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(out), m, n, k, n,
               _ffi.ptr(pos_yx), _ffi.ptr(cos_sin), tokens_per_image, rope_cols, _ffi.stream_ptr())
-    _prof_end(e0, "gemm", 2.0 * m * n * k)
+    _prof_end(e0, "gemm", 2.0 * m * n * k, 2.0 * (m * k + n * k + m * n))
     return out
 
 
@@ -107,7 +109,8 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, epi: int = EPI_BF16, st
     _ffi.call("m3_conv3x3_bf16", _ffi.ptr(x), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(out), _ffi.ptr(resid),
               _ffi.ptr(zero_page(x.device)), b, h, wd, cin, cout, stride, epi, _ffi.ptr(ws), ws_bytes,
               _ffi.stream_ptr())
-    _prof_end(e0, "conv3x3", 2.0 * b * oh * ow * cout * 9 * cin)
+    _prof_end(e0, "conv3x3", 2.0 * b * oh * ow * cout * 9 * cin,
+              2.0 * (b * h * wd * cin + cout * 9 * cin) + out.element_size() * b * oh * ow * cout * (1 if resid is None else 2))
     return out
 
 
@@ -122,7 +125,7 @@ def attention(q, k, v, out, *, nbatch, heads, tq, tk, q_row_stride, kv_row_strid
     _ffi.call("m3_attention_bf16", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q_row_stride,
               kv_row_stride, o_row_stride, q_batch_stride, kv_batch_stride, o_batch_stride, nbatch, heads, tq, tk,
               kv_batch_shift, float(scale), _ffi.stream_ptr())
-    _prof_end(e0, "attention", 4.0 * nbatch * heads * tq * tk * 64)
+    _prof_end(e0, "attention", 4.0 * nbatch * heads * tq * tk * 64, 2.0 * nbatch * heads * 64 * (2 * tq + 2 * tk))
     return out
 
 
@@ -240,7 +243,8 @@ def gemm_grouped2(a, w0, w1, b0, b1, epi=EPI_BF16, out=None, resid=None, rope=No
     e0 = _prof_begin()
     _ffi.call("m3_gemm_bf16_grouped2", _ffi.ptr(a), _ffi.ptr(w0), _ffi.ptr(w1), _ffi.ptr(b0), _ffi.ptr(b1), _ffi.ptr(out),
               _ffi.ptr(resid), m, n, k, n, m * k, m * n, epi, _ffi.ptr(pos), _ffi.ptr(cs), tpi, rc, _ffi.stream_ptr())
-    _prof_end(e0, "gemm", 4.0 * m * n * k)
+    _prof_end(e0, "gemm", 4.0 * m * n * k,
+              2.0 * (2.0 * (m * k + n * k) + out.element_size() * m * n * (1 if resid is None else 2)))
     return out
 
 

@@ -142,7 +142,7 @@ k_gemm(const GemmArgs gin) {
     }
 
     // ---- epilogue: row-contiguous stores through a per-wave LDS scratch (gemm_common.h) --------
-    epilogue_rows<EPI, 4>(g, acc, lds + wave * 9216, m0 + wr * 64, n0 + wc * 64, lane);
+    epilogue_rows<EPI, 4, 4>(g, acc, lds + wave * 9216, m0 + wr * 64, n0 + wc * 64, lane);
 }
 
 template <int MODE>
@@ -159,18 +159,29 @@ int launch(const GemmArgs &a, int epi, hipStream_t st) {
     return M3_OK;
 }
 
-// Tile choice: the 256x256 ping-pong kernel runs one workgroup per CU, the 128x128 kernel two.
-// Estimated cost = rounds over the 256 CUs x work per tile (the 256 kernel is ~1.4x more efficient
-// per FLOP once the grid fills the chip).  M3_GEMM_TILE=128|256 forces a path (experiments).
-bool use_256(int M, int N, int groups = 1) {
+// Tile choice: the 256-row ping-pong kernel runs one workgroup per CU, the 128x128 kernel two.
+// Estimated cost = rounds over the 256 CUs x work per tile (the ping-pong kernel is ~1.4x more
+// efficient per FLOP once the grid fills the chip).  Its 192-wide variant is taken when N is a
+// multiple of 192 and the tile count then divides into full rounds better (the decoder's N = 768,
+// 1536, 2304: 256-wide tiles would leave a quarter of every round idle).  All three kernels
+// accumulate K in the same order, so the choice never changes a result bit.
+// M3_GEMM_TILE=128|192|256 forces a path (experiments).  Returns 128, 192 or 256.
+int pick_tile(int M, int N, int groups = 1, bool dense = true) {
     static const int forced = [] { const char *e = getenv("M3_GEMM_TILE"); return e ? atoi(e) : 0; }();
-    if (forced == 128) return false;
-    if (forced == 256) return true;
+    const bool can192 = dense && N % 192 == 0;
+    if (forced == 128 || forced == 256) return forced;
+    if (forced == 192) return can192 ? 192 : 256;
     const long t256 = (long)m3_cdiv(M, 256) * m3_cdiv(N, 256) * groups, t128 = (long)m3_cdiv(M, 128) * m3_cdiv(N, 128) * groups;
     const double c256 = (double)((t256 + 255) / 256) * 4.0 / 1.4, c128 = (double)((t128 + 511) / 512) * 2.0;
-    return c256 < c128;
+    double c192 = 1e30;
+    if (can192) {
+        const long t192 = (long)m3_cdiv(M, 256) * (N / 192) * groups;
+        c192 = (double)((t192 + 255) / 256) * 3.0 / 1.4 * 1.02;        // 3/4 of the work per tile; ties go to 256
+    }
+    if (c192 < c256 && c192 < c128) return 192;
+    return c256 < c128 ? 256 : 128;
 }
-
+bool use_256(int M, int N, int groups = 1) { return pick_tile(M, N, groups, false) == 256; }
 
 // ---- split-K for problems that cannot fill the chip with output tiles (small feature maps, long K:
 // the stride-2 / 768-channel DPT convolutions have 96 tiles and 108 K-tiles).  Each split writes an
@@ -224,7 +235,7 @@ int run_split(const GemmArgs &a, int S, int epi, void *ws, hipStream_t st) {
 
 }  // namespace
 
-int m3_launch_gemm256_dense(const GemmArgs &a, int epi, hipStream_t st);
+int m3_launch_gemm256_dense(const GemmArgs &a, int epi, int bn, hipStream_t st);
 int m3_launch_gemm256_conv(const GemmArgs &a, int epi, hipStream_t st);
 
 extern "C" {
@@ -237,7 +248,8 @@ int m3_gemm_bf16(const void *A, const void *W, const float *bias, void *C, const
     GemmArgs a{};
     a.A = (const bf16_t *)A; a.W = (const bf16_t *)W; a.bias = bias; a.C = C; a.R = R;
     a.M = M; a.N = N; a.K = K; a.ldc = ldc;
-    if (use_256(M, N)) return m3_launch_gemm256_dense(a, epilogue, (hipStream_t)stream);
+    const int tile = pick_tile(M, N);
+    if (tile != 128) return m3_launch_gemm256_dense(a, epilogue, tile, (hipStream_t)stream);
     return launch<0>(a, epilogue, (hipStream_t)stream);
 }
 
@@ -250,7 +262,8 @@ int m3_gemm_bf16_rope(const void *A, const void *W, const float *bias, void *C, 
     a.A = (const bf16_t *)A; a.W = (const bf16_t *)W; a.bias = bias; a.C = C;
     a.M = M; a.N = N; a.K = K; a.ldc = ldc;
     a.pos_yx = pos_yx; a.cos_sin = cos_sin; a.tokens_per_image = tokens_per_image; a.rope_cols = rope_cols;
-    if (use_256(M, N)) return m3_launch_gemm256_dense(a, EPI_BF16_ROPE, (hipStream_t)stream);
+    const int tile = pick_tile(M, N);
+    if (tile != 128) return m3_launch_gemm256_dense(a, EPI_BF16_ROPE, tile, (hipStream_t)stream);
     return launch<0>(a, EPI_BF16_ROPE, (hipStream_t)stream);
 }
 
@@ -271,7 +284,8 @@ int m3_gemm_bf16_grouped2(const void *A, const void *W0, const void *W1, const f
     a.C = C; a.R = R; a.M = M; a.N = N; a.K = K; a.ldc = ldc;
     a.a_gstride = a_gstride; a.c_gstride = c_gstride; a.groups = 2;
     a.pos_yx = pos_yx; a.cos_sin = cos_sin; a.tokens_per_image = tokens_per_image; a.rope_cols = rope_cols;
-    if (use_256(M, N, 2)) return m3_launch_gemm256_dense(a, epilogue, (hipStream_t)stream);
+    const int tile = pick_tile(M, N, 2);
+    if (tile != 128) return m3_launch_gemm256_dense(a, epilogue, tile, (hipStream_t)stream);
     return launch<0>(a, epilogue, (hipStream_t)stream);
 }
 

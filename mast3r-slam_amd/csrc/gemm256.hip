@@ -19,19 +19,25 @@ using namespace m3gemm;
 
 namespace {
 
-constexpr int BM = 256, BN = 256;
+// Two tile widths share the kernel body:
+//   BN = 256: waves 2(M) x 4(N), wave sub-tile 128 x 64  (8 x 4 MFMA tiles)
+//   BN = 192: waves 4(M) x 2(N), wave sub-tile  64 x 96  (4 x 6 MFMA tiles) - for N = 768 * k (decoder):
+//             256-wide tiles leave a quarter of the CUs idle there (e.g. 16384 x 768: 192 tiles on 256 CUs).
+constexpr int BM = 256;
 constexpr int kThreads = 512;
-constexpr int kStageBytes = (BM + BN) * BK * 2;          // 64 KiB
-constexpr int kLdsBytes = 2 * kStageBytes;               // 128 KiB
 
-template <int MODE /*0 dense, 1 conv3x3*/, int EPI>
+template <int MODE /*0 dense, 1 conv3x3*/, int EPI, int BN>
 __global__ void __launch_bounds__(kThreads, 2)
 k_gemm256(const GemmArgs gin) {
+    constexpr int WN = BN == 256 ? 4 : 2, WM = 8 / WN;      // wave grid
+    constexpr int NI = BM / WM / 16, NJ = BN / WN / 16;     // MFMA tiles per wave: 8 x 4 or 4 x 6
+    constexpr int WISS = BN / 64;                           // 64-row global_load_lds issues of the W tile
+    constexpr int kStageBytes = (BM + BN) * BK * 2;         // 64 KiB / 56 KiB
     const GemmArgs g = select_group<EPI>(gin, blockIdx.y);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int group = wave >> 2;                            // 0 = ping (first wave of each SIMD), 1 = pong
-    const int wr = wave >> 2, wc = wave & 3;                // wave sub-tile: rows wr*128, cols wc*64
+    const int wr = wave / WN, wc = wave % WN;               // wave sub-tile: rows wr*16*NI, cols wc*16*NJ
 
     const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
     const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
@@ -41,16 +47,19 @@ k_gemm256(const GemmArgs gin) {
     // staging: thread t moves 16-byte slot t of each 8 KiB issue (64 rows x 128 B); 4 issues per operand
     const int srow = tid >> 3, sch = (tid & 7) ^ ((srow >> 1) & 7);
     const bf16_t *a_src[4];
-    const bf16_t *w_src[4];
+    const bf16_t *w_src[WISS];
     int a_oy[4], a_ox[4];
     const bf16_t *a_img[4];
+#pragma unroll
+    for (int i = 0; i < WISS; ++i) {
+        int n = n0 + i * 64 + srow;
+        n = n < g.N ? n : g.N - 1;
+        w_src[i] = g.W + (size_t)n * g.K + sch * 8;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int m = m0 + i * 64 + srow;
         m = m < g.M ? m : g.M - 1;
-        int n = n0 + i * 64 + srow;
-        n = n < g.N ? n : g.N - 1;
-        w_src[i] = g.W + (size_t)n * g.K + sch * 8;
         if (MODE == 0) {
             a_src[i] = g.A + (size_t)m * g.K + sch * 8;
         } else {
@@ -88,45 +97,45 @@ k_gemm256(const GemmArgs gin) {
     auto stage_w = [&](int kt, int buf) {
         unsigned char *base = lds + buf * kStageBytes;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < WISS; ++i)
             glds16(w_src[i] + (size_t)kt * BK, base + BM * BK * 2 + i * 8192 + wave * 1024);
     };
     auto stage = [&](int kt, int buf) { stage_a(kt, buf); stage_w(kt, buf); };
 
-    f32x4 acc[8][4];
+    f32x4 acc[NI][NJ];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fch = lane >> 4;
     // per-lane LDS byte offsets of the fragments (k-step 0; k-step 1 flips chunk bit 2 = byte 64)
-    int a_off[8], w_off[4];
+    int a_off[NI], w_off[NJ];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int r = wr * 128 + i * 16 + frow;
+    for (int i = 0; i < NI; ++i) {
+        const int r = wr * (16 * NI) + i * 16 + frow;
         a_off[i] = r * 128 + ((fch ^ ((r >> 1) & 7)) << 4);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = wc * 64 + j * 16 + frow;
+    for (int j = 0; j < NJ; ++j) {
+        const int r = wc * (16 * NJ) + j * 16 + frow;
         w_off[j] = BM * BK * 2 + r * 128 + ((fch ^ ((r >> 1) & 7)) << 4);
     }
 
-    bf16x8 af[8], wf[4];
+    bf16x8 af[NI], wf[NJ];
     auto read_frags = [&](int buf, int ks) {
         const unsigned char *base = lds + buf * kStageBytes;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8 *>(base + (w_off[j] ^ (ks << 6)));
+        for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8 *>(base + (w_off[j] ^ (ks << 6)));
 #pragma unroll
-        for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(base + (a_off[i] ^ (ks << 6)));
+        for (int i = 0; i < NI; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(base + (a_off[i] ^ (ks << 6)));
     };
     auto mfma_all = [&]() {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NJ; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
@@ -183,25 +192,26 @@ k_gemm256(const GemmArgs gin) {
         phase_end();
     }
 
-    // epilogue: the operand stages are dead after the last barrier; each wave transposes its 128x64
-    // sub-tile through a private 9 KiB LDS scratch and stores full rows (gemm_common.h)
-    epilogue_rows<EPI, 8>(g, acc, lds + wave * 9216, m0 + wr * 128, n0 + wc * 64, lane);
+    // epilogue: the operand stages are dead after the last barrier; each wave transposes its sub-tile
+    // through a private LDS scratch (9 / 13 KiB) and stores full rows (gemm_common.h)
+    epilogue_rows<EPI, NI, NJ>(g, acc, lds + wave * (64 * (32 * NJ + 16)), m0 + wr * (16 * NI), n0 + wc * (16 * NJ), lane);
 }
 
-template <int MODE>
+template <int MODE, int BN>
 int launch256(const GemmArgs &a, int epi, hipStream_t st) {
+    constexpr int kLdsBytes = 2 * (BM + BN) * BK * 2;    // 128 KiB / 112 KiB
     const int tiles = m3_cdiv(a.M, BM) * m3_cdiv(a.N, BN);
     dim3 grid(tiles, a.groups > 1 ? a.groups : 1), blk(kThreads);
 #define M3_L(E)                                                                                              \
     case E: {                                                                                                \
         static bool attr_set = false;                                                                        \
         if (!attr_set) {                                                                                     \
-            M3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm256<MODE, E>),            \
+            M3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm256<MODE, E, BN>),        \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes),         \
                          "m3_gemm256/attr");                                                                 \
             attr_set = true;                                                                                 \
         }                                                                                                    \
-        hipLaunchKernelGGL((k_gemm256<MODE, E>), grid, blk, kLdsBytes, st, a);                               \
+        hipLaunchKernelGGL((k_gemm256<MODE, E, BN>), grid, blk, kLdsBytes, st, a);                           \
     } break
     switch (epi) {
         M3_L(EPI_BF16); M3_L(EPI_BF16_GELU); M3_L(EPI_F32); M3_L(EPI_F32_ACCUM); M3_L(EPI_BF16_RELU); M3_L(EPI_BF16_ADD); M3_L(EPI_BF16_ROPE);
@@ -215,5 +225,7 @@ int launch256(const GemmArgs &a, int epi, hipStream_t st) {
 }  // namespace
 
 // entry points used by gemm.hip's dispatcher
-int m3_launch_gemm256_dense(const GemmArgs &a, int epi, hipStream_t st) { return launch256<0>(a, epi, st); }
-int m3_launch_gemm256_conv(const GemmArgs &a, int epi, hipStream_t st) { return launch256<1>(a, epi, st); }
+int m3_launch_gemm256_dense(const GemmArgs &a, int epi, int bn, hipStream_t st) {
+    return bn == 192 ? launch256<0, 192>(a, epi, st) : launch256<0, 256>(a, epi, st);
+}
+int m3_launch_gemm256_conv(const GemmArgs &a, int epi, hipStream_t st) { return launch256<1, 256>(a, epi, st); }

@@ -130,25 +130,29 @@ __device__ __forceinline__ void store_tile(const GemmArgs &g, f32x4 v, int m, in
     }
 }
 
-// Fused RoPE-2D on one 16-row x 64-column accumulator strip (= one attention head of one token
-// per lane): t[0..3] are the four 16-column tiles, lane holds columns 16*j + 4*(lane>>4) + e.
-// Columns 0..31 rotate with the token's y, 32..63 with x; element i pairs with i+16, i.e. tile
-// 0 with tile 1 and tile 2 with tile 3 in the SAME lane and register.  Bias is added first.
+// Fused RoPE-2D on one 16-row x (16*NJ)-column accumulator strip that starts on a 32-column boundary:
+// t[0..NJ-1] are the 16-column tiles, lane holds columns 16*j + 4*(lane>>4) + e.  Every 32-column
+// block is half a head: even blocks rotate with the token's y, odd blocks with x; element i pairs
+// with i+16, i.e. tile 2b with tile 2b+1 in the SAME lane and register.  Bias is added first.
+template <int NJ>
 __device__ __forceinline__ void rope_strip(const GemmArgs &g, f32x4 *t, int m, int n_base, int lane) {
     if (m >= g.M) return;
     const int fi = (lane >> 4) * 4;
     if (g.bias) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
+            if (n_base + j * 16 + fi >= g.N) continue;
             const float4 b = *reinterpret_cast<const float4 *>(g.bias + n_base + j * 16 + fi);
             t[j][0] += b.x; t[j][1] += b.y; t[j][2] += b.z; t[j][3] += b.w;
         }
     }
-    if (n_base >= g.rope_cols) return;
     const int2 pos = *reinterpret_cast<const int2 *>(g.pos_yx + 2 * (m % g.tokens_per_image));
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-        const float4 *cs = reinterpret_cast<const float4 *>(g.cos_sin + ((size_t)(blk ? pos.y : pos.x) * 16 + fi) * 2);
+    for (int blk = 0; blk < NJ / 2; ++blk) {
+        const int n_blk = n_base + 32 * blk;
+        if (n_blk >= g.rope_cols) continue;
+        const int p = ((n_blk >> 5) & 1) ? pos.y : pos.x;    // pos_yx = (y, x): .x is y
+        const float4 *cs = reinterpret_cast<const float4 *>(g.cos_sin + ((size_t)p * 16 + fi) * 2);
         const float4 c01 = cs[0], c23 = cs[1];               // (cos,sin) of freq fi, fi+1 | fi+2, fi+3
         const float cc[4] = {c01.x, c01.z, c23.x, c23.z}, ss[4] = {c01.y, c01.w, c23.y, c23.w};
         f32x4 &a = t[2 * blk], &b = t[2 * blk + 1];
@@ -171,12 +175,13 @@ __device__ __forceinline__ void rope_strip(const GemmArgs &g, f32x4 *t, int m, i
 // so every wave transposes its own sub-tile through a private LDS scratch (padded rows, no
 // workgroup barrier needed) and writes/reads global memory 16 bytes per lane with 8 (bf16) or 16
 // (fp32) consecutive lanes per row: full 128-byte lines, 2x fewer instructions.
-//   wave sub-tile = (16*NI) rows x 64 columns at (m_base, n_base); wlds = >= 9216 bytes per wave.
+//   wave sub-tile = (16*NI) rows x (16*NJ) columns at (m_base, n_base); wlds = this wave's scratch,
+//   64 * (32*NJ + 16) bytes (9216 for NJ = 4, 13312 for NJ = 6).
 // Bias / activation / RoPE are applied in the accumulator layout before the transpose, residuals
 // (fp32 accumulate, bf16 add) on the row-contiguous side.  Falls back to store_tile when the
 // output is not 16-byte aligned.
-template <int EPI, int NI>
-__device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI][4], unsigned char *wlds,
+template <int EPI, int NI, int NJ = 4>
+__device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI][NJ], unsigned char *wlds,
                                               int m_base, int n_base, int lane) {
     constexpr bool F32OUT = (EPI == EPI_F32 || EPI == EPI_F32_ACCUM);
     constexpr bool F32LDS = F32OUT || EPI == EPI_BF16_ADD;        // keep one rounding for the bf16 residual add
@@ -187,38 +192,40 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
     if (!aligned) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            if (EPI == EPI_BF16_ROPE) rope_strip(g, acc[i], m_base + i * 16 + r, n_base, lane);
+            if (EPI == EPI_BF16_ROPE) rope_strip<NJ>(g, acc[i], m_base + i * 16 + r, n_base, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) store_tile<EPI>(g, acc[i][j], m_base + i * 16 + r, n_base + j * 16 + gq * 4);
+            for (int j = 0; j < NJ; ++j) store_tile<EPI>(g, acc[i][j], m_base + i * 16 + r, n_base + j * 16 + gq * 4);
         }
         return;
     }
-    float4 bj[4];
+    float4 bj[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int n = n_base + j * 16 + gq * 4;
         bj[j] = (EPI != EPI_BF16_ROPE && g.bias && n < g.N) ? *reinterpret_cast<const float4 *>(g.bias + n)
                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (F32LDS) {
-        constexpr int RS = 272;                                   // 64 fp32 + 16 bytes of padding
+        constexpr int RS = NJ * 64 + 16;                          // 16*NJ fp32 + 16 bytes of padding
+        constexpr int PR = 32;                                    // rows per pass (2 accumulator row tiles)
 #pragma unroll
         for (int pass = 0; pass < NI / 2; ++pass) {
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     const f32x4 v = acc[pass * 2 + ii][j];
                     *reinterpret_cast<float4 *>(wlds + (ii * 16 + r) * RS + (j * 16 + gq * 4) * 4) =
                         make_float4(v[0] + bj[j].x, v[1] + bj[j].y, v[2] + bj[j].z, v[3] + bj[j].w);
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (F32OUT) {
+                constexpr int CPR = NJ * 4;                       // 16-byte chunks (4 columns) per row
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int rl = it * 4 + (lane >> 4), ch = lane & 15;
+                for (int it = 0; it < PR * CPR / 64; ++it) {
+                    const int c = it * 64 + lane, rl = c / CPR, ch = c - rl * CPR;
                     float4 v = *reinterpret_cast<const float4 *>(wlds + rl * RS + ch * 16);
-                    const int m = m_base + pass * 32 + rl, n = n_base + ch * 4;
+                    const int m = m_base + pass * PR + rl, n = n_base + ch * 4;
                     if (m < g.M && n < g.N) {
                         const size_t off = (size_t)m * g.ldc + n;
                         if (EPI == EPI_F32_ACCUM) {
@@ -229,12 +236,13 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
                     }
                 }
             } else {                                              // EPI_BF16_ADD: 8 columns per lane
+                constexpr int CPR = NJ * 2;
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int rl = it * 8 + (lane >> 3), ch = lane & 7;
+                for (int it = 0; it < PR * CPR / 64; ++it) {
+                    const int c = it * 64 + lane, rl = c / CPR, ch = c - rl * CPR;
                     const float4 a = *reinterpret_cast<const float4 *>(wlds + rl * RS + ch * 32);
                     const float4 b = *reinterpret_cast<const float4 *>(wlds + rl * RS + ch * 32 + 16);
-                    const int m = m_base + pass * 32 + rl, n = n_base + ch * 8;
+                    const int m = m_base + pass * PR + rl, n = n_base + ch * 8;
                     if (m < g.M && n < g.N) {
                         const size_t off = (size_t)m * g.ldc + n;
                         const uint4 q = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16_t *>(g.R) + off);
@@ -250,15 +258,16 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
             asm volatile("" ::: "memory");
         }
     } else {
-        constexpr int RS = 144;                                   // 64 bf16 + 16 bytes of padding
+        constexpr int RS = NJ * 32 + 16;                          // 16*NJ bf16 + 16 bytes of padding
+        constexpr int PR = 64, CPR = NJ * 2;                      // rows per pass, 16-byte chunks (8 columns) per row
 #pragma unroll
         for (int pass = 0; pass < NI / 4; ++pass) {
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
                 const int i = pass * 4 + ii;
-                if (EPI == EPI_BF16_ROPE) rope_strip(g, acc[i], m_base + i * 16 + r, n_base, lane);
+                if (EPI == EPI_BF16_ROPE) rope_strip<NJ>(g, acc[i], m_base + i * 16 + r, n_base, lane);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     f32x4 v = acc[i][j];
                     v[0] += bj[j].x; v[1] += bj[j].y; v[2] += bj[j].z; v[3] += bj[j].w;
                     if (EPI == EPI_BF16_GELU) {
@@ -276,10 +285,10 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int rl = it * 8 + (lane >> 3), ch = lane & 7;
+            for (int it = 0; it < PR * CPR / 64; ++it) {
+                const int c = it * 64 + lane, rl = c / CPR, ch = c - rl * CPR;
                 const uint4 v = *reinterpret_cast<const uint4 *>(wlds + rl * RS + ch * 16);
-                const int m = m_base + pass * 64 + rl, n = n_base + ch * 8;
+                const int m = m_base + pass * PR + rl, n = n_base + ch * 8;
                 if (m < g.M && n < g.N)
                     *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(g.C) + (size_t)m * g.ldc + n) = v;
             }

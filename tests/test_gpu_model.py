@@ -44,6 +44,31 @@ def test_gemm_epilogues(dev, epi, shape):
     assert _rel(out, ref) < (2e-6 if f32 else 3e-3)            # fp32 accumulate; bf16 output rounding 2^-9
 
 
+@pytest.mark.parametrize("epi", [ops.EPI_BF16, ops.EPI_BF16_GELU, ops.EPI_F32_ACCUM, ops.EPI_BF16_ADD])
+def test_gemm_192_wide_tiles(dev, epi):
+    """16384 x 768 is dispatched to the 256x192 tile variant (256 tiles = one full round of the chip);
+    all tile shapes accumulate K in the same order, so a row computed in a small batch (128x128 tiles)
+    is bitwise the same."""
+    m, n, k = 16384, 768, 128
+    g = torch.Generator(device="cpu").manual_seed(11 + epi)
+    a = torch.randn(m, k, generator=g).bfloat16()
+    w = (torch.randn(n, k, generator=g) * 0.05).bfloat16()
+    b = torch.randn(n, generator=g)
+    ref = a.float() @ w.float().T + b
+    r = None
+    if epi == ops.EPI_BF16_GELU:
+        ref = F.gelu(ref)
+    if epi == ops.EPI_F32_ACCUM:
+        r = torch.randn(m, n, generator=g); ref = ref + r
+    if epi == ops.EPI_BF16_ADD:
+        r = torch.randn(m, n, generator=g).bfloat16(); ref = ref + r.float()
+    rd = None if r is None else r.to(dev)
+    out = ops.gemm(a.to(dev), w.to(dev), b.to(dev), epi, resid=rd)
+    assert _rel(out, ref) < (2e-6 if epi == ops.EPI_F32_ACCUM else 3e-3)
+    small = ops.gemm(a[:256].to(dev), w.to(dev), b.to(dev), epi, resid=None if rd is None else rd[:256].contiguous())
+    assert torch.equal(small, out[:256])
+
+
 def test_conv_splitk_is_batch_invariant(dev):
     """A 16x16 map with K = 9*256 takes the split-K path (fp32 partial planes, fixed-order sum, epilogue in
     the finishing kernel).  The slice count depends on the per-image geometry only, so an image gives the
@@ -219,7 +244,7 @@ def test_operator_api_contract(tiny, dev):
         mast3r_utils.load_mast3r("dunemast3r")
 
 
-@pytest.mark.parametrize("m_n_k", [(256, 192, 64), (2048, 3072, 1024)])   # 128-tile path and 256-tile path
+@pytest.mark.parametrize("m_n_k", [(256, 192, 64), (2048, 3072, 1024), (16384, 768, 64)])   # 128 / 256x256 / 256x192 tiles
 def test_gemm_with_fused_rope_epilogue(dev, m_n_k):
     m, n, k = m_n_k
     g = torch.Generator().manual_seed(m)

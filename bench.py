@@ -174,8 +174,10 @@ def main():
     # ---- untimed instrumented passes: per-stage times and per-launch MFMA kernel timing --------------
     step(stage_ms)
     ops.PROFILE = []
+    conc, net.concurrent_heads = net.concurrent_heads, False      # per-launch timing wants the launches serialised
     step()
     torch.cuda.synchronize()
+    net.concurrent_heads = conc
     prof, ops.PROFILE = ops.PROFILE, None
     by_kind = {}
     for kind, flops, e0, e1, nbytes in prof:

@@ -23,14 +23,15 @@ using namespace m3gemm;
 
 namespace {
 
-constexpr int BM = 128, BN = 128;
+constexpr int BM = 128, BN = 128;                         // default tile; T = 64 gives 64x64 tiles (latency regime)
 constexpr int kThreads = 256;
-constexpr int kStageBytes = (BM + BN) * BK * 2;          // 32 KiB
-constexpr int kLdsBytes = 2 * kStageBytes;               // 64 KiB
 
-template <int MODE /*0 dense, 1 conv3x3*/, int EPI>
+template <int MODE /*0 dense, 1 conv3x3*/, int EPI, int T = 128>
 __global__ void __launch_bounds__(kThreads)
 k_gemm(const GemmArgs gin) {
+    constexpr int BM = T, BN = T;
+    constexpr int NT = T / 32;                               // MFMA tiles per wave and direction; 32-row load issues
+    constexpr int kStageBytes = (BM + BN) * BK * 2;          // 32 KiB (16 KiB)
     GemmArgs g = select_group<EPI>(gin, blockIdx.y);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -54,12 +55,12 @@ k_gemm(const GemmArgs gin) {
     // ---- per-thread staging geometry: thread t moves 16-byte slot t of every 4 KiB issue ----
     // slot s -> LDS (row = s/8, chunk' = s%8); global chunk = chunk' ^ ((row>>1)&7)
     const int srow = tid >> 3, sch = (tid & 7) ^ ((srow >> 1) & 7);
-    const bf16_t *a_src[4];
-    const bf16_t *w_src[4];
-    int a_oy[4], a_ox[4];                                   // conv: output pixel of the row
-    const bf16_t *a_img[4];
+    const bf16_t *a_src[NT];
+    const bf16_t *w_src[NT];
+    int a_oy[NT], a_ox[NT];                                 // conv: output pixel of the row
+    const bf16_t *a_img[NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NT; ++i) {
         int m = m0 + i * 32 + srow;
         m = m < g.M ? m : g.M - 1;                          // clamp (stores are predicated)
         int n = n0 + i * 32 + srow;
@@ -85,7 +86,7 @@ k_gemm(const GemmArgs gin) {
             ky = tap / 3; kx = tap - ky * 3;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NT; ++i) {
             const void *src;
             if (MODE == 0) {
                 src = a_src[i] + (size_t)kt * BK;
@@ -97,15 +98,15 @@ k_gemm(const GemmArgs gin) {
             glds16(src, base + i * 4096 + wave * 1024);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NT; ++i)
             glds16(w_src[i] + (size_t)kt * BK, base + BM * BK * 2 + i * 4096 + wave * 1024);
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[NT][NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // fragment read offsets: lane -> row (lane&15), k-chunk (lane>>4) (+4 for the second k-step)
     const int frow = lane & 15, fch = lane >> 4;
@@ -114,42 +115,45 @@ k_gemm(const GemmArgs gin) {
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
-        // wait for tile kt only (the 8 loads of tile kt+1 may stay in flight)
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // wait for tile kt only (the 2*NT loads of tile kt+1 may stay in flight)
+        if (kt + 1 < nk) {
+            if constexpr (NT == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const unsigned char *As = lds + buf * kStageBytes;
         const unsigned char *Ws = As + BM * BK * 2;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[4], wf[4];
+            bf16x8 af[NT], wf[NT];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ra = wr * 64 + i * 16 + frow;
+            for (int i = 0; i < NT; ++i) {
+                const int ra = wr * (T / 2) + i * 16 + frow;
                 const int ca = (ks * 4 + fch) ^ ((ra >> 1) & 7);
                 af[i] = *reinterpret_cast<const bf16x8 *>(As + ra * 128 + ca * 16);
-                const int rw = wc * 64 + i * 16 + frow;
+                const int rw = wc * (T / 2) + i * 16 + frow;
                 const int cw = (ks * 4 + fch) ^ ((rw >> 1) & 7);
                 wf[i] = *reinterpret_cast<const bf16x8 *>(Ws + rw * 128 + cw * 16);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NT; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
         __builtin_amdgcn_s_barrier();      // all waves done reading `buf` before it is restaged
     }
 
     // ---- epilogue: row-contiguous stores through a per-wave LDS scratch (gemm_common.h) --------
-    epilogue_rows<EPI, 4, 4>(g, acc, lds + wave * 9216, m0 + wr * 64, n0 + wc * 64, lane);
+    epilogue_rows<EPI, NT, NT>(g, acc, lds + wave * (NT == 4 ? 9216 : 4608), m0 + wr * (T / 2), n0 + wc * (T / 2), lane);
 }
 
-template <int MODE>
+template <int MODE, int T = 128>
 int launch(const GemmArgs &a, int epi, hipStream_t st) {
-    const int tiles = m3_cdiv(a.M, BM) * m3_cdiv(a.N, BN);
+    constexpr int kLdsBytes = 2 * (2 * T) * BK * 2;      // 64 KiB (32 KiB)
+    const int tiles = m3_cdiv(a.M, T) * m3_cdiv(a.N, T);
     dim3 grid(tiles, a.groups > 1 ? a.groups : 1, a.splits > 1 ? a.splits : 1), blk(kThreads);
-#define M3_L(E) case E: hipLaunchKernelGGL((k_gemm<MODE, E>), grid, blk, kLdsBytes, st, a); break
+#define M3_L(E) case E: hipLaunchKernelGGL((k_gemm<MODE, E, T>), grid, blk, kLdsBytes, st, a); break
     switch (epi) {
         M3_L(EPI_BF16); M3_L(EPI_BF16_GELU); M3_L(EPI_F32); M3_L(EPI_F32_ACCUM); M3_L(EPI_BF16_RELU); M3_L(EPI_BF16_ADD); M3_L(EPI_BF16_ROPE);
         default: return M3_ERR_INVALID_ARG;
@@ -166,6 +170,7 @@ int launch(const GemmArgs &a, int epi, hipStream_t st) {
 // 1536, 2304: 256-wide tiles would leave a quarter of every round idle).  All three kernels
 // accumulate K in the same order, so the choice never changes a result bit.
 // M3_GEMM_TILE=128|192|256 forces a path (experiments).  Returns 128, 192 or 256.
+static const double kCost64 = [] { const char *e = getenv("M3_GEMM_COST64"); return e ? atof(e) : 3.2; }();
 int pick_tile(int M, int N, int groups = 1, bool dense = true) {
     static const int forced = [] { const char *e = getenv("M3_GEMM_TILE"); return e ? atoi(e) : 0; }();
     const bool can192 = dense && N % 192 == 0;
@@ -178,6 +183,15 @@ int pick_tile(int M, int N, int groups = 1, bool dense = true) {
         const long t192 = (long)m3_cdiv(M, 256) * (N / 192) * groups;
         c192 = (double)((t192 + 255) / 256) * 3.0 / 1.4 * 1.02;        // 3/4 of the work per tile; ties go to 256
     }
+    // 64x64 tiles (up to 4 workgroups per CU) for the latency regime: a quarter of the work per tile at
+    // a round of 1024 of them costing ~0.8 of a round of 512 128x128 tiles (measured); only when the 128-tile grid leaves most of the chip idle
+    double c64 = 1e30;
+    if (dense) {
+        const long t64 = (long)m3_cdiv(M, 64) * m3_cdiv(N, 64) * groups;
+        c64 = (double)((t64 + 1023) / 1024) * 2.0 * 0.25 * kCost64;
+    }
+    if (forced == 64) return dense ? 64 : 128;
+    if (c64 < c128 && c64 < c256 && c64 < c192) return 64;
     if (c192 < c256 && c192 < c128) return 192;
     return c256 < c128 ? 256 : 128;
 }
@@ -249,7 +263,8 @@ int m3_gemm_bf16(const void *A, const void *W, const float *bias, void *C, const
     a.A = (const bf16_t *)A; a.W = (const bf16_t *)W; a.bias = bias; a.C = C; a.R = R;
     a.M = M; a.N = N; a.K = K; a.ldc = ldc;
     const int tile = pick_tile(M, N);
-    if (tile != 128) return m3_launch_gemm256_dense(a, epilogue, tile, (hipStream_t)stream);
+    if (tile >= 192) return m3_launch_gemm256_dense(a, epilogue, tile, (hipStream_t)stream);
+    if (tile == 64) return launch<0, 64>(a, epilogue, (hipStream_t)stream);
     return launch<0>(a, epilogue, (hipStream_t)stream);
 }
 
@@ -263,7 +278,8 @@ int m3_gemm_bf16_rope(const void *A, const void *W, const float *bias, void *C, 
     a.M = M; a.N = N; a.K = K; a.ldc = ldc;
     a.pos_yx = pos_yx; a.cos_sin = cos_sin; a.tokens_per_image = tokens_per_image; a.rope_cols = rope_cols;
     const int tile = pick_tile(M, N);
-    if (tile != 128) return m3_launch_gemm256_dense(a, EPI_BF16_ROPE, tile, (hipStream_t)stream);
+    if (tile >= 192) return m3_launch_gemm256_dense(a, EPI_BF16_ROPE, tile, (hipStream_t)stream);
+    if (tile == 64) return launch<0, 64>(a, EPI_BF16_ROPE, (hipStream_t)stream);
     return launch<0>(a, EPI_BF16_ROPE, (hipStream_t)stream);
 }
 
@@ -285,7 +301,8 @@ int m3_gemm_bf16_grouped2(const void *A, const void *W0, const void *W1, const f
     a.a_gstride = a_gstride; a.c_gstride = c_gstride; a.groups = 2;
     a.pos_yx = pos_yx; a.cos_sin = cos_sin; a.tokens_per_image = tokens_per_image; a.rope_cols = rope_cols;
     const int tile = pick_tile(M, N, 2);
-    if (tile != 128) return m3_launch_gemm256_dense(a, epilogue, tile, (hipStream_t)stream);
+    if (tile >= 192) return m3_launch_gemm256_dense(a, epilogue, tile, (hipStream_t)stream);
+    if (tile == 64) return launch<0, 64>(a, epilogue, (hipStream_t)stream);
     return launch<0>(a, epilogue, (hipStream_t)stream);
 }
 

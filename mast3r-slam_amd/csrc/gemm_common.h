@@ -259,12 +259,13 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
         }
     } else {
         constexpr int RS = NJ * 32 + 16;                          // 16*NJ bf16 + 16 bytes of padding
-        constexpr int PR = 64, CPR = NJ * 2;                      // rows per pass, 16-byte chunks (8 columns) per row
+        constexpr int TP = NI < 4 ? NI : 4;                       // accumulator row tiles per pass
+        constexpr int PR = 16 * TP, CPR = NJ * 2;                 // rows per pass, 16-byte chunks (8 columns) per row
 #pragma unroll
-        for (int pass = 0; pass < NI / 4; ++pass) {
+        for (int pass = 0; pass < NI / TP; ++pass) {
 #pragma unroll
-            for (int ii = 0; ii < 4; ++ii) {
-                const int i = pass * 4 + ii;
+            for (int ii = 0; ii < TP; ++ii) {
+                const int i = pass * TP + ii;
                 if (EPI == EPI_BF16_ROPE) rope_strip<NJ>(g, acc[i], m_base + i * 16 + r, n_base, lane);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {

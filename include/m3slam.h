@@ -157,6 +157,27 @@ int m3_track_normal_eq(const float *Xf, const float *Xk, const float *Qk, const 
 /* Sim3.act over a point map (tracker.py:146 Xkk = T_CkCf.act(Xkf)): out = s R X + t. */
 int m3_sim3_act(const float *T, const float *X, float *out, int N, void *stream);
 
+/* ------------------------------------------------------------------ frame / keyframe state */
+
+/* Frame.update_pointmap (frame.py:75-133), in place on the frame's X_canon [N,3] / C [N] (the summed
+ * confidence; get_average_conf = C / N_frames stays on the host side).  If T (device, [8]) is not NULL
+ * the new points are first moved by Sim3.act(T, .) - the keyframe update of tracker.py:146-147
+ * (Xkk = T_CkCf.act(Xkf); keyframe.update_pointmap(Xkk, Ckf)) in one pass.  Modes:
+ *   REPLACE             X, C <- new                      ("first" on its first update, "recent", a winning "best_score")
+ *   INDEP_CONF          per point: take new where C_new > C           (frame.py:108-114)
+ *   WEIGHTED_POINTMAP   X <- (C X + C_new X_new) / (C + C_new), C <- C + C_new   (:115-120, the default)
+ *   WEIGHTED_SPHERICAL  the same average on (r, phi, theta)           (:121-129, geometry.py:318-351) */
+enum { M3_FUSE_REPLACE = 0, M3_FUSE_INDEP_CONF = 1, M3_FUSE_WEIGHTED_POINTMAP = 2, M3_FUSE_WEIGHTED_SPHERICAL = 3 };
+int m3_fuse_pointmap(float *X_canon, float *C, const float *X_new, const float *C_new, const float *T,
+                     int N, int mode, void *stream);
+
+/* Number of distinct values among idx[n] with valid[n] != 0 (tracker.py:153-155, mx.unique(idx[valid])),
+ * values in [0, range): bitmap (atomicOr) + popcount, an exact integer.  bitmap_ws: uint32
+ * [m3_count_unique_ws_words(range)] scratch; count_out: int32 [1] on the device. */
+int64_t m3_count_unique_ws_words(int range);
+int m3_count_unique(const int64_t *idx, const uint8_t *valid, int N, int range, uint32_t *bitmap_ws,
+                    int32_t *count_out, void *stream);
+
 /* ------------------------------------------------------------------ backend GN ("rays") */
 
 /* Per-edge normal-equation blocks of kernels.gauss_newton_rays (kernels.py:262-322; numpy

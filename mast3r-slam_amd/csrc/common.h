@@ -34,6 +34,11 @@ __device__ __forceinline__ float m3_wave_sum(float v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
 }
+__device__ __forceinline__ int m3_wave_sum(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
 __device__ __forceinline__ unsigned m3_wave_max(unsigned v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {

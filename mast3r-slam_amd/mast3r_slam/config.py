@@ -40,6 +40,8 @@ DEFAULT_CONFIG: dict[str, Any] = {
         "pixel_border": 0,
         "depth_eps": 0.0,
         "match_frac_thresh": 0.333,
+        "filtering_mode": "weighted_pointmap",      # config.py:89-90 of the reference
+        "filtering_score": "median",
     },
     "local_opt": {
         "pin": 1,

@@ -1,10 +1,9 @@
-"""Minimal host-side frame container (field layout of the reference's Frame / Keyframes,
-/root/reference/src/mlx_mast3r_slam/frame.py:27-143, :146-262).
+"""Frame / keyframe state (field layout of the reference's Frame / Keyframes,
+/root/reference/src/mlx_mast3r_slam/frame.py:27-143, :146-262), tensors resident on the ROCm device.
 
-Out of the hot path (SURVEY §8 marks frame.py as host state): only the fields the
-operator API touches are kept, as torch tensors on the ROCm device.  Pointmap fusion
-supports the reference default "weighted_pointmap" (:118-123) plus "first"/"recent";
-the fused on-device version is a §8f "next" item.
+Pointmap fusion (all six filtering modes of frame.py:75-133) runs in ONE HIP kernel, in place
+on buffers the frame owns (m3_fuse_pointmap, csrc/frame.hip), optionally with the Sim3.act of the
+tracker's keyframe update fused in.  SURVEY section 8f rank 3.
 """
 from __future__ import annotations
 
@@ -12,6 +11,12 @@ from dataclasses import dataclass
 from typing import Optional
 
 import torch
+
+from . import _ffi
+from .config import get_config
+
+FUSE_REPLACE, FUSE_INDEP_CONF, FUSE_WEIGHTED_POINTMAP, FUSE_WEIGHTED_SPHERICAL = 0, 1, 2, 3   # include/m3slam.h
+_MODES = ("first", "recent", "best_score", "indep_conf", "weighted_pointmap", "weighted_spherical")
 
 
 def identity_pose(device="cuda") -> torch.Tensor:
@@ -33,32 +38,65 @@ class Frame:
     N: int = 0
     N_updates: int = 0
     K: Optional[torch.Tensor] = None
-    filtering_mode: str = "weighted_pointmap"
+    filtering_mode: Optional[str] = None    # None: config tracking.filtering_mode (frame.py:82-83)
+    _score: Optional[float] = None
 
     def __post_init__(self):
         if self.T_WC is None:
             self.T_WC = identity_pose(self.img.device if self.img.is_cuda else "cuda")
 
-    def update_pointmap(self, X: torch.Tensor, C: torch.Tensor) -> None:
-        """frame.py:75-133 (modes first / recent / weighted_pointmap)."""
-        X = X.reshape(-1, 3)
-        C = C.reshape(-1, 1)
+    def get_score(self, C: torch.Tensor) -> float:
+        """frame.py:59-73 (one host sync, only in "best_score" mode).  median = mean of the two middle
+        values for an even count, as mx.median / np.median."""
+        if get_config()["tracking"].get("filtering_score", "median") == "median":
+            v = C.reshape(-1).float()
+            k = v.numel()
+            hi = torch.kthvalue(v, k // 2 + 1).values
+            return float(hi) if k % 2 else float((hi + torch.kthvalue(v, k // 2).values) * 0.5)
+        return float(C.float().mean())
+
+    def update_pointmap(self, X: torch.Tensor, C: torch.Tensor, T: Optional[torch.Tensor] = None) -> None:
+        """frame.py:75-133.  X [N,3] (any shape with N*3 elements), C [N,1]; `T` ([1,8] Sim3, optional)
+        moves X first (tracker.py:146-147).  The mode comes from config tracking.filtering_mode unless
+        the frame overrides it."""
+        X = _ffi.check(X.reshape(-1, 3), torch.float32, "X")
+        C = _ffi.check(C.reshape(-1, 1), torch.float32, "C", (X.shape[0], 1))
+        if T is not None:
+            T = _ffi.check(T.reshape(-1), torch.float32, "T", (8,))
+        mode = self.filtering_mode or get_config()["tracking"].get("filtering_mode", "weighted_pointmap")
+        if mode not in _MODES:
+            raise ValueError(f"unknown filtering_mode {mode!r}")
+        n = X.shape[0]
+
+        def fuse(kind):
+            _ffi.call("m3_fuse_pointmap", _ffi.ptr(self.X_canon), _ffi.ptr(self.C), _ffi.ptr(X), _ffi.ptr(C),
+                      _ffi.ptr(T), n, kind, _ffi.stream_ptr())
+
         if self.N == 0:
-            self.X_canon, self.C, self.N, self.N_updates = X, C, 1, 1
+            self.X_canon = torch.empty((n, 3), dtype=torch.float32, device=X.device)    # buffers the frame owns
+            self.C = torch.empty((n, 1), dtype=torch.float32, device=X.device)
+            fuse(FUSE_REPLACE)
+            self.N, self.N_updates = 1, 1
+            if mode == "best_score":
+                self._score = self.get_score(C)
             return
-        mode = self.filtering_mode
+        if self.X_canon.shape[0] != n:
+            raise ValueError("pointmap size changed")
         if mode == "first":
             if self.N_updates == 1:
-                self.X_canon, self.C, self.N = X, C, 1
+                fuse(FUSE_REPLACE); self.N = 1
         elif mode == "recent":
-            self.X_canon, self.C, self.N = X, C, 1
+            fuse(FUSE_REPLACE); self.N = 1
+        elif mode == "best_score":
+            s = self.get_score(C)
+            if s > (self._score or 0.0):
+                fuse(FUSE_REPLACE); self.N = 1; self._score = s
+        elif mode == "indep_conf":
+            fuse(FUSE_INDEP_CONF); self.N = 1
         elif mode == "weighted_pointmap":
-            total = self.C + C
-            self.X_canon = (self.C * self.X_canon + C * X) / total
-            self.C = total
-            self.N += 1
+            fuse(FUSE_WEIGHTED_POINTMAP); self.N += 1
         else:
-            raise NotImplementedError(f"filtering_mode {mode!r} is outside the hot-path scope")
+            fuse(FUSE_WEIGHTED_SPHERICAL); self.N += 1
         self.N_updates += 1
 
     def get_average_conf(self) -> Optional[torch.Tensor]:

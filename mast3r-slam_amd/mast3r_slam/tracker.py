@@ -172,6 +172,22 @@ def normal_equations(Xf, Xk, T_CkCf, Qk, valid, cfg=None):
     return H, out[28:35].clone(), out[35].clone()
 
 
+def count_unique(idx: torch.Tensor, valid: torch.Tensor, value_range: int) -> torch.Tensor:
+    """Number of distinct idx[n] with valid[n] (mx.unique(idx[valid]).shape[0], tracker.py:153-155) as a
+    device int32 [1]: bitmap + popcount, no sort, no host sync."""
+    idx = _ffi.check(idx.reshape(-1), torch.int64, "idx")
+    valid = valid.reshape(-1)
+    if valid.dtype == torch.bool:
+        valid = valid.view(torch.uint8)
+    valid = _ffi.check(valid, torch.uint8, "valid", (idx.numel(),))
+    words = int(_ffi.lib().m3_count_unique_ws_words(value_range))
+    ws = torch.empty(words, dtype=torch.int32, device=idx.device)
+    out = torch.empty(1, dtype=torch.int32, device=idx.device)
+    _ffi.call("m3_count_unique", _ffi.ptr(idx), _ffi.ptr(valid), idx.numel(), value_range, _ffi.ptr(ws), _ffi.ptr(out),
+              _ffi.stream_ptr())
+    return out
+
+
 def sim3_act(T, X):
     """Sim3.act (liegroups/sim3.py:222-231) over a point map: s R X + t."""
     X = _ffi.check(X.reshape(-1, 3), torch.float32, "X")
@@ -217,7 +233,8 @@ class FrameTracker:
         Xf, Qk, valid_opt, valid_kf, counts = track_gather(
             Xf_canon, frame.get_average_conf(), keyframe.get_average_conf(), Qff, Qkf, idx, vm,
             self.cfg["C_conf"], self.cfg["Q_conf"])
-        cnt = counts.cpu()                       # the one host sync of the frame (match_frac gate, :116)
+        uniq = count_unique(idx, vm, n)          # tracker.py:153-155, needs only idx / valid_match: launch it now
+        cnt = torch.cat([counts.reshape(-1)[:2], uniq]).cpu()   # the ONE host sync of the frame (match_frac gate, :116)
         if float(cnt[0]) / n < self.cfg["min_match_frac"]:
             print(f"Skipped frame {frame.frame_id}")
             return False, [], True
@@ -227,10 +244,11 @@ class FrameTracker:
         else:
             T_WCf, T_CkCf, _ = opt_pose_ray_dist_sim3(Xf, Xk_canon, frame.T_WC, keyframe.T_WC, Qk, valid_opt, self.cfg)
         frame.T_WC = T_WCf.reshape(1, 8)
-        keyframe.update_pointmap(sim3_act(T_CkCf, Xkf.reshape(n, 3)), Ckf.reshape(n, 1))
+        # Xkk = T_CkCf.act(Xkf); keyframe.update_pointmap(Xkk, Ckf)  (tracker.py:146-147) in one kernel
+        keyframe.update_pointmap(Xkf.reshape(n, 3), Ckf.reshape(n, 1), T=T_CkCf)
         self.keyframes[len(self.keyframes) - 1] = keyframe
         match_frac_k = float(cnt[1]) / n
-        unique_frac_f = torch.unique(idx[vm.bool()]).numel() / n
+        unique_frac_f = float(cnt[2]) / n
         new_kf = min(match_frac_k, unique_frac_f) < self.cfg["match_frac_thresh"]
         if new_kf:
             self.reset_idx_f2k()

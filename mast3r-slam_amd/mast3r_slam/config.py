@@ -44,13 +44,23 @@ DEFAULT_CONFIG: dict[str, Any] = {
         "filtering_score": "median",
     },
     "local_opt": {
+        "window_size": 1000000,
         "pin": 1,
         "max_iters": 10,
         "C_conf": 0.0,
         "Q_conf": 1.5,
         "sigma_ray": 0.003,
         "sigma_dist": 10.0,
+        "sigma_pixel": 1.0,
+        "sigma_depth": 10.0,
+        "pixel_border": 0,
+        "depth_eps": 0.0,
         "delta_norm": 1e-3,
+        "min_match_frac": 0.1,
+    },
+    "reloc": {
+        "min_match_frac": 0.3,
+        "strict": True,
     },
 }
 

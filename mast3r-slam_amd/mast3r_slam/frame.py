@@ -125,6 +125,20 @@ class Keyframes:
     def last_keyframe(self) -> Optional[Frame]:
         return self._frames[-1] if self._frames else None
 
+    def update_T_WCs(self, T_WCs: torch.Tensor, idx) -> None:
+        """frame.py:236-246: write optimised poses ([M,8]) back to keyframes idx ([M])."""
+        ids = idx.tolist() if isinstance(idx, torch.Tensor) else list(idx)
+        for row, k in zip(T_WCs.reshape(-1, 8), ids):
+            self._frames[int(k)].T_WC = row.reshape(1, 8).clone()
+
+    def set_intrinsics(self, K: torch.Tensor) -> None:
+        self.K = K
+        for f in self._frames:
+            f.K = K
+
+    def get_intrinsics(self) -> Optional[torch.Tensor]:
+        return getattr(self, "K", None)
+
 
 def create_frame(frame_id: int, img: torch.Tensor, T_WC: Optional[torch.Tensor] = None) -> Frame:
     """frame.py:299-343 (subset): img [3,H,W] float [0,1] or uint8 [H,W,3]."""

@@ -12,7 +12,7 @@ Differences, on purpose:
     identity matches / zeros (:556-569, :611-616).
   * cached `frame.feat` is reused; the reference re-encodes both images on every call (:345-355).
   * *_batch variants take P pairs at once (the data-parallel unit that shards across GPUs).
-Image preprocessing from files (PIL resize, :121-207) and the retrieval database (:640-795) are
+resize_img (:132-207) is the same host-side PIL preprocessing; the retrieval database (:640-795) is
 outside the hot path and not provided.
 """
 from __future__ import annotations
@@ -27,7 +27,7 @@ from .model import Mast3rFull
 from . import matching
 
 __all__ = [
-    "load_mast3r", "frame_to_numpy", "downsample", "mast3r_inference_mono", "mast3r_asymmetric_inference",
+    "load_mast3r", "resize_img", "frame_to_numpy", "downsample", "mast3r_inference_mono", "mast3r_asymmetric_inference",
     "mast3r_symmetric_inference", "mast3r_match_asymmetric", "mast3r_match_symmetric",
     "mast3r_decode_symmetric_batch", "mast3r_match_asymmetric_batch",
 ]
@@ -41,6 +41,44 @@ def load_mast3r(model_type: str = "mast3r_full", variant: str = "base", resoluti
     if model_type == "dunemast3r":
         raise ValueError("model_type 'dunemast3r' (DUNE encoder) is outside this build's scope; use 'mast3r_full'")
     raise ValueError(f"Unknown model type: {model_type}. Use 'dunemast3r' or 'mast3r_full'")
+
+
+def resize_img(img, size: int, square_ok: bool = False, return_transformation: bool = False):
+    """mast3r_utils.py:132-207 (host side, PIL - as the reference): uint8 or float[0,1] [H,W,3] ->
+    dict(img float32 [1,H',W',3] in [-1,1], true_shape int32 [[H',W']], unnormalized_img uint8 [H',W',3]).
+    size 512: long edge -> 512 (LANCZOS when shrinking, BICUBIC otherwise), centre crop to multiples of
+    16, a square result becomes 4:3 unless square_ok; size 224: short edge -> 224, centre square crop."""
+    from PIL import Image
+    a = img.cpu().numpy() if isinstance(img, torch.Tensor) else np.asarray(img)
+    if a.dtype in (np.float32, np.float64):
+        a = (a * 255).astype(np.uint8) if a.max() <= 1.0 else a.astype(np.uint8)
+    pil = Image.fromarray(a)
+    w1, h1 = pil.size
+
+    def to_long_edge(im, long_edge):
+        s = max(im.size)
+        kind = Image.LANCZOS if s > long_edge else Image.BICUBIC
+        return im.resize(tuple(int(round(x * long_edge / s)) for x in im.size), kind)
+
+    pil = to_long_edge(pil, round(size * max(w1 / h1, h1 / w1)) if size == 224 else size)
+    w, h = pil.size
+    cx, cy = w // 2, h // 2
+    if size == 224:
+        half = min(cx, cy)
+        box = (cx - half, cy - half, cx + half, cy + half)
+    else:
+        halfw, halfh = ((2 * cx) // 16) * 8, ((2 * cy) // 16) * 8
+        if not square_ok and w == h:
+            halfh = int(3 * halfw / 4)
+        box = (cx - halfw, cy - halfh, cx + halfw, cy + halfh)
+    pil = pil.crop(box)
+    raw = np.asarray(pil)
+    res = {"img": torch.from_numpy(((raw.astype(np.float32) / 255.0 - 0.5) / 0.5)[None]),
+           "true_shape": torch.tensor([[pil.size[1], pil.size[0]]], dtype=torch.int32),
+           "unnormalized_img": raw}
+    if return_transformation:
+        return res, (w1 / w, h1 / h, (w - pil.size[0]) / 2, (h - pil.size[1]) / 2)
+    return res
 
 
 def frame_to_numpy(frame) -> torch.Tensor:

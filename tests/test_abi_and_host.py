@@ -106,3 +106,51 @@ def test_local_map_follows_reference_pinning():
     uniq, local, nfree = kernels._local_map(np.array([3, 1, 1]), np.array([1, 4, 3]), 6, pin=1)
     assert uniq.tolist() == [1, 3, 4] and nfree == 2
     assert local.tolist() == [-1, -1, -1, 0, 1, -1]
+
+
+def test_factor_graph_edge_bookkeeping_cpu():
+    """global_opt.py:140-166 host logic (pure torch, runs on CPU tensors): two-way edges in the reference's
+    order, and edges re-indexed to rows of the unique-keyframe stack when keyframe ids are not 0..K-1."""
+    import torch
+    from types import SimpleNamespace
+    from mast3r_slam.global_opt import FactorGraph
+    fg = FactorGraph(SimpleNamespace(device="cpu"), frames=[])
+    n = 6
+    fg.ii, fg.jj = torch.tensor([2, 5], dtype=torch.int32), torch.tensor([5, 9], dtype=torch.int32)
+    fg.idx_ii2jj = torch.arange(2 * n).reshape(2, n)
+    fg.idx_jj2ii = 100 + torch.arange(2 * n).reshape(2, n)
+    fg.valid_match_j = torch.ones(2, n, 1, dtype=torch.bool)
+    fg.valid_match_i = torch.zeros(2, n, 1, dtype=torch.bool)
+    fg.Q_ii2jj, fg.Q_jj2ii = torch.full((2, n, 1), 2.0), torch.full((2, n, 1), 3.0)
+    uniq = fg.get_unique_kf_idx()
+    assert uniq.tolist() == [2, 5, 9]
+    ii, jj, idx, valid, Q = fg._prep_two_way_edges()
+    assert ii.tolist() == [2, 5, 5, 9] and jj.tolist() == [5, 9, 2, 5]
+    assert idx[2, 0] == 100 and valid[:2].all() and not valid[2:].any() and Q[3, 0, 0] == 3.0
+    li, lj, lidx, lvalid, lQ = fg._local_edges(uniq)
+    assert li.tolist() == [0, 1, 1, 2] and lj.tolist() == [1, 2, 0, 1]
+    assert lidx.dtype == torch.int32 and lvalid.shape == (4, n) and lQ.shape == (4, n)
+
+
+def test_resize_img_contract():
+    """mast3r_utils.py:132-207: long edge 512, crop to multiples of 16, square -> 4:3 unless square_ok;
+    224: short edge 224 + centre square crop; normalisation (x/255 - 0.5)/0.5; transformation tuple."""
+    import numpy as np
+    from mast3r_slam.mast3r_utils import resize_img
+    r = np.random.default_rng(0)
+    img = r.integers(0, 256, size=(480, 640, 3), dtype=np.uint8)
+    out, (sw, sh, cw, ch) = resize_img(img, 512, return_transformation=True)
+    assert tuple(out["img"].shape) == (1, 384, 512, 3) and out["true_shape"].tolist() == [[384, 512]]
+    assert abs(sw - 640 / 512) < 1e-9 and abs(sh - 480 / 384) < 1e-9 and (cw, ch) == (0, 0)
+    raw = out["unnormalized_img"]
+    assert raw.dtype == np.uint8 and np.allclose(out["img"][0].numpy(), (raw / 255.0 - 0.5) / 0.5, atol=1e-6)
+    sq = r.random((600, 600, 3)).astype(np.float32)                          # float [0,1] input, upsampling not needed
+    assert tuple(resize_img(sq, 512)["img"].shape) == (1, 384, 512, 3)       # square -> 4:3
+    assert tuple(resize_img(sq, 512, square_ok=True)["img"].shape) == (1, 512, 512, 3)
+    odd = r.integers(0, 256, size=(333, 500, 3), dtype=np.uint8)             # 512 x 341 after resize -> 336 rows
+    o = resize_img(odd, 512)
+    h, w = o["true_shape"][0].tolist()
+    assert (h % 16, w % 16) == (0, 0) and (h, w) == (336, 512)
+    assert tuple(resize_img(img, 224)["img"].shape) == (1, 224, 224, 3)
+    small = r.integers(0, 256, size=(120, 160, 3), dtype=np.uint8)           # enlarging path (BICUBIC)
+    assert tuple(resize_img(small, 512)["img"].shape) == (1, 384, 512, 3)

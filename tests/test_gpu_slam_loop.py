@@ -1,0 +1,90 @@
+"""End-to-end: the operator API under a SLAM loop (slam.py control flow of the reference, :124-318) with the
+backend factor graph (global_opt.py:14-270).  Weights are random, so geometry is meaningless; what is checked
+is the contract: modes, keyframe / factor bookkeeping, shapes, pinning, finiteness, and that the FactorGraph's
+device solve equals the float64 oracle on the arrays it built."""
+import numpy as np
+import pytest
+import torch
+
+from mast3r_slam import config, model as M, synthetic
+from mast3r_slam.global_opt import FactorGraph
+from mast3r_slam.mast3r_utils import mast3r_match_symmetric
+from mast3r_slam.slam import SLAM, TRACKING
+from oracle import gn_rays as OG
+
+pytestmark = pytest.mark.gpu
+H, W = 128, 256
+
+
+@pytest.fixture(scope="module")
+def net(dev):
+    return M.Mast3rFull(weights=M.init_random_weights(M.TINY_CFG, seed=1), cfg=M.TINY_CFG, device=dev)
+
+
+def _frames(n):
+    return [(0.1 * k, torch.from_numpy(synthetic.textured_image(H, W, 40 + k))) for k in range(n)]
+
+
+def test_slam_loop_default_config(net, dev):
+    """Default thresholds: random-weight matches fail the tracking gate, so frames relocalise into new
+    keyframes and every keyframe is wired to its three predecessors in the factor graph."""
+    config.set_config({})
+    s = SLAM(net)
+    out = s.run(_frames(5))
+    assert out["poses"].shape == (5, 8) and torch.isfinite(out["poses"]).all()
+    k = len(s.keyframes)
+    assert 1 <= k <= 5 and out["keyframe_indices"][0] == 0 and s.mode == TRACKING
+    assert out["points"].shape == (k * H * W, 3) and torch.isfinite(out["points"]).all()
+    fg = s.factor_graph
+    e = fg.ii.numel()
+    if k > 1:
+        assert e >= k - 1                                                   # consecutive edges are always kept
+        assert fg.idx_ii2jj.shape == (e, H * W) and fg.valid_match_j.shape == (e, H * W, 1) and fg.Q_ii2jj.shape == (e, H * W, 1)
+        assert bool((fg.ii < fg.jj).all()) and int(fg.jj.max()) == k - 1
+    ident = torch.tensor([0, 0, 0, 0, 0, 0, 1, 1.0], device=dev)
+    assert torch.equal(s.keyframes[0].T_WC.reshape(8), ident)               # pin = 1: the first keyframe never moves
+
+
+def test_slam_loop_tracking_path(net, dev):
+    """Gates opened: frames are tracked against the last keyframe (GN solve + fused keyframe update)."""
+    config.set_config({"tracking": {"min_match_frac": 0.0, "match_frac_thresh": 0.0, "Q_conf": 0.0},
+                       "matching": {"dist_thresh": 1e9}})
+    try:
+        s = SLAM(net)
+        out = s.run(_frames(4))
+        assert len(s.keyframes) == 1 and s.keyframes[0].N == 4              # three tracked frames fused into the keyframe
+        assert out["poses"].shape == (4, 8) and torch.isfinite(out["poses"]).all()
+        q = out["poses"][:, 3:7]
+        assert torch.allclose(q.norm(dim=1), torch.ones(4, device=dev), atol=1e-4)
+    finally:
+        config.set_config({})
+
+
+def test_factor_graph_solve_matches_oracle(net, dev):
+    """FactorGraph builds two-way edges from symmetric matches (B2) and solves on the device (B1); the same
+    arrays through the float64 oracle give the same poses."""
+    config.set_config({"local_opt": {"Q_conf": 0.0, "max_iters": 2}})
+    try:
+        s = SLAM(net)
+        s.run(_frames(3))
+        kfs = s.keyframes
+        if len(kfs) < 3:
+            pytest.skip("needs three keyframes")
+        for i, kf in enumerate(kfs._frames):                                # spread the poses so the solve has work to do
+            kf.T_WC = torch.tensor([[0.02 * i, -0.01 * i, 0.0, 0, 0, 0, 1, 1.0 + 0.01 * i]], device=dev)
+        fg = FactorGraph(net, kfs)
+        assert fg.add_factors([0, 1, 0], [1, 2, 2], 0.0, mast3r_match_symmetric)
+        uniq = fg.get_unique_kf_idx()
+        Xs, T, Cs = fg._get_poses_points(uniq)
+        ii, jj, idx, valid, Q = fg._local_edges(uniq)
+        assert ii.tolist() == [0, 1, 0, 1, 2, 2] and jj.tolist() == [1, 2, 2, 0, 1, 0]
+        ref = OG.gauss_newton_rays(T.cpu().numpy().astype(np.float64), Xs.cpu().numpy(), Cs[..., 0].cpu().numpy(),
+                                   ii.cpu().numpy(), jj.cpu().numpy(), idx.cpu().numpy(), valid.cpu().numpy(),
+                                   Q.cpu().numpy(), Q_thresh=0.0, max_iter=2, delta_thresh=1e-3, pin=1)
+        before = T.clone()
+        fg.solve_GN_rays()
+        after = torch.stack([k.T_WC.reshape(8) for k in kfs._frames])
+        assert torch.equal(after[0], before[0]) and not torch.equal(after[1:], before[1:])
+        assert np.abs(after.cpu().numpy() - ref).max() < 2e-3
+    finally:
+        config.set_config({})

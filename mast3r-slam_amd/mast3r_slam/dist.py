@@ -59,3 +59,28 @@ def all_gather_results(tensors, group=None):
         dist.all_gather(parts, buf, group=group)
         out = torch.stack(parts)
     return unpack(out, meta, world)
+
+
+def all_gather_rows(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
+    """Ragged all-gather along dim 0 for a shard_range() partition of `total` rows: rank r passes its
+    len(shard_range(total, r, world)) rows, every rank gets all `total` rows in order.  One collective
+    (shards are padded to the largest shard; the padding is dropped on arrival)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sizes = [len(shard_range(total, r, world)) for r in range(world)]
+    if local.shape[0] != sizes[rank]:
+        raise ValueError(f"rank {rank} owns {sizes[rank]} rows, got {local.shape[0]}")
+    cap = max(sizes) if sizes else 0
+    buf = local.new_zeros((cap,) + tuple(local.shape[1:]))
+    buf[: sizes[rank]] = local
+    gathered = all_gather_results((buf[None],), group)[0]              # [world, cap, ...]
+    return torch.cat([gathered[r, : sizes[r]] for r in range(world)])
+
+
+def sharded_edge_blocks(block_fn, num_edges: int, group=None) -> torch.Tensor:
+    """Backend GN blocks with the graph edges split over the ranks: rank r evaluates
+    block_fn(edge_range) -> [len(range), 36] float64 for its own edges only (the heavy, per-point part:
+    10.8 MB of reads per edge), then the 36-double blocks are all-gathered (288 B per edge) so that every
+    rank can assemble and solve the same dense system.  Edges are independent: no other collective."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    mine = shard_range(num_edges, rank, world)
+    return all_gather_rows(block_fn(mine), num_edges, group)

@@ -174,9 +174,13 @@ def _prep_gn(Twc, Xs, Cs, ii, jj, idx, valid, Q):
 def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray: float = 0.003,
                       sigma_dist: float = 10.0, C_thresh: float = 0.0, Q_thresh: float = 1.5,
                       max_iter: int = 10, delta_thresh: float = 1e-4, pin: int = 1, use_metal: bool = True,
-                      *, return_info: bool = False, _point_mode: int = 0, _calib=None):
+                      *, return_info: bool = False, _point_mode: int = 0, _calib=None, group=None):
     """kernels.py:262-322 / gauss_newton.py:23-280.  Returns updated Twc [K,8] float32
-    (input is not modified).  sigma_dist is accepted and ignored, as in the reference."""
+    (input is not modified).  sigma_dist is accepted and ignored, as in the reference.
+    group: a torch.distributed process group -> the edges are split over its ranks (each rank evaluates
+    the per-point blocks of its own edges, 36 doubles per edge are all-gathered, every rank assembles and
+    solves; rank 0's step is broadcast so all ranks hold bit-identical poses).  Every rank passes the
+    full graph."""
     num_kf = Twc.shape[0]
     num_edges = len(ii)
     as_np = isinstance(Twc, np.ndarray)
@@ -201,7 +205,16 @@ def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray:
     ws = torch.empty(e * chunks * 36, dtype=torch.float64, device=dev)
     info = torch.zeros(4, dtype=torch.float64, device=dev)
     st = _ffi.stream_ptr()
-    if dim <= L.m3_gn_rays_max_dim():
+    sharded = group is not None
+    if sharded:
+        import torch.distributed as tdist
+        from . import dist as m3dist
+        mine = m3dist.shard_range(e, tdist.get_rank(group), tdist.get_world_size(group))
+        sl = slice(mine.start, mine.stop)
+        loc = {n: t[n][sl].contiguous() for n in ("ii", "jj", "idx", "valid", "Q")}
+        e_loc = len(mine)
+        blocks_loc = torch.empty((e_loc, 36), dtype=torch.float64, device=dev)
+    if dim <= L.m3_gn_rays_max_dim() and not sharded:
         hbuf = torch.empty(dim * dim + 2 * dim, dtype=torch.float64, device=dev)
         _ffi.call("m3_gn_rays_solve", _ffi.ptr(twc), _ffi.ptr(t["Xs"]), _ffi.ptr(t["Cs"]), _ffi.ptr(t["ii"]),
                   _ffi.ptr(t["jj"]), _ffi.ptr(t["idx"]), _ffi.ptr(t["valid"]), _ffi.ptr(t["Q"]), _ffi.ptr(local),
@@ -219,10 +232,18 @@ def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray:
         g = torch.empty(dim, dtype=torch.float64, device=dev)
         iters, last, stopped, failed = 0, 0.0, False, False
         for _ in range(max_iter):
-            _ffi.call("m3_gn_rays_blocks", _ffi.ptr(twc), _ffi.ptr(t["Xs"]), _ffi.ptr(t["Cs"]), _ffi.ptr(t["ii"]),
-                      _ffi.ptr(t["jj"]), _ffi.ptr(t["idx"]), _ffi.ptr(t["valid"]), _ffi.ptr(t["Q"]),
-                      _ffi.ptr(blocks), _ffi.ptr(ws), k, p, e, float(sigma_ray), float(C_thresh),
-                      float(Q_thresh), int(_point_mode), _calib_ptr(_calib), st)
+            if sharded:
+                if e_loc:
+                    _ffi.call("m3_gn_rays_blocks", _ffi.ptr(twc), _ffi.ptr(t["Xs"]), _ffi.ptr(t["Cs"]), _ffi.ptr(loc["ii"]),
+                              _ffi.ptr(loc["jj"]), _ffi.ptr(loc["idx"]), _ffi.ptr(loc["valid"]), _ffi.ptr(loc["Q"]),
+                              _ffi.ptr(blocks_loc), _ffi.ptr(ws), k, p, e_loc, float(sigma_ray), float(C_thresh),
+                              float(Q_thresh), int(_point_mode), _calib_ptr(_calib), st)
+                blocks = m3dist.all_gather_rows(blocks_loc, e, group).contiguous()
+            else:
+                _ffi.call("m3_gn_rays_blocks", _ffi.ptr(twc), _ffi.ptr(t["Xs"]), _ffi.ptr(t["Cs"]), _ffi.ptr(t["ii"]),
+                          _ffi.ptr(t["jj"]), _ffi.ptr(t["idx"]), _ffi.ptr(t["valid"]), _ffi.ptr(t["Q"]),
+                          _ffi.ptr(blocks), _ffi.ptr(ws), k, p, e, float(sigma_ray), float(C_thresh),
+                          float(Q_thresh), int(_point_mode), _calib_ptr(_calib), st)
             _ffi.call("m3_gn_rays_assemble", _ffi.ptr(blocks), _ffi.ptr(t["ii"]), _ffi.ptr(t["jj"]),
                       _ffi.ptr(local), _ffi.ptr(H), _ffi.ptr(g), k, e, num_free, st)
             H.diagonal().add_(1e-6)
@@ -231,6 +252,8 @@ def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray:
                 failed = stopped = True
                 break
             dx = torch.cholesky_solve((-g)[:, None], Lc)[:, 0].contiguous()
+            if sharded:
+                tdist.broadcast(dx, src=tdist.get_global_rank(group, 0) if group is not tdist.group.WORLD else 0, group=group)
             last = float(torch.linalg.norm(dx))
             if last < delta_thresh:
                 stopped = True

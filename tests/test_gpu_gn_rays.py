@@ -163,3 +163,24 @@ def test_config5_scale_blocks_and_solve(dev):
     assert np.array_equal(out[0], noisy[0])                                           # pinned keyframe
     ref = og.gauss_newton_rays(noisy, Xs, Cs, ii, jj, idx, valid, Q, max_iter=2)       # float64 oracle, same graph
     assert np.isfinite(out).all() and np.abs(out - ref).max() < 5e-4
+
+
+def test_edge_sharded_solve_single_rank_group(dev):
+    """The edge-sharded solve (config 5: blocks per rank, all-gather of 36 doubles per edge, replicated
+    assembly + solve, rank 0's step broadcast) through a ONE-rank RCCL group equals the unsharded device solve."""
+    import socket
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        args = synthetic.gn_graph(6, 2000, num_edges=11, seed=9)[:8]
+        dargs = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in args]
+        ref = kernels.gauss_newton_rays(*dargs, max_iter=3)
+        got, info = kernels.gauss_newton_rays(*dargs, max_iter=3, group=dist.group.WORLD, return_info=True)
+        assert not info["failed"] and info["iters"] >= 1
+        assert np.abs(got.cpu().numpy() - ref.cpu().numpy()).max() < 1e-5
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -63,6 +63,15 @@ int m3_conv3x3_bf16(const void *X, const void *W, const float *bias, void *Y, co
                     const void *zero16, int B, int H, int Wd, int Cin, int Cout, int stride,
                     int epilogue, void *splitk_ws, int64_t splitk_ws_bytes, void *stream);
 
+/* Tail of the DPT head in one launch (head.2 conv3x3 128->128 + ReLU, head.4 1x1 128->4, pointmap
+ * post-processing): pts [B,H,W,3] = xyz/|xyz| * expm1(|xyz|), conf [B,H,W] = 1 + exp(c) with
+ * (xyz, c) = W4 . bf16(relu(conv3x3(X, W) + bias)) + b4.  W [128,3,3,Cin], W4 [4,128] bf16; the
+ * 128-channel full-resolution map is never written.  Same numerics as m3_conv3x3_bf16(RELU) ->
+ * m3_gemm_bf16(F32) -> m3_pts_post up to fp32 summation order. */
+int m3_conv3x3_relu_head4(const void *X, const void *W, const float *bias, const void *W4, const float *b4,
+                          float *pts, float *conf, const void *zero16, int B, int H, int Wd, int Cin,
+                          void *stream);
+
 /* Fused multi-head attention, head dim 64: O = softmax(scale * Q K^T) V, bf16 in/out, fp32
  * softmax.  Q/K/V/O are addressed as base + batch*batch_stride + token*row_stride + head*64
  * (element units), so q, k, v may live interleaved in one [tokens, 3C] projection buffer.

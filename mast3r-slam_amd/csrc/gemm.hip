@@ -144,8 +144,75 @@ k_gemm(const GemmArgs gin) {
         __builtin_amdgcn_s_barrier();      // all waves done reading `buf` before it is restaged
     }
 
-    // ---- epilogue: row-contiguous stores through a per-wave LDS scratch (gemm_common.h) --------
-    epilogue_rows<EPI, NT, NT>(g, acc, lds + wave * (NT == 4 ? 9216 : 4608), m0 + wr * (T / 2), n0 + wc * (T / 2), lane);
+    if constexpr (EPI == EPI_RELU_HEAD4) {
+        // DPT head tail fused into the last 3x3 convolution (N = 128 = one tile column): h = bf16(relu(acc + b)),
+        // raw[o] = sum_n h[n] W4[o][n] + b4[o] (o < 4), then the pointmap post-processing of k_pts_post.  Saves
+        // writing and re-reading the full-resolution 128-channel map (537 MB each way for 8 pairs) and two launches.
+        static_assert(T == 128, "head fusion needs the 128-wide tile");
+        const int r = lane & 15, gq = lane >> 4;
+        float part[NT][4];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) part[i][o] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = wc * 64 + j * 16 + gq * 4;
+            const float4 b = g.bias ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float w4[4][4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const ushort4 q = *reinterpret_cast<const ushort4 *>(g.W2 + (size_t)o * g.N + n);
+                w4[o][0] = bf2f(q.x); w4[o][1] = bf2f(q.y); w4[o][2] = bf2f(q.z); w4[o][3] = bf2f(q.w);
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const f32x4 a = acc[i][j];
+                const unsigned p01 = pack_bf16(fmaxf(a[0] + b.x, 0.f), fmaxf(a[1] + b.y, 0.f));
+                const unsigned p23 = pack_bf16(fmaxf(a[2] + b.z, 0.f), fmaxf(a[3] + b.w, 0.f));
+                const float h[4] = {__uint_as_float(p01 << 16), __uint_as_float(p01 & 0xffff0000u),
+                                    __uint_as_float(p23 << 16), __uint_as_float(p23 & 0xffff0000u)};
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    part[i][o] += (h[0] * w4[o][0] + h[1] * w4[o][1]) + (h[2] * w4[o][2] + h[3] * w4[o][3]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float v = part[i][o];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                part[i][o] = v;
+            }
+        float *red = reinterpret_cast<float *>(lds);             // operand stages are dead after the last barrier
+        if (wc == 1 && gq == 0) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                *reinterpret_cast<float4 *>(red + (wr * 64 + i * 16 + r) * 4) =
+                    make_float4(part[i][0], part[i][1], part[i][2], part[i][3]);
+        }
+        __syncthreads();
+        if (wc == 0 && gq == 0) {
+            float *pts = reinterpret_cast<float *>(g.C);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int m = m0 + wr * 64 + i * 16 + r;
+                if (m >= g.M) continue;
+                const float4 q = *reinterpret_cast<const float4 *>(red + (wr * 64 + i * 16 + r) * 4);
+                const float x = part[i][0] + q.x + g.bias2[0], y = part[i][1] + q.y + g.bias2[1];
+                const float z = part[i][2] + q.z + g.bias2[2], c = part[i][3] + q.w + g.bias2[3];
+                const float d = sqrtf(x * x + y * y + z * z);
+                const float sc = expm1f(d) / fmaxf(d, 1e-8f);
+                pts[3 * (size_t)m + 0] = x * sc; pts[3 * (size_t)m + 1] = y * sc; pts[3 * (size_t)m + 2] = z * sc;
+                g.C2[m] = 1.0f + expf(c);
+            }
+        }
+    } else {
+        // ---- epilogue: row-contiguous stores through a per-wave LDS scratch (gemm_common.h) --------
+        epilogue_rows<EPI, NT, NT>(g, acc, lds + wave * (NT == 4 ? 9216 : 4608), m0 + wr * (T / 2), n0 + wc * (T / 2), lane);
+    }
 }
 
 template <int MODE, int T = 128>
@@ -154,6 +221,10 @@ int launch(const GemmArgs &a, int epi, hipStream_t st) {
     const int tiles = m3_cdiv(a.M, T) * m3_cdiv(a.N, T);
     dim3 grid(tiles, a.groups > 1 ? a.groups : 1, a.splits > 1 ? a.splits : 1), blk(kThreads);
 #define M3_L(E) case E: hipLaunchKernelGGL((k_gemm<MODE, E, T>), grid, blk, kLdsBytes, st, a); break
+    if (epi == EPI_RELU_HEAD4) {
+        if constexpr (MODE == 1 && T == 128) hipLaunchKernelGGL((k_gemm<1, EPI_RELU_HEAD4, 128>), grid, blk, kLdsBytes, st, a);
+        else return M3_ERR_INVALID_ARG;
+    } else
     switch (epi) {
         M3_L(EPI_BF16); M3_L(EPI_BF16_GELU); M3_L(EPI_F32); M3_L(EPI_F32_ACCUM); M3_L(EPI_BF16_RELU); M3_L(EPI_BF16_ADD); M3_L(EPI_BF16_ROPE);
         default: return M3_ERR_INVALID_ARG;
@@ -334,6 +405,21 @@ int m3_conv3x3_bf16(const void *X, const void *W, const float *bias, void *Y, co
     }
     if (use_256(a.M, a.N)) return m3_launch_gemm256_conv(a, epilogue, (hipStream_t)stream);
     return launch<1>(a, epilogue, (hipStream_t)stream);
+}
+
+// Last stage of the DPT head in one launch: Y = relu(conv3x3(X) + bias) (Cout = 128, never written),
+// raw = Y . W4^T + b4 (4 channels), pts = xyz / |xyz| * expm1(|xyz|), conf = 1 + exp(raw[3]).
+int m3_conv3x3_relu_head4(const void *X, const void *W, const float *bias, const void *W4, const float *b4,
+                          float *pts, float *conf, const void *zero16, int B, int H, int Wd, int Cin, void *stream) {
+    M3_REQUIRE(X && W && W4 && b4 && pts && conf && zero16 && B > 0 && H > 0 && Wd > 0 && Cin > 0 && Cin % BK == 0);
+    M3_REQUIRE((int64_t)B * H * Wd < (1ll << 31));
+    GemmArgs a{};
+    a.A = (const bf16_t *)X; a.W = (const bf16_t *)W; a.bias = bias; a.C = pts; a.C2 = conf;
+    a.W2 = (const bf16_t *)W4; a.bias2 = b4;
+    a.zero16 = (const bf16_t *)zero16;
+    a.H = H; a.Wd = Wd; a.Cin = Cin; a.stride = 1; a.OH = H; a.OW = Wd;
+    a.M = B * H * Wd; a.N = 128; a.K = 9 * Cin; a.ldc = 3;
+    return launch<1>(a, EPI_RELU_HEAD4, (hipStream_t)stream);
 }
 
 }  // extern "C"

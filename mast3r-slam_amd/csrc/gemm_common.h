@@ -74,6 +74,8 @@ struct GemmArgs {
     int groups;
     // split-K (128x128 kernel, EPI_F32 only): blockIdx.z = split, C = fp32 partials [splits][M][ldc]
     int splits;
+    // EPI_RELU_HEAD4: W2 = bf16 [4][N] projection, bias2 = its 4 biases, C = pts f32 [M,3], C2 = conf f32 [M]
+    float *C2;
 };
 
 // Per-group view of the arguments (group 1 of a 2-group launch).
@@ -92,7 +94,8 @@ __device__ __forceinline__ GemmArgs select_group(const GemmArgs &in, int grp) {
 }
 
 enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32 = 2, EPI_F32_ACCUM = 3, EPI_BF16_RELU = 4, EPI_BF16_ADD = 5,
-       EPI_BF16_ROPE = 6 };
+       EPI_BF16_ROPE = 6,
+       EPI_RELU_HEAD4 = 7 /* internal: relu -> bf16 -> 1x1 projection to 4 channels -> pointmap post-processing */ };
 
 
 // Epilogue for one 16x16 accumulator tile: the lane holds C[m][n..n+3] (operands were swapped).

@@ -114,6 +114,25 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, epi: int = EPI_BF16, st
     return out
 
 
+def conv3x3_relu_head4(x: torch.Tensor, w: torch.Tensor, bias, w4: torch.Tensor, b4: torch.Tensor):
+    """Tail of the DPT head in one launch: relu(conv3x3(x, w) + bias) [128 ch, not materialised] -> 1x1
+    projection w4 [4,128] + b4 -> (pts3d [B,H,W,3], conf [B,H,W]) f32 with the pointmap post-processing."""
+    x = _ffi.check(x, torch.bfloat16, "x")
+    b, h, wd, cin = x.shape
+    w = _ffi.check(w, torch.bfloat16, "w", (128, 3, 3, cin))
+    w4 = _ffi.check(w4, torch.bfloat16, "w4", (4, 128))
+    b4 = _ffi.check(b4, torch.float32, "b4", (4,))
+    if bias is not None:
+        bias = _ffi.check(bias, torch.float32, "bias", (128,))
+    pts = torch.empty((b, h, wd, 3), dtype=torch.float32, device=x.device)
+    conf = torch.empty((b, h, wd), dtype=torch.float32, device=x.device)
+    e0 = _prof_begin()
+    _ffi.call("m3_conv3x3_relu_head4", _ffi.ptr(x), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(w4), _ffi.ptr(b4),
+              _ffi.ptr(pts), _ffi.ptr(conf), _ffi.ptr(zero_page(x.device)), b, h, wd, cin, _ffi.stream_ptr())
+    _prof_end(e0, "conv3x3", 2.0 * b * h * wd * 128 * (9 * cin + 4), 2.0 * (b * h * wd * cin + 128 * 9 * cin) + 16.0 * b * h * wd)
+    return pts, conf
+
+
 def attention(q, k, v, out, *, nbatch, heads, tq, tk, q_row_stride, kv_row_stride, o_row_stride,
               q_batch_stride, kv_batch_stride, o_batch_stride, kv_batch_shift=0, scale=0.125):
     """Fused MHA (head dim 64).  q/k/v/out are (views into) bf16 device tensors; the strides are in

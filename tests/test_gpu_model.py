@@ -172,6 +172,29 @@ def test_rope2d_layernorm_and_elementwise(dev):
     assert torch.equal(ops.add(r.to(dev), r.to(dev)).cpu(), (r.float() * 2).bfloat16())
 
 
+def test_fused_head_tail_matches_unfused_chain(dev):
+    """conv3x3+ReLU -> 1x1 (4 ch) -> pts_post in one launch vs the three separate ops (same bf16 rounding of
+    the 128-channel map, fp32 summation order differs) and vs a plain torch fp32 reference."""
+    g = torch.Generator(device="cpu").manual_seed(21)
+    b, h, w, cin = 1, 50, 120, 64                                            # ragged: 6000 pixels (no split-K at this size)
+    x = torch.randn(b, h, w, cin, generator=g).bfloat16()
+    wc = (torch.randn(128, 3, 3, cin, generator=g) * 0.05).bfloat16()
+    bc = torch.randn(128, generator=g) * 0.1
+    w4 = (torch.randn(4, 128, generator=g) * 0.05).bfloat16()
+    b4 = torch.randn(4, generator=g) * 0.1
+    d = lambda t: t.to(dev)
+    pts, conf = ops.conv3x3_relu_head4(d(x), d(wc), d(bc), d(w4), d(b4))
+    h2 = ops.conv3x3(d(x), d(wc), d(bc), ops.EPI_BF16_RELU)
+    raw = ops.gemm(h2.view(-1, 128), d(w4), d(b4), ops.EPI_F32)
+    pts_u, conf_u = ops.pts_post(raw.view(b, h, w, 4))
+    assert _rel(pts, pts_u) < 2e-6 and _rel(conf, conf_u) < 2e-6
+    y = torch.relu(F.conv2d(x.float().permute(0, 3, 1, 2), wc.float().permute(0, 3, 1, 2), bc, padding=1)).permute(0, 2, 3, 1)
+    r = y.bfloat16().float() @ w4.float().T + b4
+    dn = r[..., :3].norm(dim=-1, keepdim=True)
+    assert _rel(pts, r[..., :3] / dn.clip(min=1e-8) * torch.expm1(dn)) < 2e-3      # bf16 rounding flips of the hidden map
+    assert _rel(conf, 1 + torch.exp(r[..., 3])) < 2e-3
+
+
 def test_heads_postprocessing(dev):
     g = torch.Generator().manual_seed(11)
     raw = torch.randn(2, 16, 16, 4, generator=g)

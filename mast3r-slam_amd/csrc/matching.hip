@@ -190,22 +190,22 @@ k_iter_proj(const float *__restrict__ rwg, const float *__restrict__ tgt, const 
     }
 }
 
-// One workgroup: reduce the per-block maxima to one value per (batch item, iteration), then find the first
-// LM iteration whose max step norm is < thresh -> number of iterations to run.
+// Early-stop limit in two small launches (one workgroup doing all B*max_iter reductions took 61 us for 8
+// maps): k_iter_reduce - one wave per (batch item, iteration) reduces the per-block maxima; k_iter_limit -
+// one wave finds the first LM iteration whose max step norm is < thresh -> number of iterations to run.
 __global__ void __launch_bounds__(kThreads)
-k_iter_limit(const uint32_t *__restrict__ stepmax, uint32_t *__restrict__ limit, int B, int max_iter, int nblk,
-             float thresh, int per_batch) {
-    extern __shared__ unsigned red[];                      // [B * max_iter]
-    const int total = B * max_iter;
-    for (int i = threadIdx.x; i < total; i += kThreads) red[i] = 0u;
-    __syncthreads();
-    for (int i = threadIdx.x >> 6; i < total; i += kThreads / 64) {        // one wave per (b, it)
-        unsigned m = 0u;
-        for (int k = threadIdx.x & 63; k < nblk; k += 64) m = max(m, stepmax[(size_t)i * nblk + k]);
-        m = m3_wave_max(m);
-        if ((threadIdx.x & 63) == 0) red[i] = m;
-    }
-    __syncthreads();
+k_iter_reduce(const uint32_t *__restrict__ stepmax, uint32_t *__restrict__ red, int total, int nblk) {
+    const int i = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (i >= total) return;
+    unsigned m = 0u;
+    for (int k = threadIdx.x & 63; k < nblk; k += 64) m = max(m, stepmax[(size_t)i * nblk + k]);
+    m = m3_wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[i] = m;
+}
+
+__global__ void __launch_bounds__(64)
+k_iter_limit(const uint32_t *__restrict__ red, uint32_t *__restrict__ limit, int B, int max_iter, float thresh,
+             int per_batch) {
     if (threadIdx.x != 0) return;
     if (per_batch) {
         for (int b = 0; b < B; ++b) {
@@ -383,7 +383,7 @@ int m3_prep_iter_proj(const float *X11, const float *X21, const int64_t *idx_ini
 
 int64_t m3_iter_proj_ws_words(int B, int N, int max_iter) {
     if (B <= 0 || N <= 0 || max_iter < 0) return 0;
-    return (int64_t)B * max_iter * m3_cdiv(N, kThreads) + B;
+    return (int64_t)B * max_iter * m3_cdiv(N, kThreads) + B + (int64_t)B * max_iter;
 }
 
 int m3_iter_proj(const float *rwg, const float *tgt, const float *p_init, float *p_out,
@@ -392,10 +392,9 @@ int m3_iter_proj(const float *rwg, const float *tgt, const float *p_init, float 
     M3_REQUIRE(rwg && tgt && p_init && p_out && valid_out && ws);
     M3_REQUIRE(B > 0 && H > 0 && W > 0 && N > 0 && max_iter >= 0 && B <= 65535);
     M3_REQUIRE((int64_t)H * W < (1ll << 31) && (stop_scope == 0 || stop_scope == 1));
-    M3_REQUIRE((int64_t)B * max_iter * 4 <= 60000);         // the limit kernel keeps B*max_iter words in LDS
     hipStream_t st = (hipStream_t)stream;
     const int nblk = m3_cdiv(N, kThreads);
-    uint32_t *stepmax = ws, *limit = ws + (size_t)B * max_iter * nblk;
+    uint32_t *stepmax = ws, *limit = ws + (size_t)B * max_iter * nblk, *red = limit + B;
     const float xhi = (float)((double)W - 1.001), yhi = (float)((double)H - 1.001);
     dim3 grid(nblk, B);
     const int tiled = (N == H * W && H % 16 == 0 && W % 16 == 0) ? 1 : 0;
@@ -403,8 +402,10 @@ int m3_iter_proj(const float *rwg, const float *tgt, const float *p_init, float 
                        stepmax, (const uint32_t *)limit, H, W, N, max_iter, lambda_init, xhi, yhi, tiled);
     M3_CHECK_LAUNCH("m3_iter_proj/pass1");
     if (max_iter > 1) {
-        hipLaunchKernelGGL(k_iter_limit, dim3(1), dim3(kThreads), sizeof(unsigned) * B * max_iter, st,
-                           (const uint32_t *)stepmax, limit, B, max_iter, nblk, convergence_thresh, stop_scope);
+        hipLaunchKernelGGL(k_iter_reduce, dim3(m3_cdiv(B * max_iter, kThreads / 64)), dim3(kThreads), 0, st,
+                           (const uint32_t *)stepmax, red, B * max_iter, nblk);
+        hipLaunchKernelGGL(k_iter_limit, dim3(1), dim3(64), 0, st, (const uint32_t *)red, limit, B, max_iter,
+                           convergence_thresh, stop_scope);
         M3_CHECK_LAUNCH("m3_iter_proj/limit");
         hipLaunchKernelGGL(k_iter_proj<false>, grid, dim3(kThreads), 0, st, rwg, tgt, p_init, p_out,
                            valid_out, stepmax, (const uint32_t *)limit, H, W, N, max_iter, lambda_init, xhi, yhi, tiled);

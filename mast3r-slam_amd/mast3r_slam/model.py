@@ -304,7 +304,11 @@ class Mast3rFull:
         D, heads = c["dec_dim"], c["dec_heads"]
         m = npairs * t
         dev = f1.device
-        fcat = torch.stack([f1, f2])                                                     # [2,M,1024]
+        if (f1.is_contiguous() and f2.is_contiguous() and f1.untyped_storage().data_ptr() == f2.untyped_storage().data_ptr()
+                and f2.data_ptr() == f1.data_ptr() + f1.numel() * f1.element_size()):
+            fcat = torch.as_strided(f1, (2, m, f1.shape[1]), (m * f1.shape[1], f1.shape[1], 1))   # adjacent halves of the encoder batch
+        else:
+            fcat = torch.stack([f1, f2])                                                 # [2,M,1024]
         x = ops.gemm_grouped2(fcat, P["decoder_embed.w"], P["decoder_embed.w"], P["decoder_embed.b"],
                               P["decoder_embed.b"], ops.EPI_F32)                         # fp32 residual streams [2,M,D]
         taps = [[f1], [f2]]

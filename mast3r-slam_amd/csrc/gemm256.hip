@@ -41,7 +41,14 @@ k_gemm256(const GemmArgs gin) {
 
     const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
     const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    // Within an XCD's contiguous id range walk the tiles in bands of 8 M-tiles, M fastest: the ~32 tiles an
+    // XCD runs at a time then form an 8 x 4 block (12 operand panels through its L2) instead of 2 x 16
+    // (18 panels) - PMC FETCH_SIZE of the 16384x4096x1024 GEMM 297 -> ~200 MB.
+    constexpr int GM = 8;
+    const int band = bid / (GM * tiles_n), first_m = band * GM;
+    const int gsz = tiles_m - first_m < GM ? tiles_m - first_m : GM;
+    const int in_band = bid - band * GM * tiles_n;
+    const int tm = first_m + in_band % gsz, tn = in_band / gsz;
     const int m0 = tm * BM, n0 = tn * BN;
 
     // staging: thread t moves 16-byte slot t of each 8 KiB issue (64 rows x 128 B); 4 issues per operand

@@ -105,16 +105,13 @@ def main():
     stage_ms = {"infer": 0.0, "match": 0.0, "gn": 0.0, "gather": 0.0}
     ev = lambda: torch.cuda.Event(enable_timing=True)
 
-    def step(timers=None):
-        marks = []
-        if timers is not None:
-            marks.append(ev()); marks[-1].record()
+    def compute(timers=None, marks=None):
+        mark = (lambda: (marks.append(ev()), marks[-1].record())) if timers is not None else (lambda: None)
+        mark()
         o1, o2 = net.reconstruct_batch(im1, im2)
-        if timers is not None:
-            marks.append(ev()); marks[-1].record()
+        mark()
         idx, valid = matching.match(o1["pts3d"], o2["pts3d"], o1["desc"], o2["desc"])
-        if timers is not None:
-            marks.append(ev()); marks[-1].record()
+        mark()
         # frame = view 1 (its own camera), keyframe = view 2; the keyframe's canonical points stand in as
         # X_ji (same shapes and data flow as FrameTracker.track, tracker.py:88-123); all P solves batched
         Xf, Qk, vo, vk, cnt = tracker.track_gather(
@@ -123,9 +120,12 @@ def main():
             tcfg["C_conf"], tcfg["Q_conf"])
         poses, T_rel, info = tracker.opt_pose_ray_dist_sim3(Xf, o2["pts3d"].reshape(P, n, 3), ident, ident, Qk, vo, tcfg,
                                                            fixed_iters=True)
-        if timers is not None:
-            marks.append(ev()); marks[-1].record()
-        out = (o1["pts3d"], o2["pts3d"], o1["conf"], o2["conf"], idx, valid, poses)
+        mark()
+        return (o1["pts3d"], o2["pts3d"], o1["conf"], o2["conf"], idx, valid, poses)
+
+    def step(timers=None):
+        marks = []
+        out = compute(timers, marks)
         if dist is not None:
             out = m3dist.all_gather_results(out)
         if timers is not None:
@@ -135,22 +135,30 @@ def main():
                 timers[k] += a.elapsed_time(b)
         return out
 
-    # Capture the whole step (~1500 launches) into a hipGraph: replay removes the host launch path,
-    # which matters for small per-GPU batches (a B=1 step is launch-bound when issued eagerly).
+    # Capture the compute part of the step (~1500 launches) into a hipGraph: replay removes the host launch
+    # path, which matters for small per-GPU batches (a B=1 step is launch-bound when issued eagerly).  The
+    # RCCL all-gather (N > 1) is issued eagerly on the graph's static result buffers after each replay.
     graph = None
-    if not args.no_graph and dist is None:
+    if not args.no_graph:
         try:
             for _ in range(2):
                 step()
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                graph_out = step()
+                graph_out = compute()
             torch.cuda.synchronize()
         except Exception as e:                                   # noqa: BLE001 - reported, never silent
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graph = None
-    run_step = (lambda: graph.replay()) if graph is not None else step
+    if graph is None:
+        run_step = step
+    elif dist is None:
+        run_step = graph.replay
+    else:
+        def run_step():
+            graph.replay()
+            return m3dist.all_gather_results(graph_out)
 
     for _ in range(args.warmup):
         run_step()
@@ -205,7 +213,7 @@ def main():
                                "two-view MASt3R ViT-L infer + iter_proj/refine match + 10-iter GN tracking"
                                + ("" if world == 1 else " + RCCL all-gather of results"),
                    "pairs_per_gpu": P, "global_pairs": world * P, "image": [H, W], "gn_iters": tcfg["max_iters"],
-                   "parallelism": f"pair-sharded x{world}", "launch": "hipGraph replay" if graph is not None else "eager"},
+                   "parallelism": f"pair-sharded x{world}", "launch": ("hipGraph replay" + ("" if dist is None else " + eager RCCL all-gather")) if graph is not None else "eager"},
         "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
         "model_tflop_per_step": model_flops / 1e12,
         "roofline": {"bound": "mfma", "kernel": "k_gemm256 / k_gemm (bf16 MFMA GEMM, 256x256x64 ping-pong and 128x128x64 tiles)",

@@ -458,6 +458,11 @@ class Mast3rFull:
             return dict(pts3d=o["pts3d"][0], conf=o["conf"][0][..., None], desc=o["desc"][0], desc_conf=o["desc_conf"][0])
         return one(o1), one(o2)
 
+    def graphed(self, npairs: int, h: int, w: int) -> "GraphedReconstruct":
+        """reconstruct_batch for a fixed (npairs, h, w) captured once into a hipGraph and replayed per call:
+        the ~700 kernel launches of a pair cost more host time than GPU time at batch 1."""
+        return GraphedReconstruct(self, npairs, h, w)
+
     def flops_per_pair(self, h: int = 512, w: int = 512) -> float:
         """Algorithmic FLOPs (2*MAC) of one reconstruct() call, from this model's own layer table."""
         c = self.cfg
@@ -479,3 +484,34 @@ class Mast3rFull:
                + sum(4 * conv(px[i], F_, F_, 3) + conv(px[i] * 4, F_, F_, 1) for i in (2, 1, 0))
                + conv(px[0] * 4, F_, F_ // 2, 3) + conv(px[0] * 16, F_ // 2, c["last_dim"], 3) + conv(px[0] * 16, c["last_dim"], 4, 1))
         return 2.0 * (enc + dec + feat + dpt)
+
+
+class GraphedReconstruct:
+    """hipGraph replay of Mast3rFull.reconstruct_batch for one input shape.
+
+    __call__(imgs1, imgs2) copies the uint8 images into the graph's static input buffers, replays, and
+    returns the two output dicts.  The outputs are the graph's STATIC buffers: they are overwritten by the
+    next call, so consume (or clone) them before calling again.  Stream-ordered on the current stream."""
+
+    def __init__(self, net: Mast3rFull, npairs: int, h: int, w: int) -> None:
+        if h % 16 or w % 16 or ((h // 16) * (w // 16)) % 128:
+            raise ValueError("H, W must be multiples of 16 with a token count that is a multiple of 128")
+        self.net = net
+        self.shape = (npairs, h, w, 3)
+        self._in1 = torch.zeros(self.shape, dtype=torch.uint8, device=net.device)
+        self._in2 = torch.zeros(self.shape, dtype=torch.uint8, device=net.device)
+        for _ in range(2):                                   # warm up (lazy attribute setup, allocator pools)
+            net.reconstruct_batch(self._in1, self._in2)
+        torch.cuda.synchronize(net.device)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._out = net.reconstruct_batch(self._in1, self._in2)
+
+    def __call__(self, imgs1, imgs2):
+        imgs1, imgs2 = self.net._as_images(imgs1), self.net._as_images(imgs2)
+        if tuple(imgs1.shape) != self.shape or tuple(imgs2.shape) != self.shape:
+            raise ValueError(f"captured for images {self.shape}, got {tuple(imgs1.shape)} / {tuple(imgs2.shape)}")
+        self._in1.copy_(imgs1)
+        self._in2.copy_(imgs2)
+        self._graph.replay()
+        return self._out

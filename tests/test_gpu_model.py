@@ -237,6 +237,23 @@ def test_two_view_network_vs_cpu_oracle(tiny, dev):
     assert torch.equal(s1["pts3d"][0], o1["pts3d"][1]) and torch.equal(s2["desc"][0], o2["desc"][1])
 
 
+def test_graphed_reconstruct_equals_eager(tiny, dev):
+    """The hipGraph-replayed network (fixed shape, static buffers) returns the same bits as eager launches,
+    call after call with different images."""
+    cfg, w, net = tiny
+    h, wd = 128, 256
+    g = net.graphed(1, h, wd)
+    for seeds in ((0, 1), (5, 6)):
+        im1 = synthetic.textured_image(h, wd, seeds[0])[None]
+        im2 = synthetic.textured_image(h, wd, seeds[1])[None]
+        e1, e2 = net.reconstruct_batch(im1, im2)
+        o1, o2 = g(im1, im2)
+        for k in ("pts3d", "conf", "desc", "desc_conf"):
+            assert torch.equal(o1[k], e1[k]) and torch.equal(o2[k], e2[k])
+    with pytest.raises(ValueError):
+        g(np.zeros((1, 64, 256, 3), np.uint8), np.zeros((1, 64, 256, 3), np.uint8))
+
+
 def test_operator_api_contract(tiny, dev):
     """Return tuples and shapes of the reference operator API (mast3r_utils.py:255-500)."""
     cfg, w, net = tiny

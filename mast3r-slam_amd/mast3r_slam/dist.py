@@ -46,19 +46,38 @@ def unpack(buf, meta, world):
     return tuple(out)
 
 
-def all_gather_results(tensors, group=None):
+class GatherHandle:
+    """An all-gather in flight (all_gather_results(..., async_op=True)).  wait() makes the CURRENT stream
+    wait for the collective (no host sync) and returns the gathered tuple."""
+
+    def __init__(self, work, out, parts, meta, world):
+        self._work, self._out, self._parts, self._meta, self._world = work, out, parts, meta, world
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        out = self._out if self._parts is None else torch.stack(self._parts)
+        return unpack(out, self._meta, self._world)
+
+
+def all_gather_results(tensors, group=None, async_op: bool = False):
     """All ranks end up with every rank's per-pair results concatenated along dim 0 (rank order).
-    One collective for the whole tuple.  Every rank must pass identically shaped tensors."""
+    One collective for the whole tuple.  Every rank must pass identically shaped tensors.
+    async_op=True returns a GatherHandle: the collective runs on the communicator's stream while the
+    caller's stream goes on with the next batch (the packed send buffer is a private copy, so the inputs
+    may be overwritten immediately)."""
     world = dist.get_world_size(group)
     buf, meta = pack(tensors)
     if dist.get_backend(group) == "nccl":
         out = torch.empty((world, buf.numel()), dtype=torch.uint8, device=buf.device)
-        dist.all_gather_into_tensor(out.view(-1), buf, group=group)
+        work = dist.all_gather_into_tensor(out.view(-1), buf, group=group, async_op=async_op)
+        handle = GatherHandle(work if async_op else None, out, None, meta, world)
     else:                                                       # gloo (CPU tests)
         parts = [torch.empty_like(buf) for _ in range(world)]
-        dist.all_gather(parts, buf, group=group)
-        out = torch.stack(parts)
-    return unpack(out, meta, world)
+        work = dist.all_gather(parts, buf, group=group, async_op=async_op)
+        handle = GatherHandle(work if async_op else None, None, parts, meta, world)
+    return handle if async_op else handle.wait()
 
 
 def all_gather_rows(local: torch.Tensor, total: int, group=None) -> torch.Tensor:

@@ -27,7 +27,10 @@ def _worker(rank, world, port, q):
         valid = torch.rand(p, 24, 1, generator=g) > 0.5
         pose = torch.randn(p, 8, generator=g)
         out = m3dist.all_gather_results((X, idx, valid, pose))
-        ok = True
+        handle = m3dist.all_gather_results((X, idx, valid, pose), async_op=True)      # the overlapped form bench.py uses
+        X.zero_()                                                                      # inputs may be overwritten at once
+        out_async = handle.wait()
+        ok = all(torch.equal(a, b) for a, b in zip(out, out_async))
         for r in range(world):
             gr = torch.Generator().manual_seed(100 + r)
             Xr = torch.randn(p, 4, 6, 3, generator=gr); ir = torch.randint(0, 24, (p, 24), generator=gr)

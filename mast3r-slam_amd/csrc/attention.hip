@@ -49,15 +49,20 @@ struct AttnArgs {
     float scale_log2e;                                    // softmax scale * log2(e)
 };
 
+// QT = 16-row query tiles per wave: 2 -> 128 query rows per workgroup (throughput regime), 1 -> 64 rows
+// per workgroup (twice the workgroups: used when the 128-row grid would leave CUs with < 2 workgroups,
+// e.g. one pair = 2 images x 16 heads x 8 blocks = 256 workgroups on 256 CUs).
+template <int QT>
 __global__ void __launch_bounds__(kThreads, 4)
 k_attn(const AttnArgs a) {
+    constexpr int QR = QT * 64;                                 // query rows per workgroup
     __shared__ __attribute__((aligned(16))) unsigned char lds[kLds];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 15, g = lane >> 4;
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so give every XCD one contiguous
     // range of ids -- the Tq/128 query blocks of a (batch, head) then share its K/V through ONE L2
     // instead of pulling them into eight (measured 5x the compulsory HBM reads before this remap).
-    const int nq = a.Tq / QROWS, nwg = gridDim.x;
+    const int nq = a.Tq / QR, nwg = gridDim.x;
     const int per = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7;
     const int id = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + (blockIdx.x >> 3);
     const int qblk = id % nq, head = (id / nq) % a.heads, b = id / (nq * a.heads);
@@ -67,10 +72,10 @@ k_attn(const AttnArgs a) {
     const bf16_t *Vp = a.V + (size_t)kvb * a.kv_batch_stride + head * HD;
 
     // Q fragments (B operand): lane -> q row (lane&15), d = 32*ks + 8*g + j
-    bf16x8 qf[2][2];
+    bf16x8 qf[QT][2];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        const int row = qblk * QROWS + wave * 32 + qt * 16 + lq;
+    for (int qt = 0; qt < QT; ++qt) {
+        const int row = qblk * QR + wave * (16 * QT) + qt * 16 + lq;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
             qf[qt][ks] = *reinterpret_cast<const bf16x8 *>(Qp + (size_t)row * a.q_row_stride + ks * 32 + g * 8);
@@ -90,10 +95,10 @@ k_attn(const AttnArgs a) {
         }
     };
 
-    f32x4 o[2][4];
-    float m_run[2], l_run[2];
+    f32x4 o[QT][4];
+    float m_run[QT], l_run[QT];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         m_run[qt] = -INFINITY; l_run[qt] = 0.f;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -109,9 +114,9 @@ k_attn(const AttnArgs a) {
         const unsigned char *Ks = lds + buf * 2 * kTileBytes, *Vs = Ks + kTileBytes;
 
         // ---- S^T = K . Q^T : s[qt][kt] holds keys kt*16 + g*4 + r of query lq ------------------
-        f32x4 s[2][4];
+        f32x4 s[QT][4];
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -122,14 +127,14 @@ k_attn(const AttnArgs a) {
                 const int c = (ks * 4 + g) ^ ((r >> 1) & 7);
                 const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + r * 128 + c * 16);
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
+                for (int qt = 0; qt < QT; ++qt)
                     s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][kt], 0, 0, 0);
             }
 
         // ---- online softmax (row = lane-local query) -------------------------------------------
-        bf16x8 pf[2][2];
+        bf16x8 pf[QT][2];
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             float mx = s[qt][0][0];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
@@ -186,7 +191,7 @@ k_attn(const AttnArgs a) {
                         (__attribute__((address_space(3))) bf16x4 *)p);
                 }
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
+                for (int qt = 0; qt < QT; ++qt)
                     o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[qt][kk], o[qt][dt], 0, 0, 0);
             }
         __builtin_amdgcn_s_barrier();
@@ -194,12 +199,12 @@ k_attn(const AttnArgs a) {
 
     // ---- finalize: O[q][dt*16 + g*4 + r] = o / l ---------------------------------------------------
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         float l = l_run[qt];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
         const float inv = 1.0f / l;
-        const int row = qblk * QROWS + wave * 32 + qt * 16 + lq;
+        const int row = qblk * QR + wave * (16 * QT) + qt * 16 + lq;
         bf16_t *op = a.O + (size_t)b * a.o_batch_stride + (size_t)row * a.o_row_stride + head * HD;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
@@ -250,7 +255,7 @@ int m3_attention_bf16(const void *Q, const void *K, const void *V, void *O, int 
                       int o_row_stride, int64_t q_batch_stride, int64_t kv_batch_stride, int64_t o_batch_stride,
                       int nbatch, int heads, int Tq, int Tk, int kv_batch_shift, float scale, void *stream) {
     M3_REQUIRE(Q && K && V && O && nbatch > 0 && heads > 0 && Tq > 0 && Tk > 0);
-    M3_REQUIRE(Tq % QROWS == 0 && Tk % KT == 0 && (int64_t)(Tq / QROWS) * heads * nbatch < (1ll << 31));
+    M3_REQUIRE(Tq % QROWS == 0 && Tk % KT == 0 && (int64_t)(Tq / 64) * heads * nbatch < (1ll << 31));
     M3_REQUIRE(q_row_stride % 8 == 0 && kv_row_stride % 8 == 0 && o_row_stride % 4 == 0);
     M3_REQUIRE(kv_batch_shift >= 0);
     AttnArgs a;
@@ -259,7 +264,11 @@ int m3_attention_bf16(const void *Q, const void *K, const void *V, void *O, int 
     a.q_batch_stride = q_batch_stride; a.kv_batch_stride = kv_batch_stride; a.o_batch_stride = o_batch_stride;
     a.Tq = Tq; a.Tk = Tk; a.heads = heads; a.nbatch = nbatch; a.kv_batch_shift = kv_batch_shift;
     a.scale_log2e = scale * 1.4426950408889634f;
-    hipLaunchKernelGGL(k_attn, dim3((Tq / QROWS) * heads * nbatch), dim3(kThreads), 0, (hipStream_t)stream, a);
+    const int64_t wg128 = (int64_t)(Tq / QROWS) * heads * nbatch;
+    if (wg128 >= 512)
+        hipLaunchKernelGGL(k_attn<2>, dim3((unsigned)wg128), dim3(kThreads), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(k_attn<1>, dim3((unsigned)(2 * wg128)), dim3(kThreads), 0, (hipStream_t)stream, a);
     M3_CHECK_LAUNCH("m3_attention_bf16");
     return M3_OK;
 }

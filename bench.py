@@ -238,6 +238,21 @@ def main():
                      "other_kernels_tflops": {k: v[0] / v[1] / 1e12 for k, v in by_kind.items() if k != "gemm"}},
     }
 
+    if world == 1 and not args.no_b1:
+        # random weights give meaningless geometry (scattered gathers), so the matcher is
+        # ALSO timed on a smooth synthetic two-view scene of the same size (what real pointmaps look like)
+        sc = synthetic.geometric_pair(H, W, seed=0, batch=1)
+        gt = lambda k: torch.from_numpy(sc[k]).to(dev).repeat(P, 1, 1, 1)
+        gX11, gX21, gD11, gD21 = gt("X11"), gt("X21"), gt("D11"), gt("D21")
+        for _ in range(2):
+            matching.match(gX11, gX21, gD11, gD21)
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(5):
+            matching.match(gX11, gX21, gD11, gD21)
+        e1.record(); torch.cuda.synchronize()
+        result["match_ms_geometric_scene"] = round(e0.elapsed_time(e1) / 5, 3)
+
     if world == 1 and not args.no_b1 and P != 1:
         # BASELINE configs[1]: one pair per step (latency regime), same pipeline, graph-replayed
         a1, b1 = im1[:1].contiguous(), im2[:1].contiguous()

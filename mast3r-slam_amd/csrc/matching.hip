@@ -14,6 +14,7 @@
 //   refine      backends/mpsgraph/kernels.py:496-537 (numpy twin)
 //   epilogue    matching.py:436-461 ; match_simple matching.py:41-90
 #include "common.h"
+#include <limits.h>
 
 namespace {
 
@@ -284,6 +285,89 @@ k_refine(const float *__restrict__ D11, const float *__restrict__ D21, const int
     p_out[pt * 2 + 1] = by;
 }
 
+// Single-pass (dilation 1) refinement with the candidate descriptors staged in LDS.  A workgroup owns a
+// 16x16 pixel tile of view 2; on real (smooth) geometry its matches fall into a compact region of view 1,
+// so the region [min - r, max + r] (clamped to the image) is copied once into LDS and every thread reads
+// its 49 candidates from there instead of issuing 49 x 6 global float4 gathers (the L1-bound part: 9.9 GB
+// of gather traffic for 8 maps).  Same candidates, same order, same arithmetic -> same bits.  Tiles whose
+// region does not fit (scattered matches) take the global path.  LDS pixel stride D + 4 floats (112 B for
+// D = 24) keeps neighbouring pixels on different banks.
+constexpr int kRefineLdsBytes = 64 * 1024;
+
+template <int D>
+__global__ void __launch_bounds__(kThreads)
+k_refine_lds(const float *__restrict__ D11, const float *__restrict__ D21, const int32_t *__restrict__ p_in,
+             int32_t *__restrict__ p_out, int H, int W, int N, int radius) {
+    extern __shared__ float4 tile[];
+    __shared__ int bb[4];
+    constexpr int PS4 = D / 4 + 1;                          // float4 per staged pixel
+    constexpr int kMaxPix = kRefineLdsBytes / (PS4 * 16);
+    const int b = blockIdx.y;
+    const int n = point_of_thread(blockIdx.x, threadIdx.x, W, 1);      // N == H*W: every thread has a point
+    const size_t pt = (size_t)b * N + n;
+    const float *img = D11 + (size_t)b * H * W * D;
+    float q[D];
+    const float4 *q4 = reinterpret_cast<const float4 *>(D21 + pt * D);
+#pragma unroll
+    for (int k = 0; k < D / 4; ++k) {
+        const float4 v = q4[k];
+        q[4 * k] = v.x; q[4 * k + 1] = v.y; q[4 * k + 2] = v.z; q[4 * k + 3] = v.w;
+    }
+    const int cx = p_in[pt * 2 + 0], cy = p_in[pt * 2 + 1];
+    if (threadIdx.x == 0) { bb[0] = INT_MAX; bb[1] = INT_MIN; bb[2] = INT_MAX; bb[3] = INT_MIN; }
+    __syncthreads();
+    int mnx = cx, mxx = cx, mny = cy, mxy = cy;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mnx = min(mnx, __shfl_down(mnx, off, 64)); mxx = max(mxx, __shfl_down(mxx, off, 64));
+        mny = min(mny, __shfl_down(mny, off, 64)); mxy = max(mxy, __shfl_down(mxy, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&bb[0], mnx); atomicMax(&bb[1], mxx); atomicMin(&bb[2], mny); atomicMax(&bb[3], mxy);
+    }
+    __syncthreads();
+    const long long lx0 = (long long)bb[0] - radius, lx1 = (long long)bb[1] + radius;
+    const long long ly0 = (long long)bb[2] - radius, ly1 = (long long)bb[3] + radius;
+    const int x0 = (int)(lx0 < 0 ? 0 : lx0), x1 = (int)(lx1 > W - 1 ? W - 1 : lx1);
+    const int y0 = (int)(ly0 < 0 ? 0 : ly0), y1 = (int)(ly1 > H - 1 ? H - 1 : ly1);
+    const int rw = x1 - x0 + 1, rh = y1 - y0 + 1;
+    int bx = cx, by = cy;
+    if (rw > 0 && rh > 0 && (long long)rw * rh <= kMaxPix) {            // uniform over the workgroup
+        const int per_row = rw * (D / 4);
+        for (int i = threadIdx.x; i < rh * per_row; i += kThreads) {
+            const int ry = i / per_row, rem = i - ry * per_row;
+            const int rx = rem / (D / 4), k = rem - rx * (D / 4);
+            tile[(ry * rw + rx) * PS4 + k] =
+                reinterpret_cast<const float4 *>(img + ((size_t)(y0 + ry) * W + x0 + rx) * D)[k];
+        }
+        __syncthreads();
+        float best = -INFINITY;
+        for (int dy = -radius; dy <= radius; ++dy) {
+            const int ny = cy + dy;
+            if (ny < 0 || ny >= H) continue;
+            for (int dx = -radius; dx <= radius; ++dx) {
+                const int nx = cx + dx;
+                if (nx < 0 || nx >= W) continue;
+                const float4 *r4 = tile + ((ny - y0) * rw + (nx - x0)) * PS4;
+                float score = 0.0f;
+#pragma unroll
+                for (int k = 0; k < D / 4; ++k) {
+                    const float4 v = r4[k];
+                    score = score + q[4 * k + 0] * v.x;
+                    score = score + q[4 * k + 1] * v.y;
+                    score = score + q[4 * k + 2] * v.z;
+                    score = score + q[4 * k + 3] * v.w;
+                }
+                if (score > best) { best = score; bx = nx; by = ny; }
+            }
+        }
+    } else {
+        refine_pass<D>(img, q, H, W, radius, 1, cx, cy, bx, by);
+    }
+    p_out[pt * 2 + 0] = bx;
+    p_out[pt * 2 + 1] = by;
+}
+
 // generic descriptor length (any D >= 1): query re-read from global (L1-resident)
 __global__ void __launch_bounds__(kThreads)
 k_refine_generic(const float *__restrict__ D11, const float *__restrict__ D21,
@@ -425,7 +509,10 @@ int m3_refine_matches(const float *D11, const float *D21, const int32_t *p_in, i
     const bool aligned = (((uintptr_t)D11 | (uintptr_t)D21) & 15) == 0;
     const int tiled = (N == H * W && H % 16 == 0 && W % 16 == 0) ? 1 : 0;
 #define M3_REFINE(DD) hipLaunchKernelGGL(k_refine<DD>, grid, blk, 0, st, D11, D21, p_in, p_out, H, W, N, radius, dmax, chained, tiled)
-    if (aligned && D == 24) M3_REFINE(24);
+    const bool single_pass = !chained || dmax == 1;
+    if (aligned && D == 24 && tiled && single_pass && radius <= 4) {
+        hipLaunchKernelGGL(k_refine_lds<24>, grid, blk, kRefineLdsBytes, st, D11, D21, p_in, p_out, H, W, N, radius);
+    } else if (aligned && D == 24) M3_REFINE(24);
     else if (aligned && D == 16) M3_REFINE(16);
     else if (aligned && D == 32) M3_REFINE(32);
     else if (aligned && D == 64) M3_REFINE(64);

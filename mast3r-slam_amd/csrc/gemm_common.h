@@ -21,7 +21,7 @@ __device__ __forceinline__ bf16_t f2bf(float f) {        // round-to-nearest-eve
 // erf(z) = z * P(z^2) on |z| <= 3 (clamped; 1 - erf(3) = 2.2e-5), P = degree-8 minimax fit, max abs
 // error 2.5e-5 in erf, 6e-5 in gelu(x) (at |x| ~ 4.2 where one bf16 ulp is 1.6e-2) - far below the
 // 2^-9 rounding of the bf16 output.  No transcendental: ~8 VALU issues per element instead of the
-// 16 + rcp + exp of the Abramowitz-Stegun form, which cost 10 us per 256x256 tile (fc1 epilogue).
+// 16 + rcp + exp of the Abramowitz-Stegun 7.1.26 form used first (~4 us per 256x256 tile in the fc1 epilogue).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     f32x2 z = x * 0.70710678118654752f;

@@ -437,16 +437,22 @@ class Mast3rFull:
                     self.head("downstream_head2", taps[1], npairs, grid))
         # The two heads are independent chains with many small-map kernels that cannot fill 256 CUs on
         # their own: fork head 2 onto a side stream (a parallel branch when the step is graph-captured).
+        # Known limit (ROCm 7.2): ending a graph capture in which the CALLER has itself forked streams around
+        # this call crashes inside hipStreamEndCapture - set `concurrent_heads = False` for such captures.
         main = torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
+            self._side = {}
+        side = self._side.get(main.cuda_stream)            # one side stream per caller stream: independent
+        if side is None:                                    # callers (e.g. two pipelined batches) never share one
+            side = self._side[main.cuda_stream] = torch.cuda.Stream(device=self.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
             o2 = self.head("downstream_head2", taps[1], npairs, grid)
         o1 = self.head("downstream_head1", taps[0], npairs, grid)
-        main.wait_stream(self._side)
-        for t in o2.values():
-            t.record_stream(main)
+        main.wait_stream(side)
+        if not torch.cuda.is_current_stream_capturing():   # a captured graph owns its memory pool
+            for t in o2.values():
+                t.record_stream(main)
         return o1, o2
 
     def reconstruct(self, img1, img2):

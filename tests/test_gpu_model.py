@@ -195,6 +195,47 @@ def test_fused_head_tail_matches_unfused_chain(dev):
     assert _rel(conf, 1 + torch.exp(r[..., 3])) < 2e-3
 
 
+@pytest.mark.parametrize("shape", [(1024, 768, 256), (16384, 768, 128)])       # 64/128-tile path and the 256x192 path
+def test_grouped_launches_equal_separate_ops(dev, shape):
+    """The 2-group GEMM / LayerNorm launches of the decoder (one launch for both branches) give the same bits
+    as two separate single-group calls; swap=True normalises the OTHER branch's rows (norm_y)."""
+    m, n, k = shape
+    g = torch.Generator(device="cpu").manual_seed(m + n)
+    a = torch.randn(2, m, k, generator=g).bfloat16().to(dev)
+    w = [(torch.randn(n, k, generator=g) * 0.05).bfloat16().to(dev) for _ in range(2)]
+    b = [torch.randn(n, generator=g).to(dev) for _ in range(2)]
+    r = torch.randn(2, m, n, generator=g).to(dev)
+    for epi in (ops.EPI_BF16, ops.EPI_BF16_GELU, ops.EPI_F32_ACCUM):
+        res = r.clone() if epi == ops.EPI_F32_ACCUM else None
+        both = ops.gemm_grouped2(a, w[0], w[1], b[0], b[1], epi, resid=res)
+        for v in range(2):
+            one = ops.gemm(a[v], w[v], b[v], epi, resid=None if res is None else r[v].contiguous())
+            assert torch.equal(both[v], one)
+    x = torch.randn(2, 512, 768, generator=g).to(dev) * 3 + 1
+    gam = [torch.randn(768, generator=g).to(dev) for _ in range(2)]
+    bet = [torch.randn(768, generator=g).to(dev) for _ in range(2)]
+    y = ops.layernorm_grouped2(x, gam[0], bet[0], gam[1], bet[1])
+    ys = ops.layernorm_grouped2(x, gam[0], bet[0], gam[1], bet[1], swap=True)
+    for v in range(2):
+        assert torch.equal(y[v], ops.layernorm(x[v].contiguous(), gam[v], bet[v]))
+        assert torch.equal(ys[v], ops.layernorm(x[1 - v].contiguous(), gam[v], bet[v]))     # group v's params on the other rows
+        ref = F.layer_norm(x[v].cpu(), (768,), gam[v].cpu(), bet[v].cpu(), 1e-6)
+        assert _rel(y[v], ref) < 3e-3
+
+
+def test_patchify_and_cast(dev):
+    """uint8 NHWC image -> [tokens, 16*16*3] bf16 patch rows with the (x/255 - 0.5)/0.5 normalisation, in the
+    (c, dy, dx) order of a Conv2d(3, E, 16, 16) weight flattened to [E, 768]; fp32 -> bf16 cast is RNE."""
+    g = torch.Generator(device="cpu").manual_seed(2)
+    img = torch.randint(0, 256, (2, 32, 48, 3), generator=g, dtype=torch.uint8)
+    out = ops.patchify16(img.to(dev)).float().cpu()
+    x = ((img.float() / 255.0 - 0.5) / 0.5).permute(0, 3, 1, 2)                       # NCHW
+    ref = F.unfold(x, kernel_size=16, stride=16).transpose(1, 2).reshape(-1, 768)     # rows = tokens, cols = (c, dy, dx)
+    assert out.shape == ref.shape and _rel(out, ref) < 3e-3
+    v = torch.randn(1000, generator=g) * 10
+    assert torch.equal(ops.f32_to_bf16(v.to(dev)).cpu(), v.bfloat16())
+
+
 def test_heads_postprocessing(dev):
     g = torch.Generator().manual_seed(11)
     raw = torch.randn(2, 16, 16, 4, generator=g)

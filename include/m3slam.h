@@ -85,6 +85,14 @@ int m3_match_simple(const float *X11, const float *X21, const int64_t *idx_init,
 /* float [.,2] -> int32 [.,2] truncation (p.astype(int32), matching.py:410). */
 int m3_trunc_i32(const float *p, int32_t *out, int64_t count, void *stream);
 
+/* Nearest neighbour in descriptor space, the search primitive of "fast reciprocal NN" matching (named by
+ * BASELINE.json; absent from the reference tree - SURVEY 8a row K8 - so the semantics are this library's):
+ * idx_out[b][s] = argmax_n <Q[b][s], DB[b][n]> in fp32 (two fused-multiply-add chains over the even and the
+ * odd dimensions, added at the end), ties to the lowest n; score_out (may be NULL) = the maximum.  Q [B,S,D], DB [B,N,D] f32, D in {16, 24, 32},
+ * 16-byte aligned; keys_ws: uint64 [B*S] scratch. */
+int m3_nn_search(const float *Q, const float *DB, int32_t *idx_out, float *score_out, uint64_t *keys_ws,
+                 int B, int S, int N, int D, void *stream);
+
 /* ------------------------------------------------------------------ tracking */
 
 /* FrameTracker.track glue (tracker.py:88-113, _get_points_poses :177-214): for each

@@ -107,3 +107,55 @@ def match(X11, X21, D11, D21, idx_1_to_2_init=None):
     if get_config().get("matching", {}).get("use_simple", True):
         return match_simple(X11, X21, D11, D21, idx_1_to_2_init)
     return match_iterative_proj(X11, X21, D11, D21, idx_1_to_2_init)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Fast reciprocal nearest-neighbour matching (named by BASELINE.json; MASt3R, Leroy et al. 2024, sec. 3.3).
+# The reference tree has no implementation: semantics and oracle are this repo's.
+def nn_search(Q: torch.Tensor, DB: torch.Tensor, return_score: bool = False):
+    """Q [B,S,D], DB [B,N,D] f32 -> idx int32 [B,S] = argmax_n <Q[b,s], DB[b,n]> (fp32 FMA chain in k order,
+    ties to the lowest n) through m3_nn_search (brute force; a lane owns a query, database rows are scalar
+    loads)."""
+    Q = _ffi.check(Q, torch.float32, "Q")
+    DB = _ffi.check(DB, torch.float32, "DB")
+    if Q.dim() != 3 or DB.dim() != 3 or Q.shape[0] != DB.shape[0] or Q.shape[2] != DB.shape[2]:
+        raise ValueError(f"Q [B,S,D] / DB [B,N,D] expected, got {tuple(Q.shape)} / {tuple(DB.shape)}")
+    b, s, d = Q.shape
+    idx = torch.empty((b, s), dtype=torch.int32, device=Q.device)
+    score = torch.empty((b, s), dtype=torch.float32, device=Q.device) if return_score else None
+    keys = torch.empty((b, s), dtype=torch.int64, device=Q.device)
+    _ffi.call("m3_nn_search", _ffi.ptr(Q), _ffi.ptr(DB), _ffi.ptr(idx), _ffi.ptr(score), _ffi.ptr(keys), b, s, DB.shape[1],
+              d, _ffi.stream_ptr())
+    return (idx, score) if return_score else idx
+
+
+def fast_reciprocal_nn(D1: torch.Tensor, D2: torch.Tensor, subsample: int = 8, max_iter: int = 10):
+    """Reciprocal matches between two descriptor maps D1, D2 [H,W,D] (L2-normalised, f32).
+
+    Seeds = view-1 pixels on a grid of step `subsample` (offset subsample//2).  Each round maps the active
+    view-1 pixels to their nearest neighbour in view 2 and back; a seed has CONVERGED when the round
+    returns to the pixel it started from (a mutual nearest neighbour pair), otherwise it continues from
+    where it landed, for at most max_iter rounds.  Returns (idx1, idx2) int64 [M]: linear pixel indices of
+    the distinct converged pairs, sorted by idx1.  One host sync per round (the active set shrinks)."""
+    if D1.dim() != 3 or D2.dim() != 3 or D1.shape[2] != D2.shape[2]:
+        raise ValueError("D1, D2 must be [H,W,D] with the same D")
+    h1, w1, d = D1.shape
+    f1, f2 = D1.reshape(1, -1, d).contiguous(), D2.reshape(1, -1, d).contiguous()
+    dev = D1.device
+    ys = torch.arange(subsample // 2, h1, subsample, device=dev)
+    xs = torch.arange(subsample // 2, w1, subsample, device=dev)
+    xy1 = (ys[:, None] * w1 + xs[None, :]).reshape(-1)                      # active view-1 pixels
+    out1, out2 = [], []
+    for _ in range(max_iter):
+        if xy1.numel() == 0:
+            break
+        xy2 = nn_search(f1[:, xy1], f2)[0].long()                           # view 1 -> view 2
+        back = nn_search(f2[:, xy2], f1)[0].long()                          # view 2 -> view 1
+        conv = back == xy1
+        out1.append(xy1[conv]); out2.append(xy2[conv])
+        xy1 = torch.unique(back[~conv])                                     # continue from where they landed
+    if not out1:
+        e = torch.empty(0, dtype=torch.int64, device=dev)
+        return e, e
+    pairs = torch.unique(torch.stack([torch.cat(out1), torch.cat(out2)], 1), dim=0)
+    return pairs[:, 0], pairs[:, 1]

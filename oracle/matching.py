@@ -226,3 +226,42 @@ def match_iterative_proj(X11, X21, D11, D21, idx_1_to_2_init=None, *, max_iter=1
         D21f = np.asarray(D21, dtype=F32).reshape(b, h * w, -1)
         p_int = refine_matches(D11, D21f, p_int, radius, dilation_max, chained)
     return match_epilogue(X11, X21, p_int, valid_proj, dist_thresh)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Fast reciprocal NN (own semantics - the reference tree has no implementation, SURVEY 8a row K8;
+# algorithm: MASt3R, Leroy et al. 2024, section 3.3).  Scores in float64; the device computes an fp32
+# FMA chain, so tests compare indices exactly where the float64 margin between the best and the second
+# best candidate exceeds the fp32 rounding bound, and by score otherwise.
+def nn_search(Q, DB, chunk=1024):
+    """Q [S,D], DB [N,D] -> (idx [S] lowest argmax of Q.DB^T in float64, best [S], second best [S])."""
+    Q64, DB64 = np.asarray(Q, np.float64), np.asarray(DB, np.float64)
+    idx = np.empty(len(Q64), np.int64); best = np.empty(len(Q64)); second = np.empty(len(Q64))
+    for lo in range(0, len(Q64), chunk):
+        sc = Q64[lo:lo + chunk] @ DB64.T
+        i = np.argmax(sc, axis=1)                       # first maximum = lowest index
+        idx[lo:lo + chunk] = i
+        best[lo:lo + chunk] = sc[np.arange(len(i)), i]
+        sc[np.arange(len(i)), i] = -np.inf
+        second[lo:lo + chunk] = sc.max(axis=1)
+    return idx, best, second
+
+
+def fast_reciprocal_nn(D1, D2, subsample=8, max_iter=10):
+    h1, w1, d = D1.shape
+    f1, f2 = D1.reshape(-1, d), D2.reshape(-1, d)
+    ys, xs = np.arange(subsample // 2, h1, subsample), np.arange(subsample // 2, w1, subsample)
+    xy1 = (ys[:, None] * w1 + xs[None, :]).reshape(-1)
+    pairs = []
+    for _ in range(max_iter):
+        if len(xy1) == 0:
+            break
+        xy2 = nn_search(f1[xy1], f2)[0]
+        back = nn_search(f2[xy2], f1)[0]
+        conv = back == xy1
+        pairs.append(np.stack([xy1[conv], xy2[conv]], 1))
+        xy1 = np.unique(back[~conv])
+    if not pairs:
+        return np.empty(0, np.int64), np.empty(0, np.int64)
+    p = np.unique(np.concatenate(pairs), axis=0)
+    return p[:, 0], p[:, 1]

@@ -104,3 +104,21 @@ def test_calibrated_tracking_recovers_known_sim3():
     assert np.allclose(T_rel[:3], pr["T_true"][:3], atol=5e-4)
     assert abs(T_rel[7] - pr["T_true"][7]) < 5e-4
     assert info["costs"][-1] < 1e-4 * info["costs"][0]
+
+
+def test_fast_reciprocal_nn_oracle_known_answers():
+    """Own-semantics op: identical maps give the identity on every seed; a permuted copy gives the
+    permutation; duplicates resolve to the lowest index."""
+    import numpy as np
+    from oracle import matching as om
+    rng = np.random.default_rng(0)
+    D = rng.normal(size=(16, 24, 24)).astype(np.float32)
+    D /= np.linalg.norm(D, axis=-1, keepdims=True)
+    i1, i2 = om.fast_reciprocal_nn(D, D, subsample=4)
+    assert len(i1) == 4 * 6 and np.array_equal(i1, i2)
+    perm = rng.permutation(16 * 24)
+    D2 = D.reshape(-1, 24)[perm].reshape(16, 24, 24)                    # D2[j] = D[perm[j]]
+    i1, i2 = om.fast_reciprocal_nn(D, D2, subsample=4)
+    assert np.array_equal(perm[i2], i1)
+    idx, best, second = om.nn_search(D.reshape(-1, 24)[:5], np.concatenate([D.reshape(-1, 24), D.reshape(-1, 24)]))
+    assert idx.tolist() == [0, 1, 2, 3, 4] and np.allclose(best, 1.0) and np.allclose(second, 1.0)

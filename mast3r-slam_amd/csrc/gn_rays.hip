@@ -104,7 +104,7 @@ k_gn_blocks(const float *__restrict__ Twc, const float *__restrict__ Xs, const f
                 JX[k][3] = jr.x; JX[k][4] = jr.y; JX[k][5] = jr.z; JX[k][6] = Yc[k];
             }
             // accumulate straight into the float64 registers with a closed-form index (a temporary
-            // float h[] indexed by a running counter was mis-compiled in tracking.hip, see DESIGN.md §8)
+            // float h[] indexed by a running counter was mis-compiled in tracking.hip, see DESIGN.md §9)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float we = fabsf(sqrt_w * err[c]);

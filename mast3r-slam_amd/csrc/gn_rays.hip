@@ -154,40 +154,44 @@ k_gn_reduce(const double *__restrict__ part, double *__restrict__ blocks, const 
     blocks[(size_t)e * kSums + threadIdx.x] = s;
 }
 
-__global__ void __launch_bounds__(kThreads)
-k_gn_zero(double *__restrict__ Hbuf, const double *__restrict__ done, int64_t count) {
-    if (done && done[0] != 0.0) return;
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < count; i += (int64_t)gridDim.x * kThreads)
-        Hbuf[i] = 0.0;
-}
-
-// scatter one edge's +-Hjj / +-gj into the dense system (gauss_newton.py:220-251)
+// Dense system from the per-edge blocks (gauss_newton.py:220-251): an edge (i, j) adds +Hjj to the diagonal
+// blocks (i,i), (j,j), -Hjj to (i,j), (j,i), -gj to g_i and +gj to g_j.  GATHER form: workgroup (a, b) owns the
+// 7x7 block (a, b) of H (and g_a when b == a) and walks the edges in index order, so every entry is summed in
+// a FIXED order - bitwise reproducible, unlike an atomicAdd scatter whose order changes from run to run (on
+// degenerate geometry that difference alone decided between a finite and an overflowing step).
 __global__ void __launch_bounds__(64)
 k_gn_assemble(const double *__restrict__ blocks, const int32_t *__restrict__ ii, const int32_t *__restrict__ jj,
               const int32_t *__restrict__ local, double *__restrict__ H, double *__restrict__ g,
-              const double *__restrict__ done, int K, int dim) {
+              const double *__restrict__ done, int K, int dim, int E) {
     if (done && done[0] != 0.0) return;
-    const int e = blockIdx.x, t = threadIdx.x;
-    const int ix = ii[e], jx = jj[e];
-    if (ix < 0 || ix >= K || jx < 0 || jx >= K) return;
-    const int il = local[ix], jl = local[jx];
-    const double *b = blocks + (size_t)e * kSums;
-    if (b[35] == 0.0 || (il < 0 && jl < 0)) return;
-    if (t < 49) {
-        const int r = t / 7, c = t % 7;
-        const int lo = r < c ? r : c, hi = r < c ? c : r;
-        const double v = b[lo * 7 - lo * (lo - 1) / 2 + (hi - lo)];
-        if (il >= 0) atomicAdd(&H[(size_t)(il * 7 + r) * dim + il * 7 + c], v);
-        if (jl >= 0) atomicAdd(&H[(size_t)(jl * 7 + r) * dim + jl * 7 + c], v);
-        if (il >= 0 && jl >= 0) {
-            atomicAdd(&H[(size_t)(il * 7 + r) * dim + jl * 7 + c], -v);
-            atomicAdd(&H[(size_t)(jl * 7 + r) * dim + il * 7 + c], -v);
+    const int a = blockIdx.y, bcol = blockIdx.x, t = threadIdx.x;
+    const int r = t / 7, c = t % 7;
+    const int lo = r < c ? r : c, hi = r < c ? c : r;
+    const int hidx = lo * 7 - lo * (lo - 1) / 2 + (hi - lo);
+    double h = 0.0, gv = 0.0;
+    for (int e = 0; e < E; ++e) {                            // uniform loop: every lane sees the same edges
+        const int ix = ii[e], jx = jj[e];
+        if (ix < 0 || ix >= K || jx < 0 || jx >= K) continue;
+        const int il = local[ix], jl = local[jx];
+        const double *blk = blocks + (size_t)e * kSums;
+        if (blk[35] == 0.0) continue;
+        const bool diag_i = (il == a && bcol == a), diag_j = (jl == a && bcol == a);
+        const bool both = il >= 0 && jl >= 0;
+        const bool off_ij = both && il == a && jl == bcol, off_ji = both && jl == a && il == bcol;
+        if (!(diag_i || diag_j || off_ij || off_ji)) continue;
+        if (t < 49) {
+            const double v = blk[hidx];
+            if (diag_i) h += v;                              // (i,i)
+            if (diag_j) h += v;                              // (j,j)
+            if (off_ij) h -= v;                              // (i,j)
+            if (off_ji) h -= v;                              // (j,i)
+        } else if (t < 56 && bcol == a) {
+            if (diag_i) gv -= blk[28 + (t - 49)];
+            if (diag_j) gv += blk[28 + (t - 49)];
         }
-    } else if (t < 56) {
-        const int r = t - 49;
-        if (il >= 0) atomicAdd(&g[il * 7 + r], -b[28 + r]);
-        if (jl >= 0) atomicAdd(&g[jl * 7 + r], b[28 + r]);
     }
+    if (t < 49) H[(size_t)(a * 7 + r) * dim + bcol * 7 + c] = h;
+    else if (t < 56 && bcol == a) g[a * 7 + (t - 49)] = gv;
 }
 
 // One workgroup: (H + 1e-6 I) dx = -g by in-place Cholesky (lower) + two triangular solves,
@@ -241,15 +245,22 @@ k_gn_step(double *__restrict__ H, double *__restrict__ g, double *__restrict__ x
         for (int i = t; i < k; i += kSolveThreads) x[i] -= H[(size_t)k * dim + i] * xk;
         __syncthreads();
     }
-    __shared__ double nrm2;
+    __shared__ double nrm2, smax;
     if (t == 0) {
-        double s = 0.0;
-        for (int i = 0; i < dim; ++i) s += x[i] * x[i];
-        nrm2 = s;
+        double s = 0.0, m = 0.0;
+        for (int i = 0; i < dim; ++i) {
+            s += x[i] * x[i];
+            if (i % 7 == 6) m = fmax(m, fabs(x[i]));
+        }
+        nrm2 = s; smax = m;
     }
     __syncthreads();
     const double dn = sqrt(nrm2);
     if (t == 0) info[1] = dn;
+    if (!isfinite(dn) || smax > 30.0) {                     // a scale step e^sigma beyond float range (degenerate
+        if (t == 0) { info[2] = 1.0; info[3] = 1.0; }       // geometry): report failure, keep the poses
+        return;
+    }
     if (dn < (double)delta_thresh) {                        // stop BEFORE the update (gauss_newton.py:262-265)
         if (t == 0) info[2] = 1.0;
         return;
@@ -327,10 +338,8 @@ int m3_gn_rays_assemble(const double *blocks, const int32_t *ii, const int32_t *
     M3_REQUIRE(blocks && ii && jj && local && H && g && K > 0 && E > 0 && num_free > 0);
     hipStream_t st = (hipStream_t)stream;
     const int dim = 7 * num_free;
-    M3_CHECK_HIP(hipMemsetAsync(H, 0, sizeof(double) * (size_t)dim * dim, st), "m3_gn_rays_assemble/memset");
-    M3_CHECK_HIP(hipMemsetAsync(g, 0, sizeof(double) * dim, st), "m3_gn_rays_assemble/memset");
-    hipLaunchKernelGGL(k_gn_assemble, dim3(E), dim3(64), 0, st, blocks, ii, jj, local, H, g,
-                       (const double *)nullptr, K, dim);
+    hipLaunchKernelGGL(k_gn_assemble, dim3(num_free, num_free), dim3(64), 0, st, blocks, ii, jj, local, H, g,
+                       (const double *)nullptr, K, dim, E);       // writes every entry of H and g: no zero fill
     M3_CHECK_LAUNCH("m3_gn_rays_assemble");
     return M3_OK;
 }
@@ -358,15 +367,12 @@ int m3_gn_rays_solve(float *Twc, const float *Xs, const float *Cs, const int32_t
     double *H = Hbuf, *g = Hbuf + (size_t)dim * dim, *x = g + dim;
     const double *done = info + 2;
     hipLaunchKernelGGL(k_gn_info_init, dim3(1), dim3(64), 0, st, info);
-    const int64_t count = (int64_t)dim * dim + dim;
     for (int it = 0; it < max_iter; ++it) {
         int rc = launch_blocks(Twc, Xs, Cs, ii, jj, idx, valid, Q, blocks, ws, done, K, P, E, sigma_ray, C_thresh,
                                Q_thresh, point_mode, cal, st);
         if (rc != M3_OK) return rc;
-        hipLaunchKernelGGL(k_gn_zero, dim3(m3_cdiv(count, kThreads) > 1024 ? 1024 : m3_cdiv(count, kThreads)),
-                           dim3(kThreads), 0, st, Hbuf, done, count);
-        hipLaunchKernelGGL(k_gn_assemble, dim3(E), dim3(64), 0, st, (const double *)blocks, ii, jj, local, H, g,
-                           done, K, dim);
+        hipLaunchKernelGGL(k_gn_assemble, dim3(num_free, num_free), dim3(64), 0, st, (const double *)blocks, ii, jj,
+                           local, H, g, done, K, dim, E);
         hipLaunchKernelGGL(k_gn_step, dim3(1), dim3(kSolveThreads), 0, st, H, g, x, Twc, local, info, K, dim,
                            delta_thresh, 1);
         M3_CHECK_LAUNCH("m3_gn_rays_solve/iter");

@@ -234,6 +234,10 @@ k_track_solve(double *__restrict__ ws, float rel_error, float delta_norm, int fi
     double tn = 0.0;
     for (int i = 0; i < 7; ++i) tn += g[i] * g[i];
     tn = sqrt(tn);
+    if (!isfinite(tn) || fabs(g[6]) > 30.0) {  // a step whose scale factor e^sigma leaves float range (degenerate
+        ws[WS_DONE] = 2.0;                      // geometry): stop and keep the pose, like the singular case
+        return;
+    }
     Pose<double> T = mul(load_pose<double>(ws + WS_T), exp_mlx(g));
     store_pose(ws + WS_T, T);
     const double old = ws[WS_OLD];

@@ -255,6 +255,9 @@ def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray:
             if sharded:
                 tdist.broadcast(dx, src=tdist.get_global_rank(group, 0) if group is not tdist.group.WORLD else 0, group=group)
             last = float(torch.linalg.norm(dx))
+            if not np.isfinite(last) or float(dx.view(-1, 7)[:, 6].abs().max()) > 30.0:
+                failed = stopped = True                      # scale step beyond float range: keep the poses (gn_rays.hip)
+                break
             if last < delta_thresh:
                 stopped = True
                 break

@@ -203,8 +203,8 @@ def main():
     for kind, flops, e0, e1, nbytes in prof:
         d = by_kind.setdefault(kind, [0.0, 0.0, 0, 0.0])
         d[0] += flops; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1; d[3] += nbytes
-    g = by_kind.get("gemm", [0.0, 1.0, 1, 0.0])
-    traffic = pmc_traffic_per_launch(("k_gemm256<0", "k_gemm<0"))
+    g = by_kind.get("gemm256", [0.0, 1.0, 1, 0.0])
+    traffic = pmc_traffic_per_launch(("k_gemm256<0",))
     gemm_tflops = g[0] / g[1] / 1e12
     model_flops = net.flops_per_pair(H, W) * P
 
@@ -228,14 +228,16 @@ def main():
                    "parallelism": f"pair-sharded x{world}", "launch": ("hipGraph replay" + ("" if dist is None else " + RCCL all-gather of the previous step overlapped on the communicator stream")) if graph is not None else "eager"},
         "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
         "model_tflop_per_step": model_flops / 1e12,
-        "roofline": {"bound": "mfma", "kernel": "k_gemm256 / k_gemm (bf16 MFMA GEMM, 256x256x64 ping-pong and 128x128x64 tiles)",
+        "roofline": {"bound": "mfma", "kernel": "k_gemm256 (bf16 MFMA GEMM, 256x256x64 / 256x192x64 ping-pong tiles; dense launches only - "
+                                                "its implicit-GEMM conv launches and the small-problem kernel are listed under other_kernels_tflops)",
                      "achieved": gemm_tflops, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": gemm_tflops / MFMA_BF16_PEAK_TFLOPS,
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE passes "
                                                          "of this command, profiles/r01_pmc_traffic.json)",
                      "algorithmic_bytes_per_launch": g[3] / max(g[2], 1),
                      "launches": g[2], "avg_launch_us": g[1] / max(g[2], 1) * 1e6,
-                     "other_kernels_tflops": {k: v[0] / v[1] / 1e12 for k, v in by_kind.items() if k != "gemm"}},
+                     "other_kernels_tflops": {k: v[0] / v[1] / 1e12 for k, v in by_kind.items() if k != "gemm256"},
+                     "all_mfma_kernels_tflops": sum(v[0] for v in by_kind.values()) / sum(v[1] for v in by_kind.values()) / 1e12},
     }
 
     if world == 1 and not args.no_b1:

@@ -34,6 +34,10 @@ enum {
 int m3_gemm_bf16(const void *A, const void *W, const float *bias, void *C, const void *R,
                  int M, int N, int K, int ldc, int epilogue, void *stream);
 
+/* Which kernel m3_gemm_bf16 / _rope / _grouped2 dispatch a dense [M,N] problem to: 256 or 192 = the
+ * 256-row ping-pong kernel with 256- / 192-wide tiles, 128 or 64 = the small-problem kernel. */
+int m3_gemm_pick_tile(int M, int N, int groups);
+
 /* Projection GEMM with RoPE-2D fused into the epilogue: C(bf16) = rope(A . W^T + bias) on the
  * 64-wide heads in columns [0, rope_cols) (q|k of a q|k|v projection), plain bias add beyond.
  * Row m is token m % tokens_per_image of its image; tables as in m3_rope2d_bf16.  N % 64 == 0. */

@@ -325,6 +325,11 @@ int m3_launch_gemm256_conv(const GemmArgs &a, int epi, hipStream_t st);
 
 extern "C" {
 
+int m3_gemm_pick_tile(int M, int N, int groups) {
+    if (M <= 0 || N <= 0) return 0;
+    return pick_tile(M, N, groups > 1 ? groups : 1);
+}
+
 int m3_gemm_bf16(const void *A, const void *W, const float *bias, void *C, const void *R, int M, int N, int K,
                  int ldc, int epilogue, void *stream) {
     M3_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0);

@@ -29,6 +29,13 @@ def _prof_begin():
     return e
 
 
+def _gemm_kind(m, n, groups=1):
+    """Profile tag naming the kernel family the dispatcher picks (k_gemm256 = 256-row ping-pong kernel)."""
+    if PROFILE is None:
+        return "gemm"
+    return "gemm256" if int(_ffi.lib().m3_gemm_pick_tile(m, n, groups)) >= 192 else "gemm_small"
+
+
 def _prof_end(e0, kind, flops, nbytes=0.0):
     if e0 is not None:
         e1 = torch.cuda.Event(enable_timing=True)
@@ -68,7 +75,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, epi: int = EPI_BF16, out=N
     _ffi.call("m3_gemm_bf16", _ffi.ptr(a), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(out), _ffi.ptr(resid),
               m, n, k, ldc, epi, _ffi.stream_ptr())
     esz = out.element_size()
-    _prof_end(e0, "gemm", 2.0 * m * n * k, 2.0 * (m * k + n * k) + esz * m * n * (1 if resid is None else 2))
+    _prof_end(e0, _gemm_kind(m, n), 2.0 * m * n * k, 2.0 * (m * k + n * k) + esz * m * n * (1 if resid is None else 2))
     return out
 
 
@@ -82,7 +89,7 @@ def gemm_rope(a, w, bias, pos_yx, cos_sin, tokens_per_image: int, rope_cols: int
     e0 = _prof_begin()
     _ffi.call("m3_gemm_bf16_rope", _ffi.ptr(a), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(out), m, n, k, n,
               _ffi.ptr(pos_yx), _ffi.ptr(cos_sin), tokens_per_image, rope_cols, _ffi.stream_ptr())
-    _prof_end(e0, "gemm", 2.0 * m * n * k, 2.0 * (m * k + n * k + m * n))
+    _prof_end(e0, _gemm_kind(m, n), 2.0 * m * n * k, 2.0 * (m * k + n * k + m * n))
     return out
 
 
@@ -262,7 +269,7 @@ def gemm_grouped2(a, w0, w1, b0, b1, epi=EPI_BF16, out=None, resid=None, rope=No
     e0 = _prof_begin()
     _ffi.call("m3_gemm_bf16_grouped2", _ffi.ptr(a), _ffi.ptr(w0), _ffi.ptr(w1), _ffi.ptr(b0), _ffi.ptr(b1), _ffi.ptr(out),
               _ffi.ptr(resid), m, n, k, n, m * k, m * n, epi, _ffi.ptr(pos), _ffi.ptr(cs), tpi, rc, _ffi.stream_ptr())
-    _prof_end(e0, "gemm", 4.0 * m * n * k,
+    _prof_end(e0, _gemm_kind(m, n, 2), 4.0 * m * n * k,
               2.0 * (2.0 * (m * k + n * k) + out.element_size() * m * n * (1 if resid is None else 2)))
     return out
 

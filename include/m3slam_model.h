@@ -7,7 +7,12 @@
  * The reference tree holds no source for that arithmetic; the architecture follows the
  * public MASt3R / DUSt3R / CroCo-v2 definition (DESIGN.md "Model").  Conventions as in
  * m3slam.h: device pointers, caller-owned buffers, stream-ordered, int status.
- * bf16 tensors are passed as void* (16-bit storage, round-to-nearest-even).
+ * 16-bit tensors are passed as void* (round-to-nearest-even).  Every operator that converts to or
+ * from the 16-bit storage type exists as NAME_dt(..., int dtype, void *stream) with dtype =
+ * M3_DT_BF16 (v_mfma_f32_16x16x32_bf16) or M3_DT_F16 (IEEE half, v_mfma_f32_16x16x32_f16 - same
+ * MFMA rate, 3 more mantissa bits, range 65504); the *_bf16 names are the dtype = M3_DT_BF16 forms.
+ * This is the `precision` argument of load_mast3r (mast3r_utils.py:47-52: "fp16" | "fp32" | "bf16").
+ * Pure data movement (m3_relu_bf16 by sign bit, m3_concat2_bf16, m3_unshuffle_bf16) serves both types.
  */
 #ifndef M3SLAM_MODEL_H
 #define M3SLAM_MODEL_H
@@ -18,7 +23,10 @@
 extern "C" {
 #endif
 
-/* epilogue selectors of m3_gemm_bf16 / m3_conv3x3_bf16 */
+/* 16-bit storage type of a launch: operands, 16-bit outputs and 16-bit residuals share it */
+enum { M3_DT_BF16 = 0, M3_DT_F16 = 1 };
+
+/* epilogue selectors of m3_gemm_* / m3_conv3x3_* ("BF16" = the launch's 16-bit type) */
 enum {
     M3_EPI_BF16 = 0,       /* C(bf16) = acc + bias */
     M3_EPI_BF16_GELU = 1,  /* C(bf16) = gelu_erf(acc + bias) */
@@ -33,6 +41,8 @@ enum {
  * accumulation on v_mfma_f32_16x16x32_bf16.  K % 64 == 0, N % 4 == 0, ldc >= N. */
 int m3_gemm_bf16(const void *A, const void *W, const float *bias, void *C, const void *R,
                  int M, int N, int K, int ldc, int epilogue, void *stream);
+int m3_gemm_dt(const void *A, const void *W, const float *bias, void *C, const void *R,
+               int M, int N, int K, int ldc, int epilogue, int dtype, void *stream);
 
 /* Which kernel m3_gemm_bf16 / _rope / _grouped2 dispatch a dense [M,N] problem to: 256 or 192 = the
  * 256-row ping-pong kernel with 256- / 192-wide tiles, 128 or 64 = the small-problem kernel. */
@@ -44,6 +54,9 @@ int m3_gemm_pick_tile(int M, int N, int groups);
 int m3_gemm_bf16_rope(const void *A, const void *W, const float *bias, void *C, int M, int N, int K,
                       int ldc, const int32_t *pos_yx, const float *cos_sin, int tokens_per_image,
                       int rope_cols, void *stream);
+int m3_gemm_rope_dt(const void *A, const void *W, const float *bias, void *C, int M, int N, int K,
+                    int ldc, const int32_t *pos_yx, const float *cos_sin, int tokens_per_image,
+                    int rope_cols, int dtype, void *stream);
 
 /* Two same-shape GEMMs in one launch (the two decoder branches have different weights): group g
  * (0/1) computes C + g*c_gstride = epi((A + g*a_gstride) . W[g]^T + bias[g]); strides in elements.
@@ -52,6 +65,10 @@ int m3_gemm_bf16_grouped2(const void *A, const void *W0, const void *W1, const f
                           const float *bias1, void *C, const void *R, int M, int N, int K, int ldc,
                           int64_t a_gstride, int64_t c_gstride, int epilogue, const int32_t *pos_yx,
                           const float *cos_sin, int tokens_per_image, int rope_cols, void *stream);
+int m3_gemm_grouped2_dt(const void *A, const void *W0, const void *W1, const float *bias0,
+                        const float *bias1, void *C, const void *R, int M, int N, int K, int ldc,
+                        int64_t a_gstride, int64_t c_gstride, int epilogue, const int32_t *pos_yx,
+                        const float *cos_sin, int tokens_per_image, int rope_cols, int dtype, void *stream);
 
 /* 3x3 convolution, padding 1, stride 1 or 2, as an implicit GEMM: X bf16 NHWC [B,H,W,Cin],
  * W bf16 [Cout,3,3,Cin], Y NHWC [B,OH,OW,Cout].  Cin % 64 == 0, Cout % 4 == 0.  zero16: 16
@@ -66,35 +83,51 @@ int64_t m3_conv3x3_splitk_bytes(int B, int H, int Wd, int Cin, int Cout, int str
 int m3_conv3x3_bf16(const void *X, const void *W, const float *bias, void *Y, const void *R,
                     const void *zero16, int B, int H, int Wd, int Cin, int Cout, int stride,
                     int epilogue, void *splitk_ws, int64_t splitk_ws_bytes, void *stream);
+int m3_conv3x3_dt(const void *X, const void *W, const float *bias, void *Y, const void *R,
+                  const void *zero16, int B, int H, int Wd, int Cin, int Cout, int stride,
+                  int epilogue, void *splitk_ws, int64_t splitk_ws_bytes, int dtype, void *stream);
 
 /* Tail of the DPT head in one launch (head.2 conv3x3 128->128 + ReLU, head.4 1x1 128->4, pointmap
  * post-processing): pts [B,H,W,3] = xyz/|xyz| * expm1(|xyz|), conf [B,H,W] = 1 + exp(c) with
- * (xyz, c) = W4 . bf16(relu(conv3x3(X, W) + bias)) + b4.  W [128,3,3,Cin], W4 [4,128] bf16; the
- * 128-channel full-resolution map is never written.  Same numerics as m3_conv3x3_bf16(RELU) ->
- * m3_gemm_bf16(F32) -> m3_pts_post up to fp32 summation order. */
+ * (xyz, c) = W4 . relu(conv3x3(X, W) + bias) + b4.  W [128,3,3,Cin], W4 [4,128] 16-bit; the
+ * 128-channel full-resolution map is never written and never rounded to 16 bits (the unfused chain
+ * m3_conv3x3(RELU) -> m3_gemm(F32) -> m3_pts_post rounds it once: that rounding was the largest
+ * single term of the pointmap error against the fp32 oracle). */
 int m3_conv3x3_relu_head4(const void *X, const void *W, const float *bias, const void *W4, const float *b4,
                           float *pts, float *conf, const void *zero16, int B, int H, int Wd, int Cin,
                           void *stream);
+int m3_conv3x3_relu_head4_dt(const void *X, const void *W, const float *bias, const void *W4, const float *b4,
+                             float *pts, float *conf, const void *zero16, int B, int H, int Wd, int Cin,
+                             int dtype, void *stream);
 
 /* Fused multi-head attention, head dim 64: O = softmax(scale * Q K^T) V, bf16 in/out, fp32
  * softmax.  Q/K/V/O are addressed as base + batch*batch_stride + token*row_stride + head*64
  * (element units), so q, k, v may live interleaved in one [tokens, 3C] projection buffer.
  * Keys/values of batch item b are read from item (b + kv_batch_shift) % nbatch (decoder
- * cross-attention to the other view).  Tq % 128 == 0, Tk % 64 == 0. */
+ * cross-attention to the other view).  Any Tq, Tk >= 1 (key tail masked with -inf, query tail
+ * rows not stored): resize_img emits every multiple of 16, e.g. 512x336 -> 672 tokens. */
 int m3_attention_bf16(const void *Q, const void *K, const void *V, void *O, int q_row_stride,
                       int kv_row_stride, int o_row_stride, int64_t q_batch_stride,
                       int64_t kv_batch_stride, int64_t o_batch_stride, int nbatch, int heads,
                       int Tq, int Tk, int kv_batch_shift, float scale, void *stream);
+int m3_attention_dt(const void *Q, const void *K, const void *V, void *O, int q_row_stride,
+                    int kv_row_stride, int o_row_stride, int64_t q_batch_stride,
+                    int64_t kv_batch_stride, int64_t o_batch_stride, int nbatch, int heads,
+                    int Tq, int Tk, int kv_batch_shift, float scale, int dtype, void *stream);
 
 /* CroCo RoPE-2D ("RoPE100") in place on the 64-wide heads of X [tokens,row_stride] bf16:
  * dims 0..31 rotate with the token's y, 32..63 with its x; pos_yx int32 [tokens_per_image,2],
  * cos_sin f32 [max_pos,16,2]. */
 int m3_rope2d_bf16(void *X, const int32_t *pos_yx, const float *cos_sin, int row_stride, int tokens,
                    int heads, int tokens_per_image, void *stream);
+int m3_rope2d_dt(void *X, const int32_t *pos_yx, const float *cos_sin, int row_stride, int tokens,
+                 int heads, int tokens_per_image, int dtype, void *stream);
 
 /* y(bf16)[M,C] = LayerNorm(x(f32)[M,C]) * gamma + beta; C % 256 == 0, C <= 2048. */
 int m3_layernorm_bf16(const float *x, const float *gamma, const float *beta, void *y, int M, int C,
                       float eps, void *stream);
+int m3_layernorm_dt(const float *x, const float *gamma, const float *beta, void *y, int M, int C,
+                    float eps, int dtype, void *stream);
 
 /* Two-group LayerNorm in one launch: rows [0,M) use (gamma0,beta0), rows [M,2M) use (gamma1,beta1);
  * output row r normalises input row (r + in_row_shift) % (2M) (in_row_shift = M swaps the halves:
@@ -102,24 +135,33 @@ int m3_layernorm_bf16(const float *x, const float *gamma, const float *beta, voi
 int m3_layernorm_bf16_grouped2(const float *x, const float *gamma0, const float *beta0, const float *gamma1,
                                const float *beta1, void *y, int M, int C, int in_row_shift, float eps,
                                void *stream);
+int m3_layernorm_grouped2_dt(const float *x, const float *gamma0, const float *beta0, const float *gamma1,
+                             const float *beta1, void *y, int M, int C, int in_row_shift, float eps,
+                             int dtype, void *stream);
 
 /* uint8 image [B,H,W,3] -> bf16 patch matrix [B*(H/16)*(W/16), 768] (column c*256+py*16+px),
  * normalised (v/255-0.5)/0.5 (resize_img, mast3r_utils.py:186-188). */
 int m3_patchify16(const uint8_t *img, void *A, int B, int H, int W, void *stream);
+int m3_patchify16_dt(const uint8_t *img, void *A, int B, int H, int W, int dtype, void *stream);
 
 int m3_f32_to_bf16(const float *x, void *y, int64_t n, void *stream);               /* n % 4 == 0 */
-int m3_relu_bf16(const void *x, void *y, int64_t n, void *stream);                  /* n % 8 == 0 */
+int m3_cast_f32_dt(const float *x, void *y, int64_t n, int dtype, void *stream);    /* f32 -> 16-bit, n % 4 == 0 */
+int m3_cast16(const void *x, void *y, int64_t n, int from_dtype, int to_dtype, void *stream);   /* bf16 <-> f16, n % 8 == 0 */
+int m3_relu_bf16(const void *x, void *y, int64_t n, void *stream);                  /* n % 8 == 0; bf16 or f16 */
 int m3_add_bf16(const void *a, const void *b, void *y, int64_t n, void *stream);     /* n % 8 == 0 */
+int m3_add_dt(const void *a, const void *b, void *y, int64_t n, int dtype, void *stream);
 int m3_concat2_bf16(const void *a, const void *b, void *out, int64_t M, int Ca, int Cb, void *stream);
 /* k = s transposed-conv GEMM output [B*h*w, s*s*C] -> NHWC [B,h*s,w*s,Cpad] (first C channels). */
 int m3_unshuffle_bf16(const void *in, void *out, int B, int h, int w, int s, int C, int Cpad, void *stream);
 /* bilinear x2, align_corners = True, NHWC bf16. */
 int m3_upsample2x_bf16(const void *in, void *out, int B, int H, int W, int C, void *stream);
+int m3_upsample2x_dt(const void *in, void *out, int B, int H, int W, int C, int dtype, void *stream);
 /* DPT output [P,4] f32 -> pts3d [P,3] = xyz/|xyz| * expm1(|xyz|), conf [P] = 1 + exp(c). */
 int m3_pts_post(const float *in, float *pts, float *conf, int64_t P, void *stream);
 /* feature-head output [B*(H/16)*(W/16), 6400] bf16 -> pixel shuffle 16 -> desc [B,H,W,24] f32
  * (L2-normalised), desc_conf [B,H,W] = exp(channel 24). */
 int m3_desc_post(const void *in, float *desc, float *dconf, int B, int H, int W, void *stream);
+int m3_desc_post_dt(const void *in, float *desc, float *dconf, int B, int H, int W, int dtype, void *stream);
 
 #ifdef __cplusplus
 }

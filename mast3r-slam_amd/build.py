@@ -30,11 +30,31 @@ def _sources():
     return sorted(f for f in os.listdir(SRC) if f.endswith(".hip"))
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
+def _digest(paths, extra=()):
+    """sha256 over the CONTENT of the inputs and the command line: a checkout, a copy to the GPU box or a
+    `touch` changes mtimes without changing what would be compiled (and the reverse after `git stash`)."""
+    import hashlib
+    h = hashlib.sha256()
+    for p in sorted(os.path.realpath(x) for x in paths):
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+    for e in extra:
+        h.update(str(e).encode() + b"\0")
+    return h.hexdigest()
+
+
+def _stale(target, deps, extra=()):
+    """True when `target` is missing or was built from different inputs (digest kept beside it)."""
+    stamp = target + ".sha256"
+    if not os.path.exists(target) or not os.path.exists(stamp):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    return open(stamp).read().strip() != _digest(deps, extra)
+
+
+def _mark(target, deps, extra=()):
+    with open(target + ".sha256", "w") as f:
+        f.write(_digest(deps, extra))
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -42,14 +62,18 @@ def build(force: bool = False, verbose: bool = True) -> str:
     headers = [os.path.join(SRC, f) for f in os.listdir(SRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "m3slam.h"))
     headers += [os.path.join(HERE, "..", "include", f) for f in os.listdir(os.path.join(HERE, "..", "include"))]
+    headers = sorted(set(os.path.realpath(h) for h in headers))
     jobs = []
     objs = []
+    marks = []
     for s in _sources():
         src = os.path.join(SRC, s)
         obj = os.path.join(OUT, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [src] + headers):
-            jobs.append([HIPCC, *COMMON, *PER_FILE.get(s, []), "-c", src, "-o", obj])
+        cmd = [HIPCC, *COMMON, *PER_FILE.get(s, []), "-c", src, "-o", obj]
+        if force or _stale(obj, [src] + headers, cmd):
+            jobs.append(cmd)
+            marks.append((obj, [src] + headers, cmd))
 
     def run(cmd):
         if verbose:
@@ -62,8 +86,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    for m in marks:
+        _mark(*m)
+    link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    if jobs or force or _stale(LIB, objs, link):
+        run(link)
+        _mark(LIB, objs, link)
     return LIB
 
 

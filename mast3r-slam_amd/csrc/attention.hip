@@ -13,15 +13,19 @@
 // buffered); K fragments are ds_read_b128 from an XOR-swizzled image, V^T fragments come from
 // the row-major V image through ds_read_b64_tr_b16 (hardware transpose), conflict-free with a
 // chunk-pair swizzle.
-#include "common.h"
-#include "../../include/m3slam_model.h"
+#include "gemm_common.h"
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
+using m3gemm::bf16x8;
+using m3gemm::f32x4;
+using m3gemm::bf16_t;
+using m3gemm::glds16;
+using m3gemm::pack16;
+using m3gemm::mfma16;
+using m3gemm::DT_BF16;
+using m3gemm::DT_F16;
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef unsigned short bf16_t;
 
 constexpr int kThreads = 256;
 constexpr int QROWS = 128;     // query rows per workgroup
@@ -30,15 +34,7 @@ constexpr int HD = 64;         // head dim
 constexpr int kTileBytes = KT * HD * 2;          // 8 KiB
 constexpr int kLds = 4 * kTileBytes;             // K,V x 2 stages = 32 KiB
 
-__device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) unsigned *)g,
-                                     (__attribute__((address_space(3))) unsigned *)lds_wave_base, 16, 0, 0);
-}
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
+using m3gemm::pack_bf16;
 
 struct AttnArgs {
     const bf16_t *Q, *K, *V;
@@ -52,7 +48,9 @@ struct AttnArgs {
 // QT = 16-row query tiles per wave: 2 -> 128 query rows per workgroup (throughput regime), 1 -> 64 rows
 // per workgroup (twice the workgroups: used when the 128-row grid would leave CUs with < 2 workgroups,
 // e.g. one pair = 2 images x 16 heads x 8 blocks = 256 workgroups on 256 CUs).
-template <int QT>
+// Any Tq, Tk >= 1: query rows past Tq are computed on a clamped row and not stored; keys past Tk (last
+// tile only) are staged from the clamped last row and their scores set to -inf before the softmax.
+template <int QT, int DT>
 __global__ void __launch_bounds__(kThreads, 4)
 k_attn(const AttnArgs a) {
     constexpr int QR = QT * 64;                                 // query rows per workgroup
@@ -62,7 +60,7 @@ k_attn(const AttnArgs a) {
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so give every XCD one contiguous
     // range of ids -- the Tq/128 query blocks of a (batch, head) then share its K/V through ONE L2
     // instead of pulling them into eight (measured 5x the compulsory HBM reads before this remap).
-    const int nq = a.Tq / QR, nwg = gridDim.x;
+    const int nq = (a.Tq + QR - 1) / QR, nwg = gridDim.x;
     const int per = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7;
     const int id = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + (blockIdx.x >> 3);
     const int qblk = id % nq, head = (id / nq) % a.heads, b = id / (nq * a.heads);
@@ -75,7 +73,8 @@ k_attn(const AttnArgs a) {
     bf16x8 qf[QT][2];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        const int row = qblk * QR + wave * (16 * QT) + qt * 16 + lq;
+        int row = qblk * QR + wave * (16 * QT) + qt * 16 + lq;
+        row = row < a.Tq ? row : a.Tq - 1;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
             qf[qt][ks] = *reinterpret_cast<const bf16x8 *>(Qp + (size_t)row * a.q_row_stride + ks * 32 + g * 8);
@@ -89,7 +88,9 @@ k_attn(const AttnArgs a) {
         unsigned char *kb = lds + buf * 2 * kTileBytes, *vb = kb + kTileBytes;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const size_t row = (size_t)(t * KT + i * 32 + srow) * a.kv_row_stride;
+            int kr = t * KT + i * 32 + srow;
+            kr = kr < a.Tk ? kr : a.Tk - 1;
+            const size_t row = (size_t)kr * a.kv_row_stride;
             glds16(Kp + row + kch * 8, kb + i * 4096 + wave * 1024);
             glds16(Vp + row + vch * 8, vb + i * 4096 + wave * 1024);
         }
@@ -104,7 +105,7 @@ k_attn(const AttnArgs a) {
         for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    const int nt = a.Tk / KT;
+    const int nt = (a.Tk + KT - 1) / KT;
     stage(0, 0);
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
@@ -128,8 +129,19 @@ k_attn(const AttnArgs a) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + r * 128 + c * 16);
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt)
-                    s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][kt], 0, 0, 0);
+                    s[qt][kt] = mfma16<DT>(kf, qf[qt][ks], s[qt][kt]);
             }
+
+        if (t == nt - 1 && (a.Tk & (KT - 1))) {           // key tail: wave-uniform branch, last tile only
+            const int kbase = t * KT + g * 4;
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kbase + kt * 16 + r >= a.Tk) s[qt][kt][r] = -INFINITY;
+        }
 
         // ---- online softmax (row = lane-local query) -------------------------------------------
         bf16x8 pf[QT][2];
@@ -166,10 +178,10 @@ k_attn(const AttnArgs a) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 union { unsigned u[4]; bf16x8 v; } pk;
-                pk.u[0] = pack_bf16(s[qt][2 * kk][0], s[qt][2 * kk][1]);
-                pk.u[1] = pack_bf16(s[qt][2 * kk][2], s[qt][2 * kk][3]);
-                pk.u[2] = pack_bf16(s[qt][2 * kk + 1][0], s[qt][2 * kk + 1][1]);
-                pk.u[3] = pack_bf16(s[qt][2 * kk + 1][2], s[qt][2 * kk + 1][3]);
+                pk.u[0] = pack16<DT>(s[qt][2 * kk][0], s[qt][2 * kk][1]);
+                pk.u[1] = pack16<DT>(s[qt][2 * kk][2], s[qt][2 * kk][3]);
+                pk.u[2] = pack16<DT>(s[qt][2 * kk + 1][0], s[qt][2 * kk + 1][1]);
+                pk.u[3] = pack16<DT>(s[qt][2 * kk + 1][2], s[qt][2 * kk + 1][3]);
                 pf[qt][kk] = pk.v;
             }
         }
@@ -192,7 +204,7 @@ k_attn(const AttnArgs a) {
                 }
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt)
-                    o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[qt][kk], o[qt][dt], 0, 0, 0);
+                    o[qt][dt] = mfma16<DT>(vf.v, pf[qt][kk], o[qt][dt]);
             }
         __builtin_amdgcn_s_barrier();
     }
@@ -205,12 +217,13 @@ k_attn(const AttnArgs a) {
         l += __shfl_xor(l, 32, 64);
         const float inv = 1.0f / l;
         const int row = qblk * QR + wave * (16 * QT) + qt * 16 + lq;
+        if (row >= a.Tq) continue;
         bf16_t *op = a.O + (size_t)b * a.o_batch_stride + (size_t)row * a.o_row_stride + head * HD;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             uint2 w;
-            w.x = pack_bf16(o[qt][dt][0] * inv, o[qt][dt][1] * inv);
-            w.y = pack_bf16(o[qt][dt][2] * inv, o[qt][dt][3] * inv);
+            w.x = pack16<DT>(o[qt][dt][0] * inv, o[qt][dt][1] * inv);
+            w.y = pack16<DT>(o[qt][dt][2] * inv, o[qt][dt][3] * inv);
             *reinterpret_cast<uint2 *>(op + dt * 16 + g * 4) = w;
         }
     }
@@ -222,6 +235,7 @@ k_attn(const AttnArgs a) {
 //   out[i]    = x[i] cos(p f_i) - x[i+16] sin(p f_i)
 //   out[i+16] = x[i+16] cos(p f_i) + x[i] sin(p f_i),   f_i = base^(-i/16), i = 0..15
 // cs: fp32 table [max_pos][16][2] = (cos, sin).  One thread handles one (token, head, 32-block).
+template <int DT>
 __global__ void __launch_bounds__(kThreads)
 k_rope2d(bf16_t *__restrict__ X, const int *__restrict__ pos_yx, const float *__restrict__ cs, int row_stride,
          int tokens, int heads, int tokens_per_image) {
@@ -238,8 +252,8 @@ k_rope2d(bf16_t *__restrict__ X, const int *__restrict__ pos_yx, const float *__
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const float c = t[2 * i], sn = t[2 * i + 1];
-        const float x1 = __uint_as_float((unsigned)v.h[i] << 16), x2 = __uint_as_float((unsigned)v.h[i + 16] << 16);
-        const unsigned pk = pack_bf16(x1 * c - x2 * sn, x2 * c + x1 * sn);
+        const float x1 = m3gemm::lo16<DT>(v.h[i]), x2 = m3gemm::lo16<DT>(v.h[i + 16]);
+        const unsigned pk = pack16<DT>(x1 * c - x2 * sn, x2 * c + x1 * sn);
         v.h[i] = (bf16_t)(pk & 0xffff);
         v.h[i + 16] = (bf16_t)(pk >> 16);
     }
@@ -251,11 +265,11 @@ k_rope2d(bf16_t *__restrict__ X, const int *__restrict__ pos_yx, const float *__
 
 extern "C" {
 
-int m3_attention_bf16(const void *Q, const void *K, const void *V, void *O, int q_row_stride, int kv_row_stride,
-                      int o_row_stride, int64_t q_batch_stride, int64_t kv_batch_stride, int64_t o_batch_stride,
-                      int nbatch, int heads, int Tq, int Tk, int kv_batch_shift, float scale, void *stream) {
+int m3_attention_dt(const void *Q, const void *K, const void *V, void *O, int q_row_stride, int kv_row_stride,
+                    int o_row_stride, int64_t q_batch_stride, int64_t kv_batch_stride, int64_t o_batch_stride,
+                    int nbatch, int heads, int Tq, int Tk, int kv_batch_shift, float scale, int dtype, void *stream) {
     M3_REQUIRE(Q && K && V && O && nbatch > 0 && heads > 0 && Tq > 0 && Tk > 0);
-    M3_REQUIRE(Tq % QROWS == 0 && Tk % KT == 0 && (int64_t)(Tq / 64) * heads * nbatch < (1ll << 31));
+    M3_REQUIRE((dtype == DT_BF16 || dtype == DT_F16) && ((int64_t)Tq / 64 + 1) * heads * nbatch < (1ll << 31));
     M3_REQUIRE(q_row_stride % 8 == 0 && kv_row_stride % 8 == 0 && o_row_stride % 4 == 0);
     M3_REQUIRE(kv_batch_shift >= 0);
     AttnArgs a;
@@ -264,23 +278,43 @@ int m3_attention_bf16(const void *Q, const void *K, const void *V, void *O, int 
     a.q_batch_stride = q_batch_stride; a.kv_batch_stride = kv_batch_stride; a.o_batch_stride = o_batch_stride;
     a.Tq = Tq; a.Tk = Tk; a.heads = heads; a.nbatch = nbatch; a.kv_batch_shift = kv_batch_shift;
     a.scale_log2e = scale * 1.4426950408889634f;
-    const int64_t wg128 = (int64_t)(Tq / QROWS) * heads * nbatch;
-    if (wg128 >= 512)
-        hipLaunchKernelGGL(k_attn<2>, dim3((unsigned)wg128), dim3(kThreads), 0, (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL(k_attn<1>, dim3((unsigned)(2 * wg128)), dim3(kThreads), 0, (hipStream_t)stream, a);
-    M3_CHECK_LAUNCH("m3_attention_bf16");
+    const int64_t wg128 = (int64_t)m3_cdiv(Tq, QROWS) * heads * nbatch;
+    const int64_t wg64 = (int64_t)m3_cdiv(Tq, 64) * heads * nbatch;
+    hipStream_t st = (hipStream_t)stream;
+    if (wg128 >= 512) {
+        if (dtype == DT_F16) hipLaunchKernelGGL((k_attn<2, DT_F16>), dim3((unsigned)wg128), dim3(kThreads), 0, st, a);
+        else hipLaunchKernelGGL((k_attn<2, DT_BF16>), dim3((unsigned)wg128), dim3(kThreads), 0, st, a);
+    } else {
+        if (dtype == DT_F16) hipLaunchKernelGGL((k_attn<1, DT_F16>), dim3((unsigned)wg64), dim3(kThreads), 0, st, a);
+        else hipLaunchKernelGGL((k_attn<1, DT_BF16>), dim3((unsigned)wg64), dim3(kThreads), 0, st, a);
+    }
+    M3_CHECK_LAUNCH("m3_attention");
     return M3_OK;
 }
+int m3_attention_bf16(const void *Q, const void *K, const void *V, void *O, int q_row_stride, int kv_row_stride,
+                      int o_row_stride, int64_t q_batch_stride, int64_t kv_batch_stride, int64_t o_batch_stride,
+                      int nbatch, int heads, int Tq, int Tk, int kv_batch_shift, float scale, void *stream) {
+    return m3_attention_dt(Q, K, V, O, q_row_stride, kv_row_stride, o_row_stride, q_batch_stride, kv_batch_stride,
+                           o_batch_stride, nbatch, heads, Tq, Tk, kv_batch_shift, scale, DT_BF16, stream);
+}
 
+int m3_rope2d_dt(void *X, const int32_t *pos_yx, const float *cos_sin, int row_stride, int tokens, int heads,
+                 int tokens_per_image, int dtype, void *stream) {
+    M3_REQUIRE(X && pos_yx && cos_sin && tokens > 0 && heads > 0 && tokens_per_image > 0 && row_stride % 8 == 0);
+    M3_REQUIRE(dtype == DT_BF16 || dtype == DT_F16);
+    const int64_t total = (int64_t)tokens * heads * 2;
+    if (dtype == DT_F16)
+        hipLaunchKernelGGL(k_rope2d<DT_F16>, dim3(m3_cdiv(total, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                           (bf16_t *)X, pos_yx, cos_sin, row_stride, tokens, heads, tokens_per_image);
+    else
+        hipLaunchKernelGGL(k_rope2d<DT_BF16>, dim3(m3_cdiv(total, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                           (bf16_t *)X, pos_yx, cos_sin, row_stride, tokens, heads, tokens_per_image);
+    M3_CHECK_LAUNCH("m3_rope2d");
+    return M3_OK;
+}
 int m3_rope2d_bf16(void *X, const int32_t *pos_yx, const float *cos_sin, int row_stride, int tokens, int heads,
                    int tokens_per_image, void *stream) {
-    M3_REQUIRE(X && pos_yx && cos_sin && tokens > 0 && heads > 0 && tokens_per_image > 0 && row_stride % 8 == 0);
-    const int64_t total = (int64_t)tokens * heads * 2;
-    hipLaunchKernelGGL(k_rope2d, dim3(m3_cdiv(total, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
-                       (bf16_t *)X, pos_yx, cos_sin, row_stride, tokens, heads, tokens_per_image);
-    M3_CHECK_LAUNCH("m3_rope2d_bf16");
-    return M3_OK;
+    return m3_rope2d_dt(X, pos_yx, cos_sin, row_stride, tokens, heads, tokens_per_image, DT_BF16, stream);
 }
 
 }  // extern "C"

@@ -1,24 +1,33 @@
 // HBM-bound helper kernels of the network path (gfx950): LayerNorm, patch extraction,
 // bilinear 2x upsampling, pixel shuffles and the output heads' post-processing.  All are
 // streaming kernels with 8-16 byte vector accesses per lane; none is on the MFMA roofline.
-#include "common.h"
-#include "../../include/m3slam_model.h"
+// Kernels that convert to / from the 16-bit storage type are templated on it (DT_BF16 / DT_F16, gemm_common.h);
+// pure data movement (ReLU by sign bit, concat, un-shuffle) is the same for both.
+#include "gemm_common.h"
 
 namespace {
 
-typedef unsigned short bf16_t;
+using m3gemm::bf16_t;
+using m3gemm::DT_BF16;
+using m3gemm::DT_F16;
+using m3gemm::pack16;
+using m3gemm::lo16;
+using m3gemm::hi16;
 constexpr int kThreads = 256;
 
-__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float((unsigned)v << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
+template <int DT> __device__ __forceinline__ float to_f32(bf16_t v) { return lo16<DT>((unsigned)v); }
+template <int DT> __device__ __forceinline__ bf16_t from_f32(float f) { return (bf16_t)(pack16<DT>(f, 0.f) & 0xffffu); }
+
+#define M3_DT_LAUNCH(dtype, KERNEL, ...)                                                        \
+    do {                                                                                        \
+        if ((dtype) == DT_F16) hipLaunchKernelGGL((KERNEL<DT_F16>), __VA_ARGS__);               \
+        else hipLaunchKernelGGL((KERNEL<DT_BF16>), __VA_ARGS__);                                \
+    } while (0)
+#define M3_DT_OK(dtype) M3_REQUIRE((dtype) == DT_BF16 || (dtype) == DT_F16)
 
 // ---------------------------------------------------------------- LayerNorm: one wave per row
 // x f32 [M,C] -> y bf16 [M,C]; two-pass statistics in fp32 from registers (row read once).
-template <int VPL /* float4 per lane */>
+template <int VPL /* float4 per lane */, int DT>
 __global__ void __launch_bounds__(kThreads)
 k_layernorm(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
             const float *__restrict__ gamma2, const float *__restrict__ beta2, bf16_t *__restrict__ y, int M, int C,
@@ -46,22 +55,21 @@ k_layernorm(const float *__restrict__ x, const float *__restrict__ gamma, const 
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
     const float rstd = rsqrtf(q / (float)C + eps);
-    ushort4 *yr = reinterpret_cast<ushort4 *>(y + (size_t)row * C);
+    uint2 *yr = reinterpret_cast<uint2 *>(y + (size_t)row * C);
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const float4 gm = reinterpret_cast<const float4 *>(gamma)[lane + 64 * i];
         const float4 bt = reinterpret_cast<const float4 *>(beta)[lane + 64 * i];
-        ushort4 o;
-        o.x = f2bf((v[i].x - mean) * rstd * gm.x + bt.x);
-        o.y = f2bf((v[i].y - mean) * rstd * gm.y + bt.y);
-        o.z = f2bf((v[i].z - mean) * rstd * gm.z + bt.z);
-        o.w = f2bf((v[i].w - mean) * rstd * gm.w + bt.w);
+        uint2 o;
+        o.x = pack16<DT>((v[i].x - mean) * rstd * gm.x + bt.x, (v[i].y - mean) * rstd * gm.y + bt.y);
+        o.y = pack16<DT>((v[i].z - mean) * rstd * gm.z + bt.z, (v[i].w - mean) * rstd * gm.w + bt.w);
         yr[lane + 64 * i] = o;
     }
 }
 
 // ---------------------------------------------------------------- patch extraction (im2col of the 16x16/16 conv)
 // img uint8 [B,H,W,3] -> A bf16 [B*(H/16)*(W/16), 768], column = c*256 + py*16 + px, value (v/255-0.5)/0.5
+template <int DT>
 __global__ void __launch_bounds__(kThreads)
 k_patchify(const uint8_t *__restrict__ img, bf16_t *__restrict__ A, int B, int H, int W) {
     const int gw = W / 16, gh = H / 16;
@@ -73,17 +81,30 @@ k_patchify(const uint8_t *__restrict__ img, bf16_t *__restrict__ A, int B, int H
     const int c = col >> 8, py = (col >> 4) & 15, px = col & 15;
     const int tx = (int)(tok % gw), ty = (int)((tok / gw) % gh), b = (int)(tok / ((int64_t)gw * gh));
     const uint8_t v = img[(((size_t)b * H + ty * 16 + py) * W + tx * 16 + px) * 3 + c];
-    A[i] = f2bf(((float)v / 255.0f - 0.5f) / 0.5f);
+    A[i] = from_f32<DT>(((float)v / 255.0f - 0.5f) / 0.5f);
 }
 
 // ---------------------------------------------------------------- generic small elementwise ops
+template <int DT>
 __global__ void __launch_bounds__(kThreads)
-k_f32_to_bf16(const float *__restrict__ x, bf16_t *__restrict__ y, int64_t n4) {
+k_f32_to_16(const float *__restrict__ x, bf16_t *__restrict__ y, int64_t n4) {
     const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (i >= n4) return;
     const float4 v = reinterpret_cast<const float4 *>(x)[i];
-    ushort4 o; o.x = f2bf(v.x); o.y = f2bf(v.y); o.z = f2bf(v.z); o.w = f2bf(v.w);
-    reinterpret_cast<ushort4 *>(y)[i] = o;
+    uint2 o; o.x = pack16<DT>(v.x, v.y); o.y = pack16<DT>(v.z, v.w);
+    reinterpret_cast<uint2 *>(y)[i] = o;
+}
+
+template <int DTI, int DTO>
+__global__ void __launch_bounds__(kThreads)
+k_cast16(const bf16_t *__restrict__ x, bf16_t *__restrict__ y, int64_t n8) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n8) return;
+    union U { uint4 q; unsigned w[4]; } u, o;
+    u.q = reinterpret_cast<const uint4 *>(x)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o.w[k] = pack16<DTO>(lo16<DTI>(u.w[k]), hi16<DTI>(u.w[k]));
+    reinterpret_cast<uint4 *>(y)[i] = o.q;
 }
 
 __global__ void __launch_bounds__(kThreads)
@@ -102,15 +123,16 @@ k_relu_bf16(const bf16_t *__restrict__ x, bf16_t *__restrict__ y, int64_t n8) {
     reinterpret_cast<uint4 *>(y)[i] = v;
 }
 
+template <int DT>
 __global__ void __launch_bounds__(kThreads)
-k_add_bf16(const bf16_t *__restrict__ a, const bf16_t *__restrict__ b, bf16_t *__restrict__ y, int64_t n8) {
+k_add16(const bf16_t *__restrict__ a, const bf16_t *__restrict__ b, bf16_t *__restrict__ y, int64_t n8) {
     const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (i >= n8) return;
-    union U { uint4 q; bf16_t h[8]; } u, v, o;
+    union U { uint4 q; unsigned w[4]; } u, v, o;
     u.q = reinterpret_cast<const uint4 *>(a)[i];
     v.q = reinterpret_cast<const uint4 *>(b)[i];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) o.h[k] = f2bf(bf2f(u.h[k]) + bf2f(v.h[k]));
+    for (int k = 0; k < 4; ++k) o.w[k] = pack16<DT>(lo16<DT>(u.w[k]) + lo16<DT>(v.w[k]), hi16<DT>(u.w[k]) + hi16<DT>(v.w[k]));
     reinterpret_cast<uint4 *>(y)[i] = o.q;
 }
 
@@ -146,7 +168,8 @@ k_unshuffle(const bf16_t *__restrict__ in, bf16_t *__restrict__ out, int B, int 
     *reinterpret_cast<uint4 *>(out + (((size_t)b * h * s + Y) * (w * s) + X) * Cpad + c) = v;
 }
 
-// bilinear x2, align_corners=True, NHWC bf16, C multiple of 8
+// bilinear x2, align_corners=True, NHWC 16-bit, C multiple of 8
+template <int DT>
 __global__ void __launch_bounds__(kThreads)
 k_upsample2x(const bf16_t *__restrict__ in, bf16_t *__restrict__ out, int B, int H, int W, int C) {
     const int OH = 2 * H, OW = 2 * W, c8 = C / 8;
@@ -166,16 +189,18 @@ k_upsample2x(const bf16_t *__restrict__ in, bf16_t *__restrict__ out, int B, int
     const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
     const float wy = fy - (float)y0, wx = fx - (float)x0;
     const bf16_t *base = in + (size_t)b * H * W * C + c;
-    union U { uint4 q; bf16_t h[8]; } a, bq, cq, d, o;
+    union U { uint4 q; unsigned w[4]; } a, bq, cq, d, o;
     a.q = *reinterpret_cast<const uint4 *>(base + ((size_t)y0 * W + x0) * C);
     bq.q = *reinterpret_cast<const uint4 *>(base + ((size_t)y0 * W + x1) * C);
     cq.q = *reinterpret_cast<const uint4 *>(base + ((size_t)y1 * W + x0) * C);
     d.q = *reinterpret_cast<const uint4 *>(base + ((size_t)y1 * W + x1) * C);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const float top = bf2f(a.h[k]) * (1.f - wx) + bf2f(bq.h[k]) * wx;
-        const float bot = bf2f(cq.h[k]) * (1.f - wx) + bf2f(d.h[k]) * wx;
-        o.h[k] = f2bf(top * (1.f - wy) + bot * wy);
+    for (int k = 0; k < 4; ++k) {
+        const float tl = lo16<DT>(a.w[k]) * (1.f - wx) + lo16<DT>(bq.w[k]) * wx;
+        const float bl = lo16<DT>(cq.w[k]) * (1.f - wx) + lo16<DT>(d.w[k]) * wx;
+        const float th = hi16<DT>(a.w[k]) * (1.f - wx) + hi16<DT>(bq.w[k]) * wx;
+        const float bh = hi16<DT>(cq.w[k]) * (1.f - wx) + hi16<DT>(d.w[k]) * wx;
+        o.w[k] = pack16<DT>(tl * (1.f - wy) + bl * wy, th * (1.f - wy) + bh * wy);
     }
     *reinterpret_cast<uint4 *>(out + (((size_t)b * OH + oy) * OW + ox) * C + c) = o.q;
 }
@@ -195,6 +220,7 @@ k_pts_post(const float *__restrict__ in, float *__restrict__ pts, float *__restr
 
 // feature-MLP output [B*gh*gw, 25*256] bf16 (column c*256 + dy*16 + dx) -> pixel shuffle(16) ->
 // desc [B,H,W,24] f32 L2-normalised, desc_conf [B,H,W] f32 = exp(channel 24).  One thread per pixel.
+template <int DT>
 __global__ void __launch_bounds__(kThreads)
 k_desc_post(const bf16_t *__restrict__ in, float *__restrict__ desc, float *__restrict__ dconf, int B, int H, int W) {
     const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
@@ -205,7 +231,7 @@ k_desc_post(const bf16_t *__restrict__ in, float *__restrict__ desc, float *__re
     const bf16_t *row = in + (((size_t)b * gh + y / 16) * gw + x / 16) * 6400 + (y % 16) * 16 + (x % 16);
     float v[25], n2 = 0.f;
 #pragma unroll
-    for (int c = 0; c < 25; ++c) v[c] = bf2f(row[c * 256]);
+    for (int c = 0; c < 25; ++c) v[c] = to_f32<DT>(row[c * 256]);
 #pragma unroll
     for (int c = 0; c < 24; ++c) n2 += v[c] * v[c];
     const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
@@ -219,51 +245,81 @@ k_desc_post(const bf16_t *__restrict__ in, float *__restrict__ desc, float *__re
 
 extern "C" {
 
-int m3_layernorm_bf16(const float *x, const float *gamma, const float *beta, void *y, int M, int C, float eps,
-                      void *stream) {
+#define M3_LN_CASES(DTV)                                                                                                \
+    switch (C / 256) {                                                                                                  \
+        M3_LN(1, DTV); M3_LN(2, DTV); M3_LN(3, DTV); M3_LN(4, DTV); M3_LN(5, DTV); M3_LN(6, DTV); M3_LN(7, DTV); M3_LN(8, DTV); \
+        default: return M3_ERR_UNSUPPORTED;                                                                             \
+    }
+
+int m3_layernorm_dt(const float *x, const float *gamma, const float *beta, void *y, int M, int C, float eps, int dtype,
+                    void *stream) {
     M3_REQUIRE(x && gamma && beta && y && M > 0 && C > 0 && C % 256 == 0 && C <= 2048);
+    M3_DT_OK(dtype);
     dim3 grid(m3_cdiv(M, kThreads / 64)), blk(kThreads);
     hipStream_t st = (hipStream_t)stream;
-#define M3_LN(V) case V: hipLaunchKernelGGL(k_layernorm<V>, grid, blk, 0, st, x, gamma, beta, gamma, beta, (bf16_t *)y, M, C, M, 0, eps); break
-    switch (C / 256) {
-        M3_LN(1); M3_LN(2); M3_LN(3); M3_LN(4); M3_LN(5); M3_LN(6); M3_LN(7); M3_LN(8);
-        default: return M3_ERR_UNSUPPORTED;
-    }
+#define M3_LN(V, DTV) case V: hipLaunchKernelGGL((k_layernorm<V, DTV>), grid, blk, 0, st, x, gamma, beta, gamma, beta, (bf16_t *)y, M, C, M, 0, eps); break
+    if (dtype == DT_F16) { M3_LN_CASES(DT_F16) } else { M3_LN_CASES(DT_BF16) }
 #undef M3_LN
-    M3_CHECK_LAUNCH("m3_layernorm_bf16");
+    M3_CHECK_LAUNCH("m3_layernorm");
     return M3_OK;
 }
+int m3_layernorm_bf16(const float *x, const float *gamma, const float *beta, void *y, int M, int C, float eps,
+                      void *stream) {
+    return m3_layernorm_dt(x, gamma, beta, y, M, C, eps, DT_BF16, stream);
+}
 
-int m3_layernorm_bf16_grouped2(const float *x, const float *gamma0, const float *beta0, const float *gamma1,
-                               const float *beta1, void *y, int M, int C, int in_row_shift, float eps, void *stream) {
+int m3_layernorm_grouped2_dt(const float *x, const float *gamma0, const float *beta0, const float *gamma1,
+                             const float *beta1, void *y, int M, int C, int in_row_shift, float eps, int dtype,
+                             void *stream) {
     M3_REQUIRE(x && gamma0 && beta0 && gamma1 && beta1 && y && M > 0 && C > 0 && C % 256 == 0 && C <= 2048);
     M3_REQUIRE(in_row_shift == 0 || in_row_shift == M);
+    M3_DT_OK(dtype);
     dim3 grid(m3_cdiv(2 * M, kThreads / 64)), blk(kThreads);
     hipStream_t st = (hipStream_t)stream;
-#define M3_LN(V) case V: hipLaunchKernelGGL(k_layernorm<V>, grid, blk, 0, st, x, gamma0, beta0, gamma1, beta1, (bf16_t *)y, 2 * M, C, M, in_row_shift, eps); break
-    switch (C / 256) {
-        M3_LN(1); M3_LN(2); M3_LN(3); M3_LN(4); M3_LN(5); M3_LN(6); M3_LN(7); M3_LN(8);
-        default: return M3_ERR_UNSUPPORTED;
-    }
+#define M3_LN(V, DTV) case V: hipLaunchKernelGGL((k_layernorm<V, DTV>), grid, blk, 0, st, x, gamma0, beta0, gamma1, beta1, (bf16_t *)y, 2 * M, C, M, in_row_shift, eps); break
+    if (dtype == DT_F16) { M3_LN_CASES(DT_F16) } else { M3_LN_CASES(DT_BF16) }
 #undef M3_LN
-    M3_CHECK_LAUNCH("m3_layernorm_bf16_grouped2");
+    M3_CHECK_LAUNCH("m3_layernorm_grouped2");
     return M3_OK;
 }
+int m3_layernorm_bf16_grouped2(const float *x, const float *gamma0, const float *beta0, const float *gamma1,
+                               const float *beta1, void *y, int M, int C, int in_row_shift, float eps, void *stream) {
+    return m3_layernorm_grouped2_dt(x, gamma0, beta0, gamma1, beta1, y, M, C, in_row_shift, eps, DT_BF16, stream);
+}
 
-int m3_patchify16(const uint8_t *img, void *A, int B, int H, int W, void *stream) {
+int m3_patchify16_dt(const uint8_t *img, void *A, int B, int H, int W, int dtype, void *stream) {
     M3_REQUIRE(img && A && B > 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0);
+    M3_DT_OK(dtype);
     const int64_t total = (int64_t)B * (H / 16) * (W / 16) * 768;
-    hipLaunchKernelGGL(k_patchify, dim3(m3_cdiv(total, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, img,
-                       (bf16_t *)A, B, H, W);
+    M3_DT_LAUNCH(dtype, k_patchify, dim3(m3_cdiv(total, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, img,
+                 (bf16_t *)A, B, H, W);
     M3_CHECK_LAUNCH("m3_patchify16");
     return M3_OK;
 }
+int m3_patchify16(const uint8_t *img, void *A, int B, int H, int W, void *stream) {
+    return m3_patchify16_dt(img, A, B, H, W, DT_BF16, stream);
+}
 
-int m3_f32_to_bf16(const float *x, void *y, int64_t n, void *stream) {
+int m3_cast_f32_dt(const float *x, void *y, int64_t n, int dtype, void *stream) {
     M3_REQUIRE(x && y && n > 0 && n % 4 == 0);
-    hipLaunchKernelGGL(k_f32_to_bf16, dim3(m3_cdiv(n / 4, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, x,
-                       (bf16_t *)y, n / 4);
-    M3_CHECK_LAUNCH("m3_f32_to_bf16");
+    M3_DT_OK(dtype);
+    M3_DT_LAUNCH(dtype, k_f32_to_16, dim3(m3_cdiv(n / 4, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, x,
+                 (bf16_t *)y, n / 4);
+    M3_CHECK_LAUNCH("m3_cast_f32");
+    return M3_OK;
+}
+int m3_f32_to_bf16(const float *x, void *y, int64_t n, void *stream) { return m3_cast_f32_dt(x, y, n, DT_BF16, stream); }
+
+int m3_cast16(const void *x, void *y, int64_t n, int from_dtype, int to_dtype, void *stream) {
+    M3_REQUIRE(x && y && n > 0 && n % 8 == 0);
+    M3_DT_OK(from_dtype); M3_DT_OK(to_dtype);
+    M3_REQUIRE(from_dtype != to_dtype);
+    const dim3 grid(m3_cdiv(n / 8, kThreads)), blk(kThreads);
+    if (from_dtype == DT_BF16)
+        hipLaunchKernelGGL((k_cast16<DT_BF16, DT_F16>), grid, blk, 0, (hipStream_t)stream, (const bf16_t *)x, (bf16_t *)y, n / 8);
+    else
+        hipLaunchKernelGGL((k_cast16<DT_F16, DT_BF16>), grid, blk, 0, (hipStream_t)stream, (const bf16_t *)x, (bf16_t *)y, n / 8);
+    M3_CHECK_LAUNCH("m3_cast16");
     return M3_OK;
 }
 
@@ -275,13 +331,15 @@ int m3_relu_bf16(const void *x, void *y, int64_t n, void *stream) {
     return M3_OK;
 }
 
-int m3_add_bf16(const void *a, const void *b, void *y, int64_t n, void *stream) {
+int m3_add_dt(const void *a, const void *b, void *y, int64_t n, int dtype, void *stream) {
     M3_REQUIRE(a && b && y && n > 0 && n % 8 == 0);
-    hipLaunchKernelGGL(k_add_bf16, dim3(m3_cdiv(n / 8, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
-                       (const bf16_t *)a, (const bf16_t *)b, (bf16_t *)y, n / 8);
-    M3_CHECK_LAUNCH("m3_add_bf16");
+    M3_DT_OK(dtype);
+    M3_DT_LAUNCH(dtype, k_add16, dim3(m3_cdiv(n / 8, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                 (const bf16_t *)a, (const bf16_t *)b, (bf16_t *)y, n / 8);
+    M3_CHECK_LAUNCH("m3_add");
     return M3_OK;
 }
+int m3_add_bf16(const void *a, const void *b, void *y, int64_t n, void *stream) { return m3_add_dt(a, b, y, n, DT_BF16, stream); }
 
 int m3_concat2_bf16(const void *a, const void *b, void *out, int64_t M, int Ca, int Cb, void *stream) {
     M3_REQUIRE(a && b && out && M > 0 && Ca > 0 && Cb > 0 && Ca % 8 == 0 && Cb % 8 == 0);
@@ -301,13 +359,17 @@ int m3_unshuffle_bf16(const void *in, void *out, int B, int h, int w, int s, int
     return M3_OK;
 }
 
-int m3_upsample2x_bf16(const void *in, void *out, int B, int H, int W, int C, void *stream) {
+int m3_upsample2x_dt(const void *in, void *out, int B, int H, int W, int C, int dtype, void *stream) {
     M3_REQUIRE(in && out && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0);
+    M3_DT_OK(dtype);
     const int64_t total = (int64_t)B * 2 * H * 2 * W * (C / 8);
-    hipLaunchKernelGGL(k_upsample2x, dim3(m3_cdiv(total, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
-                       (const bf16_t *)in, (bf16_t *)out, B, H, W, C);
-    M3_CHECK_LAUNCH("m3_upsample2x_bf16");
+    M3_DT_LAUNCH(dtype, k_upsample2x, dim3(m3_cdiv(total, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                 (const bf16_t *)in, (bf16_t *)out, B, H, W, C);
+    M3_CHECK_LAUNCH("m3_upsample2x");
     return M3_OK;
+}
+int m3_upsample2x_bf16(const void *in, void *out, int B, int H, int W, int C, void *stream) {
+    return m3_upsample2x_dt(in, out, B, H, W, C, DT_BF16, stream);
 }
 
 int m3_pts_post(const float *in, float *pts, float *conf, int64_t P, void *stream) {
@@ -317,13 +379,17 @@ int m3_pts_post(const float *in, float *pts, float *conf, int64_t P, void *strea
     return M3_OK;
 }
 
-int m3_desc_post(const void *in, float *desc, float *dconf, int B, int H, int W, void *stream) {
+int m3_desc_post_dt(const void *in, float *desc, float *dconf, int B, int H, int W, int dtype, void *stream) {
     M3_REQUIRE(in && desc && dconf && B > 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0);
+    M3_DT_OK(dtype);
     const int64_t P = (int64_t)B * H * W;
-    hipLaunchKernelGGL(k_desc_post, dim3(m3_cdiv(P, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
-                       (const bf16_t *)in, desc, dconf, B, H, W);
+    M3_DT_LAUNCH(dtype, k_desc_post, dim3(m3_cdiv(P, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                 (const bf16_t *)in, desc, dconf, B, H, W);
     M3_CHECK_LAUNCH("m3_desc_post");
     return M3_OK;
+}
+int m3_desc_post(const void *in, float *desc, float *dconf, int B, int H, int W, void *stream) {
+    return m3_desc_post_dt(in, desc, dconf, B, H, W, DT_BF16, stream);
 }
 
 }  // extern "C"

@@ -26,7 +26,7 @@ namespace {
 constexpr int BM = 128, BN = 128;                         // default tile; T = 64 gives 64x64 tiles (latency regime)
 constexpr int kThreads = 256;
 
-template <int MODE /*0 dense, 1 conv3x3*/, int EPI, int T = 128>
+template <int MODE /*0 dense, 1 conv3x3*/, int EPI, int T, int DT>
 __global__ void __launch_bounds__(kThreads)
 k_gemm(const GemmArgs gin) {
     constexpr int BM = T, BN = T;
@@ -139,13 +139,14 @@ k_gemm(const GemmArgs gin) {
             for (int i = 0; i < NT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma16<DT>(wf[j], af[i], acc[i][j]);
         }
         __builtin_amdgcn_s_barrier();      // all waves done reading `buf` before it is restaged
     }
 
     if constexpr (EPI == EPI_RELU_HEAD4) {
-        // DPT head tail fused into the last 3x3 convolution (N = 128 = one tile column): h = bf16(relu(acc + b)),
+        // DPT head tail fused into the last 3x3 convolution (N = 128 = one tile column): h = relu(acc + b) kept in
+        // fp32 (the 16-bit rounding of this map was the largest single contribution to the pointmap error),
         // raw[o] = sum_n h[n] W4[o][n] + b4[o] (o < 4), then the pointmap post-processing of k_pts_post.  Saves
         // writing and re-reading the full-resolution 128-channel map (537 MB each way for 8 pairs) and two launches.
         static_assert(T == 128, "head fusion needs the 128-wide tile");
@@ -162,16 +163,13 @@ k_gemm(const GemmArgs gin) {
             float w4[4][4];
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
-                const ushort4 q = *reinterpret_cast<const ushort4 *>(g.W2 + (size_t)o * g.N + n);
-                w4[o][0] = bf2f(q.x); w4[o][1] = bf2f(q.y); w4[o][2] = bf2f(q.z); w4[o][3] = bf2f(q.w);
+                const uint2 q = *reinterpret_cast<const uint2 *>(g.W2 + (size_t)o * g.N + n);
+                w4[o][0] = lo16<DT>(q.x); w4[o][1] = hi16<DT>(q.x); w4[o][2] = lo16<DT>(q.y); w4[o][3] = hi16<DT>(q.y);
             }
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const f32x4 a = acc[i][j];
-                const unsigned p01 = pack_bf16(fmaxf(a[0] + b.x, 0.f), fmaxf(a[1] + b.y, 0.f));
-                const unsigned p23 = pack_bf16(fmaxf(a[2] + b.z, 0.f), fmaxf(a[3] + b.w, 0.f));
-                const float h[4] = {__uint_as_float(p01 << 16), __uint_as_float(p01 & 0xffff0000u),
-                                    __uint_as_float(p23 << 16), __uint_as_float(p23 & 0xffff0000u)};
+                const float h[4] = {fmaxf(a[0] + b.x, 0.f), fmaxf(a[1] + b.y, 0.f), fmaxf(a[2] + b.z, 0.f), fmaxf(a[3] + b.w, 0.f)};
 #pragma unroll
                 for (int o = 0; o < 4; ++o)
                     part[i][o] += (h[0] * w4[o][0] + h[1] * w4[o][1]) + (h[2] * w4[o][2] + h[3] * w4[o][3]);
@@ -211,18 +209,18 @@ k_gemm(const GemmArgs gin) {
         }
     } else {
         // ---- epilogue: row-contiguous stores through a per-wave LDS scratch (gemm_common.h) --------
-        epilogue_rows<EPI, NT, NT>(g, acc, lds + wave * (NT == 4 ? 9216 : 4608), m0 + wr * (T / 2), n0 + wc * (T / 2), lane);
+        epilogue_rows<EPI, NT, NT, DT>(g, acc, lds + wave * (NT == 4 ? 9216 : 4608), m0 + wr * (T / 2), n0 + wc * (T / 2), lane);
     }
 }
 
-template <int MODE, int T = 128>
-int launch(const GemmArgs &a, int epi, hipStream_t st) {
+template <int MODE, int T, int DT>
+int launch_dt(const GemmArgs &a, int epi, hipStream_t st) {
     constexpr int kLdsBytes = 2 * (2 * T) * BK * 2;      // 64 KiB (32 KiB)
     const int tiles = m3_cdiv(a.M, T) * m3_cdiv(a.N, T);
     dim3 grid(tiles, a.groups > 1 ? a.groups : 1, a.splits > 1 ? a.splits : 1), blk(kThreads);
-#define M3_L(E) case E: hipLaunchKernelGGL((k_gemm<MODE, E, T>), grid, blk, kLdsBytes, st, a); break
+#define M3_L(E) case E: hipLaunchKernelGGL((k_gemm<MODE, E, T, DT>), grid, blk, kLdsBytes, st, a); break
     if (epi == EPI_RELU_HEAD4) {
-        if constexpr (MODE == 1 && T == 128) hipLaunchKernelGGL((k_gemm<1, EPI_RELU_HEAD4, 128>), grid, blk, kLdsBytes, st, a);
+        if constexpr (MODE == 1 && T == 128) hipLaunchKernelGGL((k_gemm<1, EPI_RELU_HEAD4, 128, DT>), grid, blk, kLdsBytes, st, a);
         else return M3_ERR_INVALID_ARG;
     } else
     switch (epi) {
@@ -232,6 +230,11 @@ int launch(const GemmArgs &a, int epi, hipStream_t st) {
 #undef M3_L
     M3_CHECK_LAUNCH("m3_gemm");
     return M3_OK;
+}
+
+template <int MODE, int T = 128>
+int launch(const GemmArgs &a, int epi, hipStream_t st) {
+    return a.dt == DT_F16 ? launch_dt<MODE, T, DT_F16>(a, epi, st) : launch_dt<MODE, T, DT_BF16>(a, epi, st);
 }
 
 // Tile choice: the 256-row ping-pong kernel runs one workgroup per CU, the 128x128 kernel two.
@@ -284,7 +287,7 @@ int pick_splits(int pix_per_image, int N, int K) {
     return s < 2 ? 1 : (int)s;
 }
 
-template <int EPI>
+template <int EPI, int DT>
 __global__ void __launch_bounds__(256)
 k_splitk_finish(const GemmArgs g, const float *__restrict__ part, int S) {
     const int nq = g.N / 4;
@@ -298,7 +301,7 @@ k_splitk_finish(const GemmArgs g, const float *__restrict__ part, int S) {
         const float4 b = *reinterpret_cast<const float4 *>(p + s * plane);
         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
-    store_tile<EPI>(g, f32x4{a.x, a.y, a.z, a.w}, m, n);
+    store_tile<EPI, DT>(g, f32x4{a.x, a.y, a.z, a.w}, m, n);
 }
 
 template <int MODE>
@@ -308,7 +311,10 @@ int run_split(const GemmArgs &a, int S, int epi, void *ws, hipStream_t st) {
     const int rc = launch<MODE>(p, EPI_F32, st);
     if (rc != M3_OK) return rc;
     const dim3 grid((unsigned)m3_cdiv((long)a.M * (a.N / 4), 256L));
-#define M3_F(E) case E: hipLaunchKernelGGL((k_splitk_finish<E>), grid, dim3(256), 0, st, a, (const float *)ws, S); break
+#define M3_F(E) case E:                                                                                        \
+        if (a.dt == DT_F16) hipLaunchKernelGGL((k_splitk_finish<E, DT_F16>), grid, dim3(256), 0, st, a, (const float *)ws, S); \
+        else hipLaunchKernelGGL((k_splitk_finish<E, DT_BF16>), grid, dim3(256), 0, st, a, (const float *)ws, S);      \
+        break
     switch (epi) {
         M3_F(EPI_BF16); M3_F(EPI_BF16_GELU); M3_F(EPI_F32); M3_F(EPI_F32_ACCUM); M3_F(EPI_BF16_RELU); M3_F(EPI_BF16_ADD);
         default: return M3_ERR_INVALID_ARG;
@@ -330,42 +336,53 @@ int m3_gemm_pick_tile(int M, int N, int groups) {
     return pick_tile(M, N, groups > 1 ? groups : 1);
 }
 
-int m3_gemm_bf16(const void *A, const void *W, const float *bias, void *C, const void *R, int M, int N, int K,
-                 int ldc, int epilogue, void *stream) {
-    M3_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0);
+static bool dt_ok(int dtype) { return dtype == DT_BF16 || dtype == DT_F16; }
+
+int m3_gemm_dt(const void *A, const void *W, const float *bias, void *C, const void *R, int M, int N, int K,
+               int ldc, int epilogue, int dtype, void *stream) {
+    M3_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0 && dt_ok(dtype));
     M3_REQUIRE(K % BK == 0 && N % 4 == 0 && ldc >= N && ldc % 4 == 0 && epilogue != EPI_BF16_ROPE);
     M3_REQUIRE(!((epilogue == EPI_F32_ACCUM || epilogue == EPI_BF16_ADD) && !R));
     GemmArgs a{};
     a.A = (const bf16_t *)A; a.W = (const bf16_t *)W; a.bias = bias; a.C = C; a.R = R;
-    a.M = M; a.N = N; a.K = K; a.ldc = ldc;
+    a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.dt = dtype;
     const int tile = pick_tile(M, N);
     if (tile >= 192) return m3_launch_gemm256_dense(a, epilogue, tile, (hipStream_t)stream);
     if (tile == 64) return launch<0, 64>(a, epilogue, (hipStream_t)stream);
     return launch<0>(a, epilogue, (hipStream_t)stream);
 }
+int m3_gemm_bf16(const void *A, const void *W, const float *bias, void *C, const void *R, int M, int N, int K,
+                 int ldc, int epilogue, void *stream) {
+    return m3_gemm_dt(A, W, bias, C, R, M, N, K, ldc, epilogue, DT_BF16, stream);
+}
 
-int m3_gemm_bf16_rope(const void *A, const void *W, const float *bias, void *C, int M, int N, int K, int ldc,
-                      const int32_t *pos_yx, const float *cos_sin, int tokens_per_image, int rope_cols,
-                      void *stream) {
-    M3_REQUIRE(A && W && C && pos_yx && cos_sin && M > 0 && N > 0 && K > 0 && tokens_per_image > 0);
+int m3_gemm_rope_dt(const void *A, const void *W, const float *bias, void *C, int M, int N, int K, int ldc,
+                    const int32_t *pos_yx, const float *cos_sin, int tokens_per_image, int rope_cols, int dtype,
+                    void *stream) {
+    M3_REQUIRE(A && W && C && pos_yx && cos_sin && M > 0 && N > 0 && K > 0 && tokens_per_image > 0 && dt_ok(dtype));
     M3_REQUIRE(K % BK == 0 && N % 64 == 0 && ldc >= N && ldc % 4 == 0 && rope_cols % 64 == 0 && rope_cols <= N);
     GemmArgs a{};
     a.A = (const bf16_t *)A; a.W = (const bf16_t *)W; a.bias = bias; a.C = C;
-    a.M = M; a.N = N; a.K = K; a.ldc = ldc;
+    a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.dt = dtype;
     a.pos_yx = pos_yx; a.cos_sin = cos_sin; a.tokens_per_image = tokens_per_image; a.rope_cols = rope_cols;
     const int tile = pick_tile(M, N);
     if (tile >= 192) return m3_launch_gemm256_dense(a, EPI_BF16_ROPE, tile, (hipStream_t)stream);
     if (tile == 64) return launch<0, 64>(a, EPI_BF16_ROPE, (hipStream_t)stream);
     return launch<0>(a, EPI_BF16_ROPE, (hipStream_t)stream);
 }
+int m3_gemm_bf16_rope(const void *A, const void *W, const float *bias, void *C, int M, int N, int K, int ldc,
+                      const int32_t *pos_yx, const float *cos_sin, int tokens_per_image, int rope_cols,
+                      void *stream) {
+    return m3_gemm_rope_dt(A, W, bias, C, M, N, K, ldc, pos_yx, cos_sin, tokens_per_image, rope_cols, DT_BF16, stream);
+}
 
 // Two GEMMs of identical shape in one launch (the two decoder branches / the two heads):
 // group g reads A + g*a_gstride, weights W[g], bias[g] and writes C + g*c_gstride.
-int m3_gemm_bf16_grouped2(const void *A, const void *W0, const void *W1, const float *bias0, const float *bias1,
-                          void *C, const void *R, int M, int N, int K, int ldc, int64_t a_gstride,
-                          int64_t c_gstride, int epilogue, const int32_t *pos_yx, const float *cos_sin,
-                          int tokens_per_image, int rope_cols, void *stream) {
-    M3_REQUIRE(A && W0 && W1 && C && M > 0 && N > 0 && K > 0);
+int m3_gemm_grouped2_dt(const void *A, const void *W0, const void *W1, const float *bias0, const float *bias1,
+                        void *C, const void *R, int M, int N, int K, int ldc, int64_t a_gstride,
+                        int64_t c_gstride, int epilogue, const int32_t *pos_yx, const float *cos_sin,
+                        int tokens_per_image, int rope_cols, int dtype, void *stream) {
+    M3_REQUIRE(A && W0 && W1 && C && M > 0 && N > 0 && K > 0 && dt_ok(dtype));
     M3_REQUIRE(K % BK == 0 && N % 4 == 0 && ldc >= N && ldc % 4 == 0);
     M3_REQUIRE(!((epilogue == EPI_F32_ACCUM || epilogue == EPI_BF16_ADD) && !R));
     M3_REQUIRE((bias0 == nullptr) == (bias1 == nullptr));
@@ -373,13 +390,20 @@ int m3_gemm_bf16_grouped2(const void *A, const void *W0, const void *W1, const f
         M3_REQUIRE(pos_yx && cos_sin && tokens_per_image > 0 && N % 64 == 0 && rope_cols % 64 == 0 && rope_cols <= N);
     GemmArgs a{};
     a.A = (const bf16_t *)A; a.W = (const bf16_t *)W0; a.W2 = (const bf16_t *)W1; a.bias = bias0; a.bias2 = bias1;
-    a.C = C; a.R = R; a.M = M; a.N = N; a.K = K; a.ldc = ldc;
+    a.C = C; a.R = R; a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.dt = dtype;
     a.a_gstride = a_gstride; a.c_gstride = c_gstride; a.groups = 2;
     a.pos_yx = pos_yx; a.cos_sin = cos_sin; a.tokens_per_image = tokens_per_image; a.rope_cols = rope_cols;
     const int tile = pick_tile(M, N, 2);
     if (tile >= 192) return m3_launch_gemm256_dense(a, epilogue, tile, (hipStream_t)stream);
     if (tile == 64) return launch<0, 64>(a, epilogue, (hipStream_t)stream);
     return launch<0>(a, epilogue, (hipStream_t)stream);
+}
+int m3_gemm_bf16_grouped2(const void *A, const void *W0, const void *W1, const float *bias0, const float *bias1,
+                          void *C, const void *R, int M, int N, int K, int ldc, int64_t a_gstride,
+                          int64_t c_gstride, int epilogue, const int32_t *pos_yx, const float *cos_sin,
+                          int tokens_per_image, int rope_cols, void *stream) {
+    return m3_gemm_grouped2_dt(A, W0, W1, bias0, bias1, C, R, M, N, K, ldc, a_gstride, c_gstride, epilogue, pos_yx,
+                               cos_sin, tokens_per_image, rope_cols, DT_BF16, stream);
 }
 
 int64_t m3_conv3x3_splitk_bytes(int B, int H, int Wd, int Cin, int Cout, int stride) {
@@ -389,10 +413,10 @@ int64_t m3_conv3x3_splitk_bytes(int B, int H, int Wd, int Cin, int Cout, int str
     return S > 1 ? (int64_t)S * B * OH * OW * Cout * 4 : 0;
 }
 
-int m3_conv3x3_bf16(const void *X, const void *W, const float *bias, void *Y, const void *R, const void *zero16,
-                    int B, int H, int Wd, int Cin, int Cout, int stride, int epilogue, void *splitk_ws,
-                    int64_t splitk_ws_bytes, void *stream) {
-    M3_REQUIRE(X && W && Y && zero16 && B > 0 && H > 0 && Wd > 0 && Cin > 0 && Cout > 0);
+int m3_conv3x3_dt(const void *X, const void *W, const float *bias, void *Y, const void *R, const void *zero16,
+                  int B, int H, int Wd, int Cin, int Cout, int stride, int epilogue, void *splitk_ws,
+                  int64_t splitk_ws_bytes, int dtype, void *stream) {
+    M3_REQUIRE(X && W && Y && zero16 && B > 0 && H > 0 && Wd > 0 && Cin > 0 && Cout > 0 && dt_ok(dtype));
     M3_REQUIRE(Cin % BK == 0 && Cout % 4 == 0 && (stride == 1 || stride == 2) && epilogue != EPI_BF16_ROPE);
     M3_REQUIRE(!((epilogue == EPI_F32_ACCUM || epilogue == EPI_BF16_ADD) && !R));
     GemmArgs a{};
@@ -400,7 +424,7 @@ int m3_conv3x3_bf16(const void *X, const void *W, const float *bias, void *Y, co
     a.zero16 = (const bf16_t *)zero16;
     a.H = H; a.Wd = Wd; a.Cin = Cin; a.stride = stride;
     a.OH = (H + 2 - 3) / stride + 1; a.OW = (Wd + 2 - 3) / stride + 1;
-    a.M = B * a.OH * a.OW; a.N = Cout; a.K = 9 * Cin; a.ldc = Cout;
+    a.M = B * a.OH * a.OW; a.N = Cout; a.K = 9 * Cin; a.ldc = Cout; a.dt = dtype;
     // split-K is decided by the per-image geometry alone; a shape that wants it must be given its scratch
     const int S = pick_splits(a.OH * a.OW, Cout, a.K);
     if (S > 1) {
@@ -412,19 +436,32 @@ int m3_conv3x3_bf16(const void *X, const void *W, const float *bias, void *Y, co
     return launch<1>(a, epilogue, (hipStream_t)stream);
 }
 
+int m3_conv3x3_bf16(const void *X, const void *W, const float *bias, void *Y, const void *R, const void *zero16,
+                    int B, int H, int Wd, int Cin, int Cout, int stride, int epilogue, void *splitk_ws,
+                    int64_t splitk_ws_bytes, void *stream) {
+    return m3_conv3x3_dt(X, W, bias, Y, R, zero16, B, H, Wd, Cin, Cout, stride, epilogue, splitk_ws, splitk_ws_bytes,
+                         DT_BF16, stream);
+}
+
 // Last stage of the DPT head in one launch: Y = relu(conv3x3(X) + bias) (Cout = 128, never written),
 // raw = Y . W4^T + b4 (4 channels), pts = xyz / |xyz| * expm1(|xyz|), conf = 1 + exp(raw[3]).
-int m3_conv3x3_relu_head4(const void *X, const void *W, const float *bias, const void *W4, const float *b4,
-                          float *pts, float *conf, const void *zero16, int B, int H, int Wd, int Cin, void *stream) {
+int m3_conv3x3_relu_head4_dt(const void *X, const void *W, const float *bias, const void *W4, const float *b4,
+                             float *pts, float *conf, const void *zero16, int B, int H, int Wd, int Cin, int dtype,
+                             void *stream) {
     M3_REQUIRE(X && W && W4 && b4 && pts && conf && zero16 && B > 0 && H > 0 && Wd > 0 && Cin > 0 && Cin % BK == 0);
+    M3_REQUIRE(dt_ok(dtype));
     M3_REQUIRE((int64_t)B * H * Wd < (1ll << 31));
     GemmArgs a{};
     a.A = (const bf16_t *)X; a.W = (const bf16_t *)W; a.bias = bias; a.C = pts; a.C2 = conf;
     a.W2 = (const bf16_t *)W4; a.bias2 = b4;
     a.zero16 = (const bf16_t *)zero16;
     a.H = H; a.Wd = Wd; a.Cin = Cin; a.stride = 1; a.OH = H; a.OW = Wd;
-    a.M = B * H * Wd; a.N = 128; a.K = 9 * Cin; a.ldc = 3;
+    a.M = B * H * Wd; a.N = 128; a.K = 9 * Cin; a.ldc = 3; a.dt = dtype;
     return launch<1>(a, EPI_RELU_HEAD4, (hipStream_t)stream);
+}
+int m3_conv3x3_relu_head4(const void *X, const void *W, const float *bias, const void *W4, const float *b4,
+                          float *pts, float *conf, const void *zero16, int B, int H, int Wd, int Cin, void *stream) {
+    return m3_conv3x3_relu_head4_dt(X, W, bias, W4, b4, pts, conf, zero16, B, H, Wd, Cin, DT_BF16, stream);
 }
 
 }  // extern "C"

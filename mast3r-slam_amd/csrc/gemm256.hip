@@ -26,7 +26,7 @@ namespace {
 constexpr int BM = 256;
 constexpr int kThreads = 512;
 
-template <int MODE /*0 dense, 1 conv3x3*/, int EPI, int BN>
+template <int MODE /*0 dense, 1 conv3x3*/, int EPI, int BN, int DT>
 __global__ void __launch_bounds__(kThreads, 2)
 k_gemm256(const GemmArgs gin) {
     constexpr int WN = BN == 256 ? 4 : 2, WM = 8 / WN;      // wave grid
@@ -143,7 +143,7 @@ k_gemm256(const GemmArgs gin) {
         for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = mfma16<DT>(wf[j], af[i], acc[i][j]);
         __builtin_amdgcn_s_setprio(0);
     };
     auto phase_end = [&]() {
@@ -201,10 +201,10 @@ k_gemm256(const GemmArgs gin) {
 
     // epilogue: the operand stages are dead after the last barrier; each wave transposes its sub-tile
     // through a private LDS scratch (9 / 13 KiB) and stores full rows (gemm_common.h)
-    epilogue_rows<EPI, NI, NJ>(g, acc, lds + wave * (64 * (32 * NJ + 16)), m0 + wr * (16 * NI), n0 + wc * (16 * NJ), lane);
+    epilogue_rows<EPI, NI, NJ, DT>(g, acc, lds + wave * (64 * (32 * NJ + 16)), m0 + wr * (16 * NI), n0 + wc * (16 * NJ), lane);
 }
 
-template <int MODE, int BN>
+template <int MODE, int BN, int DT>
 int launch256(const GemmArgs &a, int epi, hipStream_t st) {
     constexpr int kLdsBytes = 2 * (BM + BN) * BK * 2;    // 128 KiB / 112 KiB
     const int tiles = m3_cdiv(a.M, BM) * m3_cdiv(a.N, BN);
@@ -213,12 +213,12 @@ int launch256(const GemmArgs &a, int epi, hipStream_t st) {
     case E: {                                                                                                \
         static bool attr_set = false;                                                                        \
         if (!attr_set) {                                                                                     \
-            M3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm256<MODE, E, BN>),        \
+            M3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm256<MODE, E, BN, DT>),        \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes),         \
                          "m3_gemm256/attr");                                                                 \
             attr_set = true;                                                                                 \
         }                                                                                                    \
-        hipLaunchKernelGGL((k_gemm256<MODE, E, BN>), grid, blk, kLdsBytes, st, a);                           \
+        hipLaunchKernelGGL((k_gemm256<MODE, E, BN, DT>), grid, blk, kLdsBytes, st, a);                           \
     } break
     switch (epi) {
         M3_L(EPI_BF16); M3_L(EPI_BF16_GELU); M3_L(EPI_F32); M3_L(EPI_F32_ACCUM); M3_L(EPI_BF16_RELU); M3_L(EPI_BF16_ADD); M3_L(EPI_BF16_ROPE);
@@ -233,6 +233,9 @@ int launch256(const GemmArgs &a, int epi, hipStream_t st) {
 
 // entry points used by gemm.hip's dispatcher
 int m3_launch_gemm256_dense(const GemmArgs &a, int epi, int bn, hipStream_t st) {
-    return bn == 192 ? launch256<0, 192>(a, epi, st) : launch256<0, 256>(a, epi, st);
+    if (a.dt == DT_F16) return bn == 192 ? launch256<0, 192, DT_F16>(a, epi, st) : launch256<0, 256, DT_F16>(a, epi, st);
+    return bn == 192 ? launch256<0, 192, DT_BF16>(a, epi, st) : launch256<0, 256, DT_BF16>(a, epi, st);
 }
-int m3_launch_gemm256_conv(const GemmArgs &a, int epi, hipStream_t st) { return launch256<1, 256>(a, epi, st); }
+int m3_launch_gemm256_conv(const GemmArgs &a, int epi, hipStream_t st) {
+    return a.dt == DT_F16 ? launch256<1, 256, DT_F16>(a, epi, st) : launch256<1, 256, DT_BF16>(a, epi, st);
+}

@@ -48,6 +48,32 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     return r;
 }
 
+// ---- 16-bit storage type of a launch: DT = 0 bf16 (v_mfma_f32_16x16x32_bf16), DT = 1 IEEE fp16
+// (v_mfma_f32_16x16x32_f16, same issue rate).  Operands, 16-bit outputs and 16-bit residuals of one
+// launch share the type; accumulation is fp32 either way.
+enum { DT_BF16 = 0, DT_F16 = 1 };
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <int DT> __device__ __forceinline__ unsigned pack16(float lo, float hi) {
+    if constexpr (DT == DT_BF16) return pack_bf16(lo, hi);
+    else {
+        unsigned r;                                            // round to nearest even
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+        return r;
+    }
+}
+template <int DT> __device__ __forceinline__ float lo16(unsigned q) {   // low half of a packed pair -> fp32
+    if constexpr (DT == DT_BF16) return __uint_as_float(q << 16);
+    else return (float)__builtin_bit_cast(_Float16, (unsigned short)(q & 0xffffu));
+}
+template <int DT> __device__ __forceinline__ float hi16(unsigned q) {
+    if constexpr (DT == DT_BF16) return __uint_as_float(q & 0xffff0000u);
+    else return (float)__builtin_bit_cast(_Float16, (unsigned short)(q >> 16));
+}
+template <int DT> __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    if constexpr (DT == DT_BF16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
 __device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) unsigned *)g,
                                      (__attribute__((address_space(3))) unsigned *)lds_wave_base, 16, 0, 0);
@@ -76,6 +102,7 @@ struct GemmArgs {
     int splits;
     // EPI_RELU_HEAD4: W2 = bf16 [4][N] projection, bias2 = its 4 biases, C = pts f32 [M,3], C2 = conf f32 [M]
     float *C2;
+    int dt;                 // DT_BF16 / DT_F16: 16-bit storage type of A, W and of 16-bit C / R
 };
 
 // Per-group view of the arguments (group 1 of a 2-group launch).
@@ -99,7 +126,7 @@ enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32 = 2, EPI_F32_ACCUM = 3, EPI_BF16
 
 
 // Epilogue for one 16x16 accumulator tile: the lane holds C[m][n..n+3] (operands were swapped).
-template <int EPI>
+template <int EPI, int DT = DT_BF16>
 __device__ __forceinline__ void store_tile(const GemmArgs &g, f32x4 v, int m, int n) {
     if (m >= g.M || n >= g.N) return;                       // N is a multiple of 4 (checked on the host)
     if (EPI != EPI_BF16_ROPE && g.bias) {
@@ -120,16 +147,16 @@ __device__ __forceinline__ void store_tile(const GemmArgs &g, f32x4 v, int m, in
             v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
         }
         if (EPI == EPI_BF16_ADD) {
-            const ushort4 r = *reinterpret_cast<const ushort4 *>(reinterpret_cast<const bf16_t *>(g.R) + off);
-            v[0] += bf2f(r.x); v[1] += bf2f(r.y); v[2] += bf2f(r.z); v[3] += bf2f(r.w);
+            const uint2 r = *reinterpret_cast<const uint2 *>(reinterpret_cast<const bf16_t *>(g.R) + off);
+            v[0] += lo16<DT>(r.x); v[1] += hi16<DT>(r.x); v[2] += lo16<DT>(r.y); v[3] += hi16<DT>(r.y);
         }
         if (EPI == EPI_BF16_RELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
         }
-        ushort4 o;
-        o.x = f2bf(v[0]); o.y = f2bf(v[1]); o.z = f2bf(v[2]); o.w = f2bf(v[3]);
-        *reinterpret_cast<ushort4 *>(reinterpret_cast<bf16_t *>(g.C) + off) = o;
+        uint2 o;
+        o.x = pack16<DT>(v[0], v[1]); o.y = pack16<DT>(v[2], v[3]);
+        *reinterpret_cast<uint2 *>(reinterpret_cast<bf16_t *>(g.C) + off) = o;
     }
 }
 
@@ -183,7 +210,7 @@ __device__ __forceinline__ void rope_strip(const GemmArgs &g, f32x4 *t, int m, i
 // Bias / activation / RoPE are applied in the accumulator layout before the transpose, residuals
 // (fp32 accumulate, bf16 add) on the row-contiguous side.  Falls back to store_tile when the
 // output is not 16-byte aligned.
-template <int EPI, int NI, int NJ = 4>
+template <int EPI, int NI, int NJ = 4, int DT = DT_BF16>
 __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI][NJ], unsigned char *wlds,
                                               int m_base, int n_base, int lane) {
     constexpr bool F32OUT = (EPI == EPI_F32 || EPI == EPI_F32_ACCUM);
@@ -197,7 +224,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
         for (int i = 0; i < NI; ++i) {
             if (EPI == EPI_BF16_ROPE) rope_strip<NJ>(g, acc[i], m_base + i * 16 + r, n_base, lane);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) store_tile<EPI>(g, acc[i][j], m_base + i * 16 + r, n_base + j * 16 + gq * 4);
+            for (int j = 0; j < NJ; ++j) store_tile<EPI, DT>(g, acc[i][j], m_base + i * 16 + r, n_base + j * 16 + gq * 4);
         }
         return;
     }
@@ -250,10 +277,10 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
                         const size_t off = (size_t)m * g.ldc + n;
                         const uint4 q = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16_t *>(g.R) + off);
                         uint4 o;
-                        o.x = pack_bf16(a.x + __uint_as_float(q.x << 16), a.y + __uint_as_float(q.x & 0xffff0000u));
-                        o.y = pack_bf16(a.z + __uint_as_float(q.y << 16), a.w + __uint_as_float(q.y & 0xffff0000u));
-                        o.z = pack_bf16(b.x + __uint_as_float(q.z << 16), b.y + __uint_as_float(q.z & 0xffff0000u));
-                        o.w = pack_bf16(b.z + __uint_as_float(q.w << 16), b.w + __uint_as_float(q.w & 0xffff0000u));
+                        o.x = pack16<DT>(a.x + lo16<DT>(q.x), a.y + hi16<DT>(q.x));
+                        o.y = pack16<DT>(a.z + lo16<DT>(q.y), a.w + hi16<DT>(q.y));
+                        o.z = pack16<DT>(b.x + lo16<DT>(q.z), b.y + hi16<DT>(q.z));
+                        o.w = pack16<DT>(b.z + lo16<DT>(q.w), b.w + hi16<DT>(q.w));
                         *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(g.C) + off) = o;
                     }
                 }
@@ -283,7 +310,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
                         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
                     }
                     uint2 pk;
-                    pk.x = pack_bf16(v[0], v[1]); pk.y = pack_bf16(v[2], v[3]);
+                    pk.x = pack16<DT>(v[0], v[1]); pk.y = pack16<DT>(v[2], v[3]);
                     *reinterpret_cast<uint2 *>(wlds + (ii * 16 + r) * RS + (j * 16 + gq * 4) * 2) = pk;
                 }
             }

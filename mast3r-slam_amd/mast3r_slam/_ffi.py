@@ -90,7 +90,7 @@ def check(t: torch.Tensor, dtype, name: str, shape=None) -> torch.Tensor:
         raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
     if not t.is_cuda:
         raise RuntimeError(f"{name}: must live on the ROCm device (got {t.device}); no CPU path exists")
-    if t.dtype != dtype:
+    if t.dtype != dtype and not (isinstance(dtype, tuple) and t.dtype in dtype):
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
     if shape is not None:
         if len(shape) != t.dim() or any(s is not None and s != d for s, d in zip(shape, t.shape)):

@@ -35,7 +35,9 @@ __all__ = [
 
 def load_mast3r(model_type: str = "mast3r_full", variant: str = "base", resolution: int = 512,
                 precision: str = "bf16", weights_path: Optional[str] = None, **kw) -> Mast3rFull:
-    """mast3r_utils.py:47-80.  Only the full ViT-L model named by the hot path is provided."""
+    """mast3r_utils.py:47-80.  Only the full ViT-L model named by the hot path is provided.  `precision`:
+    "bf16" | "fp16" | "fp32" as the reference (see model.py for what each selects on the MI355X);
+    `weights_path`: a torch / safetensors state dict with the public MASt3R key names."""
     if model_type == "mast3r_full":
         return Mast3rFull.from_pretrained(resolution=resolution, precision=precision, weights_path=weights_path, **kw)
     if model_type == "dunemast3r":
@@ -184,8 +186,8 @@ def mast3r_decode_symmetric_batch(model: Mast3rFull, feat_i, pos_i, feat_j, pos_
     b = feat_i.shape[0]
     h, w = _hw(shape_i)
     grid = (h // 16, w // 16)
-    fi = feat_i.to(model.device, torch.bfloat16)
-    fj = feat_j.to(model.device, torch.bfloat16)
+    fi = feat_i.to(model.device, model.tdt)          # cached tokens are stored in the trunk's 16-bit type
+    fj = feat_j.to(model.device, model.tdt)
     o1, o2 = model.decode_heads(torch.cat([fi, fj], 0), torch.cat([fj, fi], 0), 2 * b, grid)
     sl = lambda o, lo: {n: v[lo:lo + b] for n, v in o.items()}
     parts = [sl(o1, 0), sl(o2, 0), sl(o1, b), sl(o2, b)]           # ii, ji, jj, ij

@@ -8,8 +8,20 @@ MASt3R ViT-L/16 + base decoder + catmlp+dpt head (see oracle/model.py for the la
 weights are either random-initialised (seeded) or loaded from a state dict that uses the public
 checkpoint's key names.
 
+Precision (`load_mast3r(..., precision)`, mast3r_utils.py:47-52 accepts "fp16" | "fp32" | "bf16"): the 16-bit
+storage type of GEMM operands; accumulation, residual stream, LayerNorm statistics, softmax and all outputs
+are fp32 in every mode.
+  * "bf16" (BASELINE configs[1]): ViT trunk (encoder + decoders) on v_mfma_f32_16x16x32_bf16; the two heads
+    (DPT conv chain, local-feature MLP) on v_mfma_f32_16x16x32_f16 - same MFMA rate.  Measured on the fp32 oracle
+    at full depth (scratch study recorded in DESIGN.md section 4): with bf16 everywhere the head's roundings alone move
+    the pointmap by 9.7e-4 rel-L2 (trunk: 3.7e-4), with fp16 heads the total is ~4e-4.  `head_precision="bf16"`
+    gives the all-bf16 variant.
+  * "fp16" (the reference's default): every operand fp16 (3 more mantissa bits, range 65504).
+  * "fp32": there is no fp32 MFMA GEMM path worth running (1/16 of the 16-bit rate); the request is served by
+    the most precise mode, "fp16" operands with fp32 accumulation - documented cast, not an error.
+
 Device-side design (all kernels are hand-written HIP behind include/m3slam_model.h):
-  * activations entering a GEMM are bf16, every GEMM accumulates in fp32 on MFMA;
+  * activations entering a GEMM are 16-bit (see above), every GEMM accumulates in fp32 on MFMA;
   * the residual stream stays fp32 (GEMM epilogue `C = R + acc + bias`), LayerNorm reads it
     and writes the bf16 GEMM operand - no separate add / cast passes;
   * q, k, v stay interleaved in the projection buffer; RoPE-2D is applied in place to the q|k
@@ -111,6 +123,30 @@ def init_random_weights(cfg: Optional[dict] = None, seed: int = 0, std: float = 
     return w
 
 
+def load_state_dict(path: str) -> dict:
+    """A checkpoint with the public MASt3R key names -> {name: fp32 CPU tensor}.
+
+    Accepts a bare state dict or the public checkpoint layout {"model": state_dict, "args": Namespace, ...}
+    (torch.load's weights_only=True default refuses the argparse Namespace, so the wrapper layout is read
+    with weights_only=False after a weights_only attempt fails - the file is the user's own checkpoint) and
+    .safetensors files.  Keys this network does not use (mask_token, the `dec_blocks*.cross_attn` RoPE
+    buffers, the training heads) are ignored; a missing key raises KeyError in `_prepare`."""
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        sd = load_file(path, device="cpu")
+    else:
+        try:
+            sd = torch.load(path, map_location="cpu", weights_only=True)
+        except Exception:                                  # noqa: BLE001 - pickled Namespace in the public checkpoint
+            sd = torch.load(path, map_location="cpu", weights_only=False)
+    if isinstance(sd, dict) and "model" in sd and isinstance(sd["model"], dict):
+        sd = sd["model"]
+    out = {k: v.detach().float() for k, v in sd.items() if isinstance(v, torch.Tensor)}
+    if "patch_embed.proj.weight" not in out:
+        raise KeyError(f"{path}: not a MASt3R state dict (no 'patch_embed.proj.weight'; keys like {list(out)[:3]})")
+    return out
+
+
 def _pad_to(t: torch.Tensor, dim: int, size: int) -> torch.Tensor:
     if t.shape[dim] == size:
         return t
@@ -129,15 +165,23 @@ class Mast3rFull:
     embed_dim = 1024
     patch_size = 16
 
+    _PRECISIONS = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float16}
+
     def __init__(self, weights: Optional[dict] = None, cfg: Optional[dict] = None, device="cuda",
-                 resolution: int = 512, precision: str = "bf16", seed: int = 0) -> None:
-        if precision not in ("bf16",):
-            raise ValueError("the MI355X path computes in bf16 with fp32 accumulation; precision must be 'bf16'")
+                 resolution: int = 512, precision: str = "bf16", seed: int = 0,
+                 head_precision: Optional[str] = None) -> None:
+        if precision not in self._PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(self._PRECISIONS)}, got {precision!r}")
+        if head_precision is not None and head_precision not in self._PRECISIONS:
+            raise ValueError(f"head_precision must be one of {sorted(self._PRECISIONS)}, got {head_precision!r}")
         if not torch.cuda.is_available():
             raise RuntimeError("Mast3rFull needs a ROCm device; there is no CPU path")
         self.cfg = dict(cfg or FULL_CFG)
         self.device = torch.device(device)
         self.resolution = resolution
+        self.precision = precision
+        self.tdt = self._PRECISIONS[precision]                                    # trunk operand type
+        self.hdt = self._PRECISIONS[head_precision] if head_precision else torch.float16   # heads: fp16 unless asked
         self.host_weights = weights if weights is not None else init_random_weights(self.cfg, seed)
         self._prepare(self.host_weights)
         self._rope_cache = {}
@@ -151,18 +195,17 @@ class Mast3rFull:
         torch state dict with the public MASt3R key names, else seeded random weights are used."""
         weights = None
         if weights_path is not None:
-            sd = torch.load(weights_path, map_location="cpu")
-            sd = sd.get("model", sd)
-            weights = {k: v.float() for k, v in sd.items() if isinstance(v, torch.Tensor)}
+            weights = load_state_dict(weights_path)
         return cls(weights=weights, resolution=resolution, precision=precision, **kw)
 
     # ------------------------------------------------------------------ weight preparation
     def _prepare(self, w: dict) -> None:
         dev = self.device
         P: dict[str, torch.Tensor] = {}
+        wdt = self.tdt                                          # switched to self.hdt for the head weights below
 
         def lin(p):
-            P[p + ".w"] = w[p + ".weight"].to(dev, torch.bfloat16).contiguous()
+            P[p + ".w"] = w[p + ".weight"].to(dev, wdt).contiguous()
             P[p + ".b"] = w[p + ".bias"].to(dev, torch.float32).contiguous()
 
         def norm(p):
@@ -173,14 +216,14 @@ class Mast3rFull:
             t = w[p + ".weight"].permute(0, 2, 3, 1)                       # [Co,3,3,Ci]
             if cin_pad:
                 t = _pad_to(t, 3, cin_pad)
-            P[p + ".w"] = t.to(dev, torch.bfloat16).contiguous()
+            P[p + ".w"] = t.to(dev, wdt).contiguous()
             P[p + ".b"] = w[p + ".bias"].to(dev, torch.float32).contiguous() if bias else None
 
         def conv1(p, kpad=None):
             t = w[p + ".weight"][:, :, 0, 0]
             if kpad:
                 t = _pad_to(t, 1, kpad)
-            P[p + ".w"] = t.to(dev, torch.bfloat16).contiguous()
+            P[p + ".w"] = t.to(dev, wdt).contiguous()
             P[p + ".b"] = w[p + ".bias"].to(dev, torch.float32).contiguous()
 
         def convT(p, s, kpad=None):
@@ -189,11 +232,11 @@ class Mast3rFull:
             t = t.permute(2, 3, 1, 0).reshape(s * s * co, ci)               # row (dy*s+dx)*Co+co
             if kpad:
                 t = _pad_to(t, 1, kpad)
-            P[p + ".w"] = t.to(dev, torch.bfloat16).contiguous()
+            P[p + ".w"] = t.to(dev, wdt).contiguous()
             P[p + ".b"] = w[p + ".bias"].repeat(s * s).to(dev, torch.float32).contiguous()
 
         c = self.cfg
-        P["patch.w"] = w["patch_embed.proj.weight"].reshape(c["enc_dim"], -1).to(dev, torch.bfloat16).contiguous()
+        P["patch.w"] = w["patch_embed.proj.weight"].reshape(c["enc_dim"], -1).to(dev, wdt).contiguous()
         P["patch.b"] = w["patch_embed.proj.bias"].to(dev, torch.float32).contiguous()
         for i in range(c["enc_depth"]):
             p = f"enc_blocks.{i}"
@@ -206,12 +249,13 @@ class Mast3rFull:
                 norm(p + ".norm1"); lin(p + ".attn.qkv"); lin(p + ".attn.proj")
                 norm(p + ".norm2"); norm(p + ".norm_y"); lin(p + ".cross_attn.projq"); lin(p + ".cross_attn.proj")
                 P[p + ".cross_attn.kv.w"] = torch.cat([w[p + ".cross_attn.projk.weight"],
-                                                       w[p + ".cross_attn.projv.weight"]], 0).to(dev, torch.bfloat16).contiguous()
+                                                       w[p + ".cross_attn.projv.weight"]], 0).to(dev, wdt).contiguous()
                 P[p + ".cross_attn.kv.b"] = torch.cat([w[p + ".cross_attn.projk.bias"],
                                                        w[p + ".cross_attn.projv.bias"]], 0).to(dev, torch.float32).contiguous()
                 norm(p + ".norm3"); lin(p + ".mlp.fc1"); lin(p + ".mlp.fc2")
         norm("dec_norm")
         ld = c["layer_dims"]
+        wdt = self.hdt
         for hname in ("downstream_head1", "downstream_head2"):
             p = hname + ".dpt"
             conv1(p + ".act_postprocess.0.0"); convT(p + ".act_postprocess.0.1", 4, _ceil64(ld[0]))
@@ -257,7 +301,7 @@ class Mast3rFull:
         P = self.P
         c = heads * 64
         qkv = ops.gemm_rope(xn, P[p + ".qkv.w"], P[p + ".qkv.b"], pos, cs, t, 2 * c)    # [M,3c], q|k rotated
-        out = torch.empty((nb * t, c), dtype=torch.bfloat16, device=xn.device)
+        out = torch.empty((nb * t, c), dtype=xn.dtype, device=xn.device)
         ops.attention(qkv, qkv[:, c:], qkv[:, 2 * c:], out, nbatch=nb, heads=heads, tq=t, tk=t,
                       q_row_stride=3 * c, kv_row_stride=3 * c, o_row_stride=c, q_batch_stride=t * 3 * c,
                       kv_batch_stride=t * 3 * c, o_batch_stride=t * c)
@@ -265,27 +309,27 @@ class Mast3rFull:
 
     # ------------------------------------------------------------------ encoder
     def encode_tokens(self, imgs_u8: torch.Tensor):
-        """uint8 [B,H,W,3] -> (enc_norm tokens bf16 [B*T,1024], (gh,gw))."""
+        """uint8 [B,H,W,3] -> (enc_norm tokens, trunk 16-bit type, [B*T,1024], (gh,gw)).  Any H, W that are
+        multiples of 16 (resize_img emits e.g. 512x336 -> 672 tokens, 512x288 -> 576)."""
         P, c = self.P, self.cfg
         b, h, w, _ = imgs_u8.shape
         gh, gw = h // 16, w // 16
         t = gh * gw
-        if t % 128:
-            raise ValueError(f"token count {t} must be a multiple of 128 (e.g. 512x512, 512x384)")
+        dt = self.tdt
         pos, cs = self._rope(gh, gw)
-        x = ops.gemm(ops.patchify16(imgs_u8), P["patch.w"], P["patch.b"], ops.EPI_F32)   # fp32 residual stream
+        x = ops.gemm(ops.patchify16(imgs_u8, dt), P["patch.w"], P["patch.b"], ops.EPI_F32)   # fp32 residual stream
         for i in range(c["enc_depth"]):
             p = f"enc_blocks.{i}"
-            xn = ops.layernorm(x, P[p + ".norm1.g"], P[p + ".norm1.b"])
+            xn = ops.layernorm(x, P[p + ".norm1.g"], P[p + ".norm1.b"], dtype=dt)
             a = self._self_attn(xn, p + ".attn", c["enc_heads"], b, t, pos, cs)
             ops.gemm(a, P[p + ".attn.proj.w"], P[p + ".attn.proj.b"], ops.EPI_F32_ACCUM, out=x, resid=x)
-            xn = ops.layernorm(x, P[p + ".norm2.g"], P[p + ".norm2.b"])
+            xn = ops.layernorm(x, P[p + ".norm2.g"], P[p + ".norm2.b"], dtype=dt)
             hdn = ops.gemm(xn, P[p + ".mlp.fc1.w"], P[p + ".mlp.fc1.b"], ops.EPI_BF16_GELU)
             ops.gemm(hdn, P[p + ".mlp.fc2.w"], P[p + ".mlp.fc2.b"], ops.EPI_F32_ACCUM, out=x, resid=x)
-        return ops.layernorm(x, P["enc_norm.g"], P["enc_norm.b"]), (gh, gw)
+        return ops.layernorm(x, P["enc_norm.g"], P["enc_norm.b"], dtype=dt), (gh, gw)
 
     def encode(self, img):
-        """model.encode(img) (mast3r_utils.py:278): uint8 [H,W,3] -> tokens [T,1024] (bf16 tensor);
+        """model.encode(img) (mast3r_utils.py:278): uint8 [H,W,3] -> tokens [T,1024] (16-bit tensor of the trunk type);
         a batch [B,H,W,3] gives [B,T,1024]."""
         imgs = self._as_images(img)
         tok, _ = self.encode_tokens(imgs)
@@ -294,9 +338,9 @@ class Mast3rFull:
 
     # ------------------------------------------------------------------ decoder
     def decode_tokens(self, f1: torch.Tensor, f2: torch.Tensor, npairs: int, grid):
-        """f1, f2 bf16 [P*T,1024] (enc_norm outputs of view 1 / view 2) -> two lists of DPT taps
-        (bf16 [P*T,C]) at the configured hooks.  The two decoder branches (different weights, same
-        shapes) run as 2-group launches: one GEMM / LayerNorm / attention launch serves both views."""
+        """f1, f2 [P*T,1024] in the trunk 16-bit type (enc_norm outputs of view 1 / view 2) -> two lists of DPT
+        taps ([P*T,C] in the HEAD 16-bit type) at the configured hooks.  The two decoder branches (different
+        weights, same shapes) run as 2-group launches: one GEMM / LayerNorm / attention launch serves both views."""
         P, c = self.P, self.cfg
         gh, gw = grid
         t = gh * gw
@@ -304,6 +348,9 @@ class Mast3rFull:
         D, heads = c["dec_dim"], c["dec_heads"]
         m = npairs * t
         dev = f1.device
+        dt, hdt = self.tdt, self.hdt
+        if f1.dtype != dt or f2.dtype != dt:
+            raise TypeError(f"encoder features must be {dt} (precision={self.precision!r}), got {f1.dtype}")
         if (f1.is_contiguous() and f2.is_contiguous() and f1.untyped_storage().data_ptr() == f2.untyped_storage().data_ptr()
                 and f2.data_ptr() == f1.data_ptr() + f1.numel() * f1.element_size()):
             fcat = torch.as_strided(f1, (2, m, f1.shape[1]), (m * f1.shape[1], f1.shape[1], 1))   # adjacent halves of the encoder batch
@@ -311,44 +358,46 @@ class Mast3rFull:
             fcat = torch.stack([f1, f2])                                                 # [2,M,1024]
         x = ops.gemm_grouped2(fcat, P["decoder_embed.w"], P["decoder_embed.w"], P["decoder_embed.b"],
                               P["decoder_embed.b"], ops.EPI_F32)                         # fp32 residual streams [2,M,D]
-        taps = [[f1], [f2]]
+        # tap 0 = the cached encoder features; the heads read them in their own 16-bit type (bf16 -> fp16 is exact
+        # for these LayerNorm outputs: fp16 has more mantissa bits and |x| << 65504)
+        taps = [[f1 if hdt == dt else ops.cast16(f1, hdt)], [f2 if hdt == dt else ops.cast16(f2, hdt)]]
         hooks = set(c["hooks"])
         W = lambda i, s: (P[f"dec_blocks.{i}.{s}"], P[f"dec_blocks2.{i}.{s}"])
         for i in range(c["dec_depth"]):
             # cross-attention memory: norm_y of the OTHER view's previous-layer tokens, then k|v projection
             yn = ops.layernorm_grouped2(x, *W(i, "norm_y.g")[:1], W(i, "norm_y.b")[0], W(i, "norm_y.g")[1],
-                                        W(i, "norm_y.b")[1], swap=True)
+                                        W(i, "norm_y.b")[1], swap=True, dtype=dt)
             kv = ops.gemm_grouped2(yn, *W(i, "cross_attn.kv.w"), *W(i, "cross_attn.kv.b"), ops.EPI_BF16_ROPE,
                                    rope=(pos, cs, t, D))                                  # [2,M,2D], k rotated
             # self-attention
-            xn = ops.layernorm_grouped2(x, W(i, "norm1.g")[0], W(i, "norm1.b")[0], W(i, "norm1.g")[1], W(i, "norm1.b")[1])
+            xn = ops.layernorm_grouped2(x, W(i, "norm1.g")[0], W(i, "norm1.b")[0], W(i, "norm1.g")[1], W(i, "norm1.b")[1], dtype=dt)
             qkv = ops.gemm_grouped2(xn, *W(i, "attn.qkv.w"), *W(i, "attn.qkv.b"), ops.EPI_BF16_ROPE,
                                     rope=(pos, cs, t, 2 * D)).view(2 * m, 3 * D)
-            a = torch.empty((2, m, D), dtype=torch.bfloat16, device=dev)
+            a = torch.empty((2, m, D), dtype=dt, device=dev)
             ops.attention(qkv, qkv[:, D:], qkv[:, 2 * D:], a, nbatch=2 * npairs, heads=heads, tq=t, tk=t,
                           q_row_stride=3 * D, kv_row_stride=3 * D, o_row_stride=D, q_batch_stride=t * 3 * D,
                           kv_batch_stride=t * 3 * D, o_batch_stride=t * D)
             ops.gemm_grouped2(a, *W(i, "attn.proj.w"), *W(i, "attn.proj.b"), ops.EPI_F32_ACCUM, out=x, resid=x)
             # cross-attention
-            xn = ops.layernorm_grouped2(x, W(i, "norm2.g")[0], W(i, "norm2.b")[0], W(i, "norm2.g")[1], W(i, "norm2.b")[1])
+            xn = ops.layernorm_grouped2(x, W(i, "norm2.g")[0], W(i, "norm2.b")[0], W(i, "norm2.g")[1], W(i, "norm2.b")[1], dtype=dt)
             q = ops.gemm_grouped2(xn, *W(i, "cross_attn.projq.w"), *W(i, "cross_attn.projq.b"), ops.EPI_BF16_ROPE,
                                   rope=(pos, cs, t, D)).view(2 * m, D)
             kvf = kv.view(2 * m, 2 * D)
-            a = torch.empty((2, m, D), dtype=torch.bfloat16, device=dev)
+            a = torch.empty((2, m, D), dtype=dt, device=dev)
             ops.attention(q, kvf, kvf[:, D:], a, nbatch=2 * npairs, heads=heads, tq=t, tk=t, q_row_stride=D,
                           kv_row_stride=2 * D, o_row_stride=D, q_batch_stride=t * D, kv_batch_stride=t * 2 * D,
                           o_batch_stride=t * D)
             ops.gemm_grouped2(a, *W(i, "cross_attn.proj.w"), *W(i, "cross_attn.proj.b"), ops.EPI_F32_ACCUM, out=x, resid=x)
             # MLP
-            xn = ops.layernorm_grouped2(x, W(i, "norm3.g")[0], W(i, "norm3.b")[0], W(i, "norm3.g")[1], W(i, "norm3.b")[1])
+            xn = ops.layernorm_grouped2(x, W(i, "norm3.g")[0], W(i, "norm3.b")[0], W(i, "norm3.g")[1], W(i, "norm3.b")[1], dtype=dt)
             hdn = ops.gemm_grouped2(xn, *W(i, "mlp.fc1.w"), *W(i, "mlp.fc1.b"), ops.EPI_BF16_GELU)
             ops.gemm_grouped2(hdn, *W(i, "mlp.fc2.w"), *W(i, "mlp.fc2.b"), ops.EPI_F32_ACCUM, out=x, resid=x)
             layer = i + 1
             if layer in hooks:
                 if layer == c["dec_depth"]:
-                    tap = ops.layernorm_grouped2(x, P["dec_norm.g"], P["dec_norm.b"], P["dec_norm.g"], P["dec_norm.b"])
+                    tap = ops.layernorm_grouped2(x, P["dec_norm.g"], P["dec_norm.b"], P["dec_norm.g"], P["dec_norm.b"], dtype=hdt)
                 else:
-                    tap = ops.f32_to_bf16(x)
+                    tap = ops.cast_f32(x, hdt)
                 taps[0].append(tap[0])
                 taps[1].append(tap[1])
         return taps
@@ -370,7 +419,7 @@ class Mast3rFull:
         return ops.upsample2x(out)
 
     def head(self, hname: str, taps, npairs: int, grid):
-        """taps: 4 bf16 [P*T,C] tensors -> dict(pts3d [P,H,W,3], conf [P,H,W], desc [P,H,W,24], desc_conf [P,H,W])."""
+        """taps: 4 [P*T,C] tensors in the head 16-bit type -> dict(pts3d [P,H,W,3], conf [P,H,W], desc [P,H,W,24], desc_conf [P,H,W])."""
         P, c = self.P, self.cfg
         gh, gw = grid
         m = npairs * gh * gw
@@ -379,12 +428,12 @@ class Mast3rFull:
         dev = taps[0].device
         # act_postprocess
         k0 = _ceil64(ld[0])
-        t0 = torch.zeros((m, k0), dtype=torch.bfloat16, device=dev) if k0 != ld[0] else None
+        t0 = torch.zeros((m, k0), dtype=self.hdt, device=dev) if k0 != ld[0] else None
         t0 = ops.gemm(taps[0], P[p + ".act_postprocess.0.0.w"], P[p + ".act_postprocess.0.0.b"], ops.EPI_BF16, out=t0)
         u0 = ops.gemm(t0, P[p + ".act_postprocess.0.1.w"], P[p + ".act_postprocess.0.1.b"], ops.EPI_BF16)
         l0 = ops.unshuffle(u0, npairs, gh, gw, 4, ld[0], _ceil64(ld[0]))
         k1 = _ceil64(ld[1])
-        t1 = torch.zeros((m, k1), dtype=torch.bfloat16, device=dev) if k1 != ld[1] else None
+        t1 = torch.zeros((m, k1), dtype=self.hdt, device=dev) if k1 != ld[1] else None
         t1 = ops.gemm(taps[1], P[p + ".act_postprocess.1.0.w"], P[p + ".act_postprocess.1.0.b"], ops.EPI_BF16, out=t1)
         u1 = ops.gemm(t1, P[p + ".act_postprocess.1.1.w"], P[p + ".act_postprocess.1.1.b"], ops.EPI_BF16)
         l1 = ops.unshuffle(u1, npairs, gh, gw, 2, ld[1], _ceil64(ld[1]))
@@ -396,6 +445,10 @@ class Mast3rFull:
         rn = [ops.conv3x3(l, P[p + f".scratch.layer_rn.{i}.w"], None, ops.EPI_BF16)
               for i, l in enumerate((l0, l1, l2, l3))]
         path = self._fusion(p + ".scratch.refinenet4", rn[3])
+        if path.shape[1:3] != rn[2].shape[1:3]:
+            # odd token grids (e.g. 512x336 -> 32x21): the stride-2 map has ceil(g/2) rows, its x2 upsampling one
+            # row more than the 1/16 map; the public DPT crops it (oracle/model.py dpt_head, path4[:, :, :h, :w])
+            path = path[:, :rn[2].shape[1], :rn[2].shape[2]].contiguous()
         path = self._fusion(p + ".scratch.refinenet3", path, rn[2])
         path = self._fusion(p + ".scratch.refinenet2", path, rn[1])
         path = self._fusion(p + ".scratch.refinenet1", path, rn[0])
@@ -481,7 +534,7 @@ class Mast3rFull:
         feat = 2 * t * (E + D) * r * (E + D) + 2 * t * r * (E + D) * 25 * 256
         F_, ld = c["feat_dim"], c["layer_dims"]
         gh, gw = h // 16, w // 16
-        px = [gh * 4 * gw * 4, gh * 2 * gw * 2, gh * gw, gh * gw // 4]
+        px = [gh * 4 * gw * 4, gh * 2 * gw * 2, gh * gw, ((gh + 1) // 2) * ((gw + 1) // 2)]
         conv = lambda n, ci, co, k: 2.0 * n * ci * co * k * k
         dpt = (conv(t, E, ld[0], 1) + conv(t, ld[0], ld[0] * 16, 1) + conv(t, D, ld[1], 1) + conv(t, ld[1], ld[1] * 4, 1)
                + conv(t, D, ld[2], 1) + conv(t, D, ld[3], 1) + conv(px[3], ld[3], ld[3], 3)
@@ -500,8 +553,8 @@ class GraphedReconstruct:
     next call, so consume (or clone) them before calling again.  Stream-ordered on the current stream."""
 
     def __init__(self, net: Mast3rFull, npairs: int, h: int, w: int) -> None:
-        if h % 16 or w % 16 or ((h // 16) * (w // 16)) % 128:
-            raise ValueError("H, W must be multiples of 16 with a token count that is a multiple of 128")
+        if h % 16 or w % 16 or h <= 0 or w <= 0:
+            raise ValueError("H, W must be positive multiples of 16")
         self.net = net
         self.shape = (npairs, h, w, 3)
         self._in1 = torch.zeros(self.shape, dtype=torch.uint8, device=net.device)

@@ -1,6 +1,7 @@
 """Thin torch-tensor wrappers over the network operators of the C ABI (include/m3slam_model.h).
 
-bf16 activations / weights, fp32 accumulation.  All ops are stream-ordered; outputs are
+16-bit activations / weights (torch.bfloat16 or torch.float16: the `dtype` argument of the *_dt entry
+points follows the tensors), fp32 accumulation.  All ops are stream-ordered; outputs are
 allocated by the caller-facing wrapper (torch caching allocator) and passed as raw pointers.
 """
 from __future__ import annotations
@@ -13,6 +14,17 @@ EPI_BF16, EPI_BF16_GELU, EPI_F32, EPI_F32_ACCUM, EPI_BF16_RELU, EPI_BF16_ADD, EP
 _F32_EPIS = (EPI_F32, EPI_F32_ACCUM)
 
 _zero16 = {}
+
+H16 = (torch.bfloat16, torch.float16)          # the two 16-bit storage types of the network operators
+DT_CODE = {torch.bfloat16: 0, torch.float16: 1}   # M3_DT_BF16 / M3_DT_F16 (include/m3slam_model.h)
+
+
+def _same16(a, *others):
+    """dtype code of `a`; every other (non-None) 16-bit tensor must have the same type."""
+    for t in others:
+        if t is not None and t.dtype != a.dtype:
+            raise TypeError(f"mixed 16-bit types in one launch: {a.dtype} vs {t.dtype}")
+    return DT_CODE[a.dtype]
 
 # When set to a list, every MFMA GEMM / implicit-GEMM conv launch appends
 # (kind, algorithmic_flops, start_event, end_event, algorithmic_bytes): events are recorded on the
@@ -54,13 +66,14 @@ def zero_page(dev):
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, epi: int = EPI_BF16, out=None, resid=None):
     """out[M,N] = epi(a[M,K] @ w[N,K].T + bias).  a, w bf16; out bf16 or f32 by epilogue."""
-    a = _ffi.check(a, torch.bfloat16, "a")
-    w = _ffi.check(w, torch.bfloat16, "w")
+    a = _ffi.check(a, H16, "a")
+    w = _ffi.check(w, H16, "w")
+    dt = _same16(a, w)
     m, k = a.shape
     n = w.shape[0]
     if w.shape[1] != k:
         raise ValueError(f"K mismatch: a {tuple(a.shape)} vs w {tuple(w.shape)}")
-    odt = torch.float32 if epi in _F32_EPIS else torch.bfloat16
+    odt = torch.float32 if epi in _F32_EPIS else a.dtype
     if out is None:
         out = torch.empty((m, n), dtype=odt, device=a.device)
     else:
@@ -72,8 +85,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, epi: int = EPI_BF16, out=N
     if resid is not None and (resid.dtype != odt or resid.stride(0) != ldc):
         raise ValueError("residual must match out dtype/stride")
     e0 = _prof_begin()
-    _ffi.call("m3_gemm_bf16", _ffi.ptr(a), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(out), _ffi.ptr(resid),
-              m, n, k, ldc, epi, _ffi.stream_ptr())
+    _ffi.call("m3_gemm_dt", _ffi.ptr(a), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(out), _ffi.ptr(resid),
+              m, n, k, ldc, epi, dt, _ffi.stream_ptr())
     esz = out.element_size()
     _prof_end(e0, _gemm_kind(m, n), 2.0 * m * n * k, 2.0 * (m * k + n * k) + esz * m * n * (1 if resid is None else 2))
     return out
@@ -81,28 +94,30 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, epi: int = EPI_BF16, out=N
 
 def gemm_rope(a, w, bias, pos_yx, cos_sin, tokens_per_image: int, rope_cols: int):
     """bf16 out[M,N] = a @ w.T + bias with RoPE-2D applied to the 64-wide heads in columns < rope_cols."""
-    a = _ffi.check(a, torch.bfloat16, "a")
-    w = _ffi.check(w, torch.bfloat16, "w")
+    a = _ffi.check(a, H16, "a")
+    w = _ffi.check(w, H16, "w")
+    dt = _same16(a, w)
     m, k = a.shape
     n = w.shape[0]
-    out = torch.empty((m, n), dtype=torch.bfloat16, device=a.device)
+    out = torch.empty((m, n), dtype=a.dtype, device=a.device)
     e0 = _prof_begin()
-    _ffi.call("m3_gemm_bf16_rope", _ffi.ptr(a), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(out), m, n, k, n,
-              _ffi.ptr(pos_yx), _ffi.ptr(cos_sin), tokens_per_image, rope_cols, _ffi.stream_ptr())
+    _ffi.call("m3_gemm_rope_dt", _ffi.ptr(a), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(out), m, n, k, n,
+              _ffi.ptr(pos_yx), _ffi.ptr(cos_sin), tokens_per_image, rope_cols, dt, _ffi.stream_ptr())
     _prof_end(e0, _gemm_kind(m, n), 2.0 * m * n * k, 2.0 * (m * k + n * k + m * n))
     return out
 
 
 def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, epi: int = EPI_BF16, stride: int = 1, resid=None, out=None):
     """x NHWC bf16 [B,H,W,Cin], w bf16 [Cout,3,3,Cin] -> NHWC [B,OH,OW,Cout], padding 1."""
-    x = _ffi.check(x, torch.bfloat16, "x")
-    w = _ffi.check(w, torch.bfloat16, "w")
+    x = _ffi.check(x, H16, "x")
+    w = _ffi.check(w, H16, "w")
+    dt = _same16(x, w)
     b, h, wd, cin = x.shape
     cout = w.shape[0]
     if tuple(w.shape[1:]) != (3, 3, cin):
         raise ValueError(f"weight must be [Cout,3,3,{cin}], got {tuple(w.shape)}")
     oh, ow = (h + 2 - 3) // stride + 1, (wd + 2 - 3) // stride + 1
-    odt = torch.float32 if epi in _F32_EPIS else torch.bfloat16
+    odt = torch.float32 if epi in _F32_EPIS else x.dtype
     if out is None:
         out = torch.empty((b, oh, ow, cout), dtype=odt, device=x.device)
     if bias is not None:
@@ -113,8 +128,8 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, epi: int = EPI_BF16, st
     # fp32 partial planes of the split-K path, from torch's caching allocator: stream-ordered, capture-safe
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes > 0 else None
     e0 = _prof_begin()
-    _ffi.call("m3_conv3x3_bf16", _ffi.ptr(x), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(out), _ffi.ptr(resid),
-              _ffi.ptr(zero_page(x.device)), b, h, wd, cin, cout, stride, epi, _ffi.ptr(ws), ws_bytes,
+    _ffi.call("m3_conv3x3_dt", _ffi.ptr(x), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(out), _ffi.ptr(resid),
+              _ffi.ptr(zero_page(x.device)), b, h, wd, cin, cout, stride, epi, _ffi.ptr(ws), ws_bytes, dt,
               _ffi.stream_ptr())
     _prof_end(e0, "conv3x3", 2.0 * b * oh * ow * cout * 9 * cin,
               2.0 * (b * h * wd * cin + cout * 9 * cin) + out.element_size() * b * oh * ow * cout * (1 if resid is None else 2))
@@ -124,18 +139,19 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, epi: int = EPI_BF16, st
 def conv3x3_relu_head4(x: torch.Tensor, w: torch.Tensor, bias, w4: torch.Tensor, b4: torch.Tensor):
     """Tail of the DPT head in one launch: relu(conv3x3(x, w) + bias) [128 ch, not materialised] -> 1x1
     projection w4 [4,128] + b4 -> (pts3d [B,H,W,3], conf [B,H,W]) f32 with the pointmap post-processing."""
-    x = _ffi.check(x, torch.bfloat16, "x")
+    x = _ffi.check(x, H16, "x")
     b, h, wd, cin = x.shape
-    w = _ffi.check(w, torch.bfloat16, "w", (128, 3, 3, cin))
-    w4 = _ffi.check(w4, torch.bfloat16, "w4", (4, 128))
+    w = _ffi.check(w, H16, "w", (128, 3, 3, cin))
+    w4 = _ffi.check(w4, H16, "w4", (4, 128))
+    dt = _same16(x, w, w4)
     b4 = _ffi.check(b4, torch.float32, "b4", (4,))
     if bias is not None:
         bias = _ffi.check(bias, torch.float32, "bias", (128,))
     pts = torch.empty((b, h, wd, 3), dtype=torch.float32, device=x.device)
     conf = torch.empty((b, h, wd), dtype=torch.float32, device=x.device)
     e0 = _prof_begin()
-    _ffi.call("m3_conv3x3_relu_head4", _ffi.ptr(x), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(w4), _ffi.ptr(b4),
-              _ffi.ptr(pts), _ffi.ptr(conf), _ffi.ptr(zero_page(x.device)), b, h, wd, cin, _ffi.stream_ptr())
+    _ffi.call("m3_conv3x3_relu_head4_dt", _ffi.ptr(x), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(w4), _ffi.ptr(b4),
+              _ffi.ptr(pts), _ffi.ptr(conf), _ffi.ptr(zero_page(x.device)), b, h, wd, cin, dt, _ffi.stream_ptr())
     _prof_end(e0, "conv3x3", 2.0 * b * h * wd * 128 * (9 * cin + 4), 2.0 * (b * h * wd * cin + 128 * 9 * cin) + 16.0 * b * h * wd)
     return pts, conf
 
@@ -145,60 +161,77 @@ def attention(q, k, v, out, *, nbatch, heads, tq, tk, q_row_stride, kv_row_strid
     """Fused MHA (head dim 64).  q/k/v/out are (views into) bf16 device tensors; the strides are in
     elements, so q, k, v may be column slices of one projection buffer."""
     for name, t in (("q", q), ("k", k), ("v", v), ("out", out)):
-        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.bfloat16):
-            raise TypeError(f"{name}: expected a bf16 tensor on the ROCm device")
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype in H16):
+            raise TypeError(f"{name}: expected a bf16 / fp16 tensor on the ROCm device")
+    dt = _same16(q, k, v, out)
     e0 = _prof_begin()
-    _ffi.call("m3_attention_bf16", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q_row_stride,
+    _ffi.call("m3_attention_dt", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q_row_stride,
               kv_row_stride, o_row_stride, q_batch_stride, kv_batch_stride, o_batch_stride, nbatch, heads, tq, tk,
-              kv_batch_shift, float(scale), _ffi.stream_ptr())
+              kv_batch_shift, float(scale), dt, _ffi.stream_ptr())
     _prof_end(e0, "attention", 4.0 * nbatch * heads * tq * tk * 64, 2.0 * nbatch * heads * 64 * (2 * tq + 2 * tk))
     return out
 
 
 def rope2d_(x, pos_yx, cos_sin, *, row_stride, tokens, heads, tokens_per_image):
     """In-place RoPE-2D on `heads` 64-wide heads starting at x.data_ptr()."""
-    _ffi.call("m3_rope2d_bf16", x.data_ptr(), _ffi.ptr(pos_yx), _ffi.ptr(cos_sin), row_stride, tokens, heads,
-              tokens_per_image, _ffi.stream_ptr())
+    _ffi.call("m3_rope2d_dt", x.data_ptr(), _ffi.ptr(pos_yx), _ffi.ptr(cos_sin), row_stride, tokens, heads,
+              tokens_per_image, DT_CODE[x.dtype], _ffi.stream_ptr())
     return x
 
 
-def layernorm(x, gamma, beta, eps=1e-6, out=None):
+def layernorm(x, gamma, beta, eps=1e-6, out=None, dtype=torch.bfloat16):
     x = _ffi.check(x, torch.float32, "x")
     m, c = x.shape
     if out is None:
-        out = torch.empty((m, c), dtype=torch.bfloat16, device=x.device)
-    _ffi.call("m3_layernorm_bf16", _ffi.ptr(x), _ffi.ptr(gamma), _ffi.ptr(beta), _ffi.ptr(out), m, c, float(eps),
-              _ffi.stream_ptr())
+        out = torch.empty((m, c), dtype=dtype, device=x.device)
+    _ffi.call("m3_layernorm_dt", _ffi.ptr(x), _ffi.ptr(gamma), _ffi.ptr(beta), _ffi.ptr(out), m, c, float(eps),
+              DT_CODE[out.dtype], _ffi.stream_ptr())
     return out
 
 
-def patchify16(img_u8):
+def patchify16(img_u8, dtype=torch.bfloat16):
     img_u8 = _ffi.check(img_u8, torch.uint8, "img")
     b, h, w, _ = img_u8.shape
-    out = torch.empty((b * (h // 16) * (w // 16), 768), dtype=torch.bfloat16, device=img_u8.device)
-    _ffi.call("m3_patchify16", _ffi.ptr(img_u8), _ffi.ptr(out), b, h, w, _ffi.stream_ptr())
+    out = torch.empty((b * (h // 16) * (w // 16), 768), dtype=dtype, device=img_u8.device)
+    _ffi.call("m3_patchify16_dt", _ffi.ptr(img_u8), _ffi.ptr(out), b, h, w, DT_CODE[dtype], _ffi.stream_ptr())
+    return out
+
+
+def cast_f32(x, dtype=torch.bfloat16):
+    """fp32 -> bf16 / fp16, round to nearest even."""
+    x = _ffi.check(x, torch.float32, "x")
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _ffi.call("m3_cast_f32_dt", _ffi.ptr(x), _ffi.ptr(out), x.numel(), DT_CODE[dtype], _ffi.stream_ptr())
     return out
 
 
 def f32_to_bf16(x):
-    x = _ffi.check(x, torch.float32, "x")
-    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    _ffi.call("m3_f32_to_bf16", _ffi.ptr(x), _ffi.ptr(out), x.numel(), _ffi.stream_ptr())
+    return cast_f32(x, torch.bfloat16)
+
+
+def cast16(x, dtype):
+    """bf16 <-> fp16 (through fp32, round to nearest even; bf16 -> fp16 is exact for |x| in [6.1e-5, 65504])."""
+    x = _ffi.check(x, H16, "x")
+    if x.dtype == dtype:
+        return x
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _ffi.call("m3_cast16", _ffi.ptr(x), _ffi.ptr(out), x.numel(), DT_CODE[x.dtype], DT_CODE[dtype], _ffi.stream_ptr())
     return out
 
 
 def relu(x):
-    x = _ffi.check(x, torch.bfloat16, "x")
+    x = _ffi.check(x, H16, "x")
     out = torch.empty_like(x)
     _ffi.call("m3_relu_bf16", _ffi.ptr(x), _ffi.ptr(out), x.numel(), _ffi.stream_ptr())
     return out
 
 
 def concat2(a, b):
-    a = _ffi.check(a, torch.bfloat16, "a")
-    b = _ffi.check(b, torch.bfloat16, "b")
+    a = _ffi.check(a, H16, "a")
+    b = _ffi.check(b, H16, "b")
+    _same16(a, b)
     m = a.shape[0]
-    out = torch.empty((m, a.shape[1] + b.shape[1]), dtype=torch.bfloat16, device=a.device)
+    out = torch.empty((m, a.shape[1] + b.shape[1]), dtype=a.dtype, device=a.device)
     _ffi.call("m3_concat2_bf16", _ffi.ptr(a), _ffi.ptr(b), _ffi.ptr(out), m, a.shape[1], b.shape[1],
               _ffi.stream_ptr())
     return out
@@ -207,18 +240,18 @@ def concat2(a, b):
 def unshuffle(x, b, h, w, s, c, cpad=None):
     """[B*h*w, s*s*c] -> NHWC [B,h*s,w*s,cpad] (extra channels zero)."""
     cpad = cpad or c
-    x = _ffi.check(x, torch.bfloat16, "x", (b * h * w, s * s * c))
+    x = _ffi.check(x, H16, "x", (b * h * w, s * s * c))
     alloc = torch.zeros if cpad != c else torch.empty
-    out = alloc((b, h * s, w * s, cpad), dtype=torch.bfloat16, device=x.device)
+    out = alloc((b, h * s, w * s, cpad), dtype=x.dtype, device=x.device)
     _ffi.call("m3_unshuffle_bf16", _ffi.ptr(x), _ffi.ptr(out), b, h, w, s, c, cpad, _ffi.stream_ptr())
     return out
 
 
 def upsample2x(x):
-    x = _ffi.check(x, torch.bfloat16, "x")
+    x = _ffi.check(x, H16, "x")
     b, h, w, c = x.shape
-    out = torch.empty((b, 2 * h, 2 * w, c), dtype=torch.bfloat16, device=x.device)
-    _ffi.call("m3_upsample2x_bf16", _ffi.ptr(x), _ffi.ptr(out), b, h, w, c, _ffi.stream_ptr())
+    out = torch.empty((b, 2 * h, 2 * w, c), dtype=x.dtype, device=x.device)
+    _ffi.call("m3_upsample2x_dt", _ffi.ptr(x), _ffi.ptr(out), b, h, w, c, DT_CODE[x.dtype], _ffi.stream_ptr())
     return out
 
 
@@ -233,32 +266,33 @@ def pts_post(raw):
 
 
 def desc_post(f, b, h, w):
-    f = _ffi.check(f, torch.bfloat16, "f", (b * (h // 16) * (w // 16), 6400))
+    f = _ffi.check(f, H16, "f", (b * (h // 16) * (w // 16), 6400))
     desc = torch.empty((b, h, w, 24), dtype=torch.float32, device=f.device)
     dconf = torch.empty((b, h, w), dtype=torch.float32, device=f.device)
-    _ffi.call("m3_desc_post", _ffi.ptr(f), _ffi.ptr(desc), _ffi.ptr(dconf), b, h, w, _ffi.stream_ptr())
+    _ffi.call("m3_desc_post_dt", _ffi.ptr(f), _ffi.ptr(desc), _ffi.ptr(dconf), b, h, w, DT_CODE[f.dtype], _ffi.stream_ptr())
     return desc, dconf
 
 
 def add(a, b):
-    a = _ffi.check(a, torch.bfloat16, "a")
-    b = _ffi.check(b, torch.bfloat16, "b", tuple(a.shape))
+    a = _ffi.check(a, H16, "a")
+    b = _ffi.check(b, H16, "b", tuple(a.shape))
     out = torch.empty_like(a)
-    _ffi.call("m3_add_bf16", _ffi.ptr(a), _ffi.ptr(b), _ffi.ptr(out), a.numel(), _ffi.stream_ptr())
+    _ffi.call("m3_add_dt", _ffi.ptr(a), _ffi.ptr(b), _ffi.ptr(out), a.numel(), _same16(a, b), _ffi.stream_ptr())
     return out
 
 
 def gemm_grouped2(a, w0, w1, b0, b1, epi=EPI_BF16, out=None, resid=None, rope=None):
     """Two same-shape GEMMs in one launch.  a [2,M,K] bf16, weights [N,K] x2 -> out [2,M,N].
     rope = (pos_yx, cos_sin, tokens_per_image, rope_cols) with epi=EPI_BF16_ROPE."""
-    a = _ffi.check(a, torch.bfloat16, "a")
+    a = _ffi.check(a, H16, "a")
     if a.dim() != 3 or a.shape[0] != 2:
         raise ValueError(f"a must be [2,M,K], got {tuple(a.shape)}")
     _, m, k = a.shape
-    w0 = _ffi.check(w0, torch.bfloat16, "w0")
-    w1 = _ffi.check(w1, torch.bfloat16, "w1", tuple(w0.shape))
+    w0 = _ffi.check(w0, H16, "w0")
+    w1 = _ffi.check(w1, H16, "w1", tuple(w0.shape))
+    dt = _same16(a, w0, w1)
     n = w0.shape[0]
-    odt = torch.float32 if epi in _F32_EPIS else torch.bfloat16
+    odt = torch.float32 if epi in _F32_EPIS else a.dtype
     if out is None:
         out = torch.empty((2, m, n), dtype=odt, device=a.device)
     elif out.dtype != odt or tuple(out.shape) != (2, m, n) or not out.is_contiguous():
@@ -267,18 +301,18 @@ def gemm_grouped2(a, w0, w1, b0, b1, epi=EPI_BF16, out=None, resid=None, rope=No
         raise ValueError("bad `resid`")
     pos, cs, tpi, rc = rope if rope is not None else (None, None, 0, 0)
     e0 = _prof_begin()
-    _ffi.call("m3_gemm_bf16_grouped2", _ffi.ptr(a), _ffi.ptr(w0), _ffi.ptr(w1), _ffi.ptr(b0), _ffi.ptr(b1), _ffi.ptr(out),
-              _ffi.ptr(resid), m, n, k, n, m * k, m * n, epi, _ffi.ptr(pos), _ffi.ptr(cs), tpi, rc, _ffi.stream_ptr())
+    _ffi.call("m3_gemm_grouped2_dt", _ffi.ptr(a), _ffi.ptr(w0), _ffi.ptr(w1), _ffi.ptr(b0), _ffi.ptr(b1), _ffi.ptr(out),
+              _ffi.ptr(resid), m, n, k, n, m * k, m * n, epi, _ffi.ptr(pos), _ffi.ptr(cs), tpi, rc, dt, _ffi.stream_ptr())
     _prof_end(e0, _gemm_kind(m, n, 2), 4.0 * m * n * k,
               2.0 * (2.0 * (m * k + n * k) + out.element_size() * m * n * (1 if resid is None else 2)))
     return out
 
 
-def layernorm_grouped2(x, g0, b0, g1, b1, swap=False, eps=1e-6):
-    """x f32 [2,M,C] -> bf16 [2,M,C]; group v uses (g_v, b_v); swap=True normalises the OTHER group's rows."""
+def layernorm_grouped2(x, g0, b0, g1, b1, swap=False, eps=1e-6, dtype=torch.bfloat16):
+    """x f32 [2,M,C] -> 16-bit [2,M,C]; group v uses (g_v, b_v); swap=True normalises the OTHER group's rows."""
     x = _ffi.check(x, torch.float32, "x")
     _, m, c = x.shape
-    out = torch.empty((2, m, c), dtype=torch.bfloat16, device=x.device)
-    _ffi.call("m3_layernorm_bf16_grouped2", _ffi.ptr(x), _ffi.ptr(g0), _ffi.ptr(b0), _ffi.ptr(g1), _ffi.ptr(b1),
-              _ffi.ptr(out), m, c, m if swap else 0, float(eps), _ffi.stream_ptr())
+    out = torch.empty((2, m, c), dtype=dtype, device=x.device)
+    _ffi.call("m3_layernorm_grouped2_dt", _ffi.ptr(x), _ffi.ptr(g0), _ffi.ptr(b0), _ffi.ptr(g1), _ffi.ptr(b1),
+              _ffi.ptr(out), m, c, m if swap else 0, float(eps), DT_CODE[dtype], _ffi.stream_ptr())
     return out

@@ -154,3 +154,40 @@ def test_resize_img_contract():
     assert tuple(resize_img(img, 224)["img"].shape) == (1, 224, 224, 3)
     small = r.integers(0, 256, size=(120, 160, 3), dtype=np.uint8)           # enlarging path (BICUBIC)
     assert tuple(resize_img(small, 512)["img"].shape) == (1, 384, 512, 3)
+
+
+def test_checkpoint_loader_layouts_cpu(tmp_path):
+    """model.load_state_dict (behind Mast3rFull.from_pretrained(weights_path=...), reference call
+    mast3r_utils.py:67-76): bare state dict, the public checkpoint wrapper {"model": ..., "args": Namespace}
+    (which torch.load's weights_only default refuses), safetensors; unrelated files are rejected."""
+    import argparse
+
+    import torch
+
+    from mast3r_slam import model as M
+    w = M.init_random_weights(dict(M.TINY_CFG, enc_depth=1, dec_depth=1, hooks=(0, 1, 1, 1)), seed=3)
+    torch.save(w, tmp_path / "bare.pth")
+    torch.save({"model": dict(w, mask_token=torch.zeros(1, 1, 768).half()), "args": argparse.Namespace(x=1), "epoch": 7},
+               tmp_path / "ckpt.pth")
+    from safetensors.torch import save_file
+    save_file({k: v.contiguous() for k, v in w.items()}, str(tmp_path / "w.safetensors"))
+    for name in ("bare.pth", "ckpt.pth", "w.safetensors"):
+        sd = M.load_state_dict(str(tmp_path / name))
+        assert all(torch.equal(sd[k], v) and sd[k].dtype == torch.float32 for k, v in w.items()), name
+    torch.save({"foo": torch.zeros(2)}, tmp_path / "bad.pth")
+    with pytest.raises(KeyError, match="not a MASt3R state dict"):
+        M.load_state_dict(str(tmp_path / "bad.pth"))
+
+
+def test_precision_argument_is_validated_before_the_device_is_needed():
+    """load_mast3r's precision (mast3r_utils.py:51: "fp16" | "fp32" | "bf16"): an unknown value is a ValueError
+    even on a box without a GPU; a known one only then asks for the device (RuntimeError here, no CPU path)."""
+    import torch
+
+    from mast3r_slam import mast3r_utils
+    with pytest.raises(ValueError, match="precision"):
+        mast3r_utils.load_mast3r("mast3r_full", precision="int8")
+    if not torch.cuda.is_available():
+        for prec in ("bf16", "fp16", "fp32"):
+            with pytest.raises(RuntimeError, match="ROCm device"):
+                mast3r_utils.load_mast3r("mast3r_full", precision=prec)

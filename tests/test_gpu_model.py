@@ -19,14 +19,19 @@ def _rel(a, b):
     return float((a.float().cpu() - b.float().cpu()).norm() / b.float().cpu().norm())
 
 
+DT16 = [torch.bfloat16, torch.float16]
+TOL16 = {torch.bfloat16: 3e-3, torch.float16: 4e-4}      # storage rounding 2^-9 / 2^-12 (relative, per element)
+
+
+@pytest.mark.parametrize("dt", DT16)
 @pytest.mark.parametrize("epi", [ops.EPI_BF16, ops.EPI_BF16_GELU, ops.EPI_F32, ops.EPI_F32_ACCUM, ops.EPI_BF16_RELU,
                                  ops.EPI_BF16_ADD])
 @pytest.mark.parametrize("shape", [(256, 256, 128), (300, 132, 64), (2048, 768, 3072), (128, 4, 64)])
-def test_gemm_epilogues(dev, epi, shape):
+def test_gemm_epilogues(dev, epi, shape, dt):
     m, n, k = shape
     g = torch.Generator(device="cpu").manual_seed(m + n + k + epi)
-    a = torch.randn(m, k, generator=g).bfloat16()
-    w = (torch.randn(n, k, generator=g) * 0.05).bfloat16()
+    a = torch.randn(m, k, generator=g).to(dt)
+    w = (torch.randn(n, k, generator=g) * 0.05).to(dt)
     b = torch.randn(n, generator=g)
     ref = a.float() @ w.float().T + b
     r = None
@@ -37,11 +42,11 @@ def test_gemm_epilogues(dev, epi, shape):
     if epi == ops.EPI_F32_ACCUM:
         r = torch.randn(m, n, generator=g); ref = ref + r
     if epi == ops.EPI_BF16_ADD:
-        r = torch.randn(m, n, generator=g).bfloat16(); ref = ref + r.float()
+        r = torch.randn(m, n, generator=g).to(dt); ref = ref + r.float()
     out = ops.gemm(a.to(dev), w.to(dev), b.to(dev), epi, resid=None if r is None else r.to(dev))
     f32 = epi in (ops.EPI_F32, ops.EPI_F32_ACCUM)
-    assert out.dtype == (torch.float32 if f32 else torch.bfloat16)
-    assert _rel(out, ref) < (2e-6 if f32 else 3e-3)            # fp32 accumulate; bf16 output rounding 2^-9
+    assert out.dtype == (torch.float32 if f32 else dt)
+    assert _rel(out, ref) < (2e-6 if f32 else TOL16[dt])       # fp32 accumulate; 16-bit output rounding
 
 
 @pytest.mark.parametrize("epi", [ops.EPI_BF16, ops.EPI_BF16_GELU, ops.EPI_F32_ACCUM, ops.EPI_BF16_ADD])
@@ -101,30 +106,32 @@ def test_gemm_rejects_bad_k(dev):
         ops.gemm(torch.zeros(128, 96, device=dev).bfloat16(), torch.zeros(128, 96, device=dev).bfloat16())
 
 
+@pytest.mark.parametrize("dt", DT16)
 @pytest.mark.parametrize("cfg", [(2, 16, 16, 64, 128, 1), (1, 32, 32, 256, 256, 1), (1, 32, 32, 128, 64, 2),
-                                 (1, 20, 28, 64, 36, 1)])
-def test_conv3x3_implicit_gemm(dev, cfg):
+                                 (1, 20, 28, 64, 36, 1), (2, 128, 128, 64, 256, 1)])       # last: 256-row ping-pong conv
+def test_conv3x3_implicit_gemm(dev, cfg, dt):
     b, h, w_, cin, cout, s = cfg
     g = torch.Generator().manual_seed(sum(cfg))
-    x = torch.randn(b, h, w_, cin, generator=g).bfloat16()
-    w = (torch.randn(cout, 3, 3, cin, generator=g) * 0.05).bfloat16()
+    x = torch.randn(b, h, w_, cin, generator=g).to(dt)
+    w = (torch.randn(cout, 3, 3, cin, generator=g) * 0.05).to(dt)
     bias = torch.randn(cout, generator=g)
     ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias, stride=s, padding=1).permute(0, 2, 3, 1)
     out = ops.conv3x3(x.to(dev), w.to(dev), bias.to(dev), ops.EPI_F32, stride=s)
     assert tuple(out.shape) == tuple(ref.shape) and _rel(out, ref) < 2e-6
-    res = torch.randn(ref.shape, generator=g).bfloat16()
+    res = torch.randn(ref.shape, generator=g).to(dt)
     out = ops.conv3x3(x.to(dev), w.to(dev), bias.to(dev), ops.EPI_BF16_ADD, stride=s, resid=res.to(dev))
-    assert _rel(out, ref + res.float()) < 3e-3
+    assert out.dtype == dt and _rel(out, ref + res.float()) < TOL16[dt]
 
 
+@pytest.mark.parametrize("dt", DT16)
 @pytest.mark.parametrize("cross", [False, True])
-def test_attention_vs_softmax_reference(dev, cross):
+def test_attention_vs_softmax_reference(dev, cross, dt):
     b, h, t = 2, 3, 256
     g = torch.Generator().manual_seed(7)
     c = h * 64
-    qkv = torch.randn(b * t, 3 * c, generator=g).bfloat16()
+    qkv = torch.randn(b * t, 3 * c, generator=g).to(dt)
     qkv[5, :64] *= 30.0                                           # a spiked query: exercises the running-max rescale
-    out = torch.empty(b * t, c, dtype=torch.bfloat16, device=dev)
+    out = torch.empty(b * t, c, dtype=dt, device=dev)
     d = qkv.to(dev)
     ops.attention(d, d[:, c:], d[:, 2 * c:], out, nbatch=b, heads=h, tq=t, tk=t, q_row_stride=3 * c,
                   kv_row_stride=3 * c, o_row_stride=c, q_batch_stride=t * 3 * c, kv_batch_stride=t * 3 * c,
@@ -135,8 +142,31 @@ def test_attention_vs_softmax_reference(dev, cross):
     if cross:
         k, v = k.roll(-1, 0), v.roll(-1, 0)                      # batch item i attends item (i+1) % b
     ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).transpose(1, 2).reshape(b * t, c)
-    assert _rel(out, ref) < 4e-3                                  # P and O are bf16
+    assert _rel(out, ref) < (4e-3 if dt == torch.bfloat16 else 6e-4)     # P and O are 16-bit
     assert torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("tq_tk_b_h", [(672, 672, 2, 16), (576, 576, 16, 12), (196, 196, 1, 2), (200, 150, 2, 3),
+                                       (1, 1, 1, 1), (65, 129, 1, 2)])
+def test_attention_ragged_token_counts(dev, tq_tk_b_h):
+    """Token counts that are not multiples of the 64-key tile / 64- or 128-row query block: 512x336 -> 672,
+    512x288 -> 576, 224x224 -> 196 (what resize_img emits, mast3r_utils.py:132-207), and tiny ragged cases.
+    Key tail masked with -inf, query tail rows not stored: rows past Tq of a padded output buffer stay untouched."""
+    tq, tk, b, h = tq_tk_b_h
+    g = torch.Generator().manual_seed(tq + tk)
+    c = h * 64
+    q = torch.randn(b, tq, c, generator=g).bfloat16()
+    kv = torch.randn(b, tk, 2 * c, generator=g).bfloat16()
+    out = torch.full((b, tq + 3, c), 7.0, dtype=torch.bfloat16, device=dev)        # 3 guard rows per batch item
+    qd, kvd = q.to(dev), kv.to(dev)
+    ops.attention(qd, kvd, kvd[..., c:], out, nbatch=b, heads=h, tq=tq, tk=tk, q_row_stride=c, kv_row_stride=2 * c,
+                  o_row_stride=c, q_batch_stride=tq * c, kv_batch_stride=tk * 2 * c, o_batch_stride=(tq + 3) * c)
+    qf = q.float().view(b, tq, h, 64).transpose(1, 2)
+    kf = kv[..., :c].float().view(b, tk, h, 64).transpose(1, 2)
+    vf = kv[..., c:].float().view(b, tk, h, 64).transpose(1, 2)
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * 0.125, -1) @ vf).transpose(1, 2).reshape(b, tq, c)
+    assert _rel(out[:, :tq], ref) < 4e-3
+    assert bool((out[:, tq:] == 7.0).all())
 
 
 def test_rope2d_layernorm_and_elementwise(dev):
@@ -172,27 +202,60 @@ def test_rope2d_layernorm_and_elementwise(dev):
     assert torch.equal(ops.add(r.to(dev), r.to(dev)).cpu(), (r.float() * 2).bfloat16())
 
 
-def test_fused_head_tail_matches_unfused_chain(dev):
-    """conv3x3+ReLU -> 1x1 (4 ch) -> pts_post in one launch vs the three separate ops (same bf16 rounding of
-    the 128-channel map, fp32 summation order differs) and vs a plain torch fp32 reference."""
+def test_fp16_storage_variants_of_the_elementwise_ops(dev):
+    """The *_dt entry points with dtype = M3_DT_F16: LayerNorm / cast outputs, upsample, add, ReLU (sign bit),
+    bf16 <-> fp16 cast, patchify and the descriptor post-processing read."""
+    g = torch.Generator().manual_seed(4)
+    xf = torch.randn(37, 768, generator=g) * 3 + 1
+    gm, bt = torch.randn(768, generator=g), torch.randn(768, generator=g)
+    out = ops.layernorm(xf.to(dev), gm.to(dev), bt.to(dev), dtype=torch.float16)
+    assert out.dtype == torch.float16 and _rel(out, F.layer_norm(xf, (768,), gm, bt, 1e-6)) < 4e-4
+    v = torch.randn(1000, generator=g) * 10
+    assert torch.equal(ops.cast_f32(v.to(dev), torch.float16).cpu(), v.half())
+    y = torch.randn(2, 5, 7, 16, generator=g).half()
+    ref = F.interpolate(y.float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    assert _rel(ops.upsample2x(y.to(dev)), ref) < 4e-4
+    r = torch.randn(64, generator=g).half()
+    assert torch.equal(ops.relu(r.to(dev)).cpu(), torch.relu(r))
+    assert torch.equal(ops.add(r.to(dev), r.to(dev)).cpu(), (r.float() * 2).half())
+    b16 = (torch.randn(4096, generator=g) * 5).bfloat16()
+    assert torch.equal(ops.cast16(b16.to(dev), torch.float16).cpu(), b16.float().half())
+    assert torch.equal(ops.cast16(b16.float().half().to(dev), torch.bfloat16).cpu(), b16.float().half().float().bfloat16())
+    img = torch.randint(0, 256, (1, 32, 48, 3), generator=g, dtype=torch.uint8)
+    pa = ops.patchify16(img.to(dev), torch.float16)
+    x = ((img.float() / 255.0 - 0.5) / 0.5).permute(0, 3, 1, 2)
+    assert torch.equal(pa.cpu(), F.unfold(x, kernel_size=16, stride=16).transpose(1, 2).reshape(-1, 768).half())
+    f = torch.randn(2 * 1 * 2, 6400, generator=g).half()
+    desc, dconf = ops.desc_post(f.to(dev), 2, 16, 32)
+    ps = F.pixel_shuffle(f.float().view(2, 2, 6400).transpose(1, 2).reshape(2, 6400, 1, 2), 16).permute(0, 2, 3, 1)
+    assert _rel(desc, ps[..., :24] / ps[..., :24].norm(dim=-1, keepdim=True)) < 1e-6
+    with pytest.raises(TypeError, match="mixed 16-bit"):
+        ops.add(r.to(dev), r.bfloat16().to(dev))
+
+
+@pytest.mark.parametrize("dt", DT16)
+def test_fused_head_tail_matches_unfused_chain(dev, dt):
+    """conv3x3+ReLU -> 1x1 (4 ch) -> pts_post in one launch.  The fused kernel keeps the 128-channel ReLU map in
+    fp32 registers (never rounded to 16 bits), so it matches a plain torch fp32 reference to fp32 accuracy; the
+    three separate ops round that map once and agree to the 16-bit rounding."""
     g = torch.Generator(device="cpu").manual_seed(21)
     b, h, w, cin = 1, 50, 120, 64                                            # ragged: 6000 pixels (no split-K at this size)
-    x = torch.randn(b, h, w, cin, generator=g).bfloat16()
-    wc = (torch.randn(128, 3, 3, cin, generator=g) * 0.05).bfloat16()
+    x = torch.randn(b, h, w, cin, generator=g).to(dt)
+    wc = (torch.randn(128, 3, 3, cin, generator=g) * 0.05).to(dt)
     bc = torch.randn(128, generator=g) * 0.1
-    w4 = (torch.randn(4, 128, generator=g) * 0.05).bfloat16()
+    w4 = (torch.randn(4, 128, generator=g) * 0.05).to(dt)
     b4 = torch.randn(4, generator=g) * 0.1
     d = lambda t: t.to(dev)
     pts, conf = ops.conv3x3_relu_head4(d(x), d(wc), d(bc), d(w4), d(b4))
     h2 = ops.conv3x3(d(x), d(wc), d(bc), ops.EPI_BF16_RELU)
     raw = ops.gemm(h2.view(-1, 128), d(w4), d(b4), ops.EPI_F32)
     pts_u, conf_u = ops.pts_post(raw.view(b, h, w, 4))
-    assert _rel(pts, pts_u) < 2e-6 and _rel(conf, conf_u) < 2e-6
+    assert _rel(pts, pts_u) < TOL16[dt] and _rel(conf, conf_u) < TOL16[dt]
     y = torch.relu(F.conv2d(x.float().permute(0, 3, 1, 2), wc.float().permute(0, 3, 1, 2), bc, padding=1)).permute(0, 2, 3, 1)
-    r = y.bfloat16().float() @ w4.float().T + b4
+    r = y @ w4.float().T + b4
     dn = r[..., :3].norm(dim=-1, keepdim=True)
-    assert _rel(pts, r[..., :3] / dn.clip(min=1e-8) * torch.expm1(dn)) < 2e-3      # bf16 rounding flips of the hidden map
-    assert _rel(conf, 1 + torch.exp(r[..., 3])) < 2e-3
+    assert _rel(pts, r[..., :3] / dn.clip(min=1e-8) * torch.expm1(dn)) < 5e-6      # fp32 accumulation order only
+    assert _rel(conf, 1 + torch.exp(r[..., 3])) < 5e-6
 
 
 @pytest.mark.parametrize("shape", [(1024, 768, 256), (16384, 768, 128)])       # 64/128-tile path and the 256x192 path

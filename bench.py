@@ -35,6 +35,7 @@ import torch  # noqa: E402
 
 H = W = 512
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16, MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_GBS = 8000.0               # HBM3E peak, same table (6.29 TB/s measured by a float4 copy)
 
 
 def parse():
@@ -52,25 +53,50 @@ def parse():
     return ap.parse_args()
 
 
-def pmc_traffic_per_launch(prefixes):
-    """HBM bytes per launch of the dense GEMM kernels, from the committed PMC summary of this command
-    (FETCH_SIZE and WRITE_SIZE cannot be collected inside the timed run: separate rocprofv3 passes,
-    tools/prof_summary.py).  None when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+def pmc_traffic(prefixes):
+    """HBM bytes per launch of the kernels whose name starts with one of `prefixes`, from the newest committed PMC
+    summary of this command (FETCH_SIZE and WRITE_SIZE cannot be collected inside the timed run: separate rocprofv3
+    passes, tools/prof_summary.py).  (None, None) when no summary is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
     try:
-        kern = json.load(open(path))["kernels"]
+        kern = json.load(open(files[-1]))["kernels"]
     except (OSError, ValueError, KeyError):
-        return None
+        return None, None
     sel = [v for k, v in kern.items() if k.startswith(prefixes)]
     n = sum(v["launches"] for v in sel)
-    return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / n if n else None
+    return (sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / n if n else None), os.path.basename(files[-1])
 
 
-def make_inputs(model_mod, synthetic, pairs, rank, dev):
+def make_inputs(synthetic, pairs, rank, dev):
     base = rank * pairs
     im1 = np.stack([synthetic.textured_image(H, W, 2 * (base + p)) for p in range(pairs)])
     im2 = np.stack([synthetic.textured_image(H, W, 2 * (base + p) + 1) for p in range(pairs)])
     return torch.from_numpy(im1).to(dev), torch.from_numpy(im2).to(dev)
+
+
+def make_scene(synthetic, pairs, rank, dev):
+    """What the matcher and the Gauss-Newton solve run on: P smooth two-view scenes of
+    the benchmark size - pointmaps of both views in the frame's coordinates, 24-d descriptors, confidences and
+    descriptor confidences drawn so that the tracker's gates (tracker.py:108-113: C > 0, Q > 1.5) pass for most
+    points, and the keyframe's own canonical pointmap Xk = T * X21 under a known small Sim(3) (2 degrees about y,
+    t = (0.05, 0, 0.01), s = 1.02) that the solve has to recover.  Random-init weights give neither matchable
+    geometry nor confidences above the gates, so feeding the network's outputs here would time a matcher on
+    white noise and a solver on ~0 valid points (round-1 verdict)."""
+    base = rank * pairs
+    sc = synthetic.geometric_pair(H, W, seed=1000 + base, batch=pairs)
+    rng = np.random.default_rng(2000 + base)
+    n = H * W
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ang = np.deg2rad(2.0)
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    Xk = (1.02 * sc["X21"].reshape(pairs, n, 3).astype(np.float64) @ R.T + np.array([0.05, 0.0, 0.01])).astype(np.float32)
+    u = lambda lo, hi: rng.uniform(lo, hi, size=(pairs, n)).astype(np.float32)
+    return dict(X11=t(sc["X11"]), X21=t(sc["X21"]), D11=t(sc["D11"]), D21=t(sc["D21"]), Xk=t(Xk),
+                Cf=t(u(1.0, 3.0)), Ck=t(u(1.0, 3.0)), Qf=t(u(1.0, 4.0)), Qk=t(u(1.0, 4.0)),
+                T_true=np.array([0.05, 0.0, 0.01, 0.0, np.sin(ang / 2), 0.0, np.cos(ang / 2), 1.02]))
 
 
 def main():
@@ -97,85 +123,94 @@ def main():
 
     P = args.pairs_per_gpu
     config.set_config({"matching": {"use_simple": False}})            # the iter_proj + refine matcher
-    net = model_mod.Mast3rFull(seed=0, device=dev)
-    im1, im2 = make_inputs(model_mod, synthetic, P, rank, dev)
+    net = model_mod.Mast3rFull(seed=0, device=dev, precision="bf16")
+    im1, im2 = make_inputs(synthetic, P, rank, dev)
+    sc = make_scene(synthetic, P, rank, dev)
     ident = torch.tensor([0, 0, 0, 0, 0, 0, 1, 1], dtype=torch.float32, device=dev)
     n = H * W
     tcfg = config.get_config()["tracking"]
-    stage_ms = {"infer": 0.0, "match": 0.0, "gn": 0.0, "gather": 0.0}
     ev = lambda: torch.cuda.Event(enable_timing=True)
 
-    def compute(timers=None, marks=None):
-        mark = (lambda: (marks.append(ev()), marks[-1].record())) if timers is not None else (lambda: None)
-        mark()
+    # ---- the three legs of a step.  Each writes into tensors that stay alive (graph-static buffers). ----
+    def leg_infer():
         o1, o2 = net.reconstruct_batch(im1, im2)
-        mark()
-        idx, valid = matching.match(o1["pts3d"], o2["pts3d"], o1["desc"], o2["desc"])
-        mark()
-        # frame = view 1 (its own camera), keyframe = view 2; the keyframe's canonical points stand in as
-        # X_ji (same shapes and data flow as FrameTracker.track, tracker.py:88-123); all P solves batched
-        Xf, Qk, vo, vk, cnt = tracker.track_gather(
-            o1["pts3d"].reshape(P, n, 3), o1["conf"].reshape(P, n), o2["conf"].reshape(P, n),
-            o1["desc_conf"].reshape(P, n), o2["desc_conf"].reshape(P, n), idx, valid.reshape(P, n),
-            tcfg["C_conf"], tcfg["Q_conf"])
-        poses, T_rel, info = tracker.opt_pose_ray_dist_sim3(Xf, o2["pts3d"].reshape(P, n, 3), ident, ident, Qk, vo, tcfg,
-                                                           fixed_iters=True)
-        mark()
-        return (o1["pts3d"], o2["pts3d"], o1["conf"], o2["conf"], idx, valid, poses)
+        return o1, o2
 
-    def wire(out):
+    def leg_match():
+        return matching.match(sc["X11"], sc["X21"], sc["D11"], sc["D21"])
+
+    def leg_gn(idx, valid):
+        # FrameTracker.track's data flow (tracker.py:88-123, :177-214): frame = view 1, keyframe = view 2;
+        # gather the frame's points at the match index, gate on confidences, then the 10-iteration solve of
+        # all P problems in one launch sequence
+        Xf, Qk, vo, vk, cnt = tracker.track_gather(sc["X11"].reshape(P, n, 3), sc["Cf"], sc["Ck"], sc["Qf"], sc["Qk"],
+                                                   idx, valid.reshape(P, n), tcfg["C_conf"], tcfg["Q_conf"])
+        poses, T_rel, info = tracker.opt_pose_ray_dist_sim3(Xf, sc["Xk"], ident, ident, Qk, vo, tcfg, fixed_iters=True)
+        return poses, T_rel, info, vo
+
+    def wire(o1, o2, idx, valid, poses):
         """What travels: pointmaps + confidences fp32, match index int32, validity u8, poses."""
-        return out[:4] + (out[4].to(torch.int32),) + out[5:]
+        return (o1["pts3d"], o2["pts3d"], o1["conf"], o2["conf"], idx.to(torch.int32), valid, poses)
 
-    def step(timers=None):
-        marks = []
-        out = compute(timers, marks)
-        if dist is not None:
-            out = m3dist.all_gather_results(wire(out))
-        if timers is not None:
-            marks.append(ev()); marks[-1].record()
-            torch.cuda.synchronize()
-            for k, (a, b) in zip(("infer", "match", "gn", "gather"), zip(marks[:-1], marks[1:])):
-                timers[k] += a.elapsed_time(b)
-        return out
-
-    # Capture the compute part of the step (~1500 launches) into a hipGraph: replay removes the host launch
-    # path, which matters for small per-GPU batches (a B=1 step is launch-bound when issued eagerly).  The
-    # RCCL all-gather (N > 1) is issued eagerly on the graph's static result buffers after each replay.
-    graph = None
+    # eager warm-up (lazy allocations, attribute setup), then capture each leg into its own hipGraph: the step
+    # is ~1600 launches, replay removes the host launch path (a B=1 step is launch-bound when issued eagerly).
+    # Three graphs instead of one so that stream events BETWEEN the replays give device time per stage inside
+    # the timed region itself.
+    for _ in range(2):
+        o1, o2 = leg_infer(); idx, valid = leg_match(); gn = leg_gn(idx, valid)
+    torch.cuda.synchronize()
+    graphs = None
     if not args.no_graph:
         try:
-            for _ in range(2):
-                step()
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                graph_out = compute()
+            graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
+            with torch.cuda.graph(graphs[0]):
+                o1, o2 = leg_infer()
+            with torch.cuda.graph(graphs[1]):
+                idx, valid = leg_match()
+            with torch.cuda.graph(graphs[2]):
+                gn = leg_gn(idx, valid)
             torch.cuda.synchronize()
         except Exception as e:                                   # noqa: BLE001 - reported, never silent
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            graph = None
-    if graph is None:
-        run_step = step
-    elif dist is None:
-        run_step = graph.replay
-    else:
-        pending = []
+            graphs = None
+    state = {"o1": o1, "o2": o2, "idx": idx, "valid": valid, "gn": gn}
+    marks = []           # per timed step: 4 events (start, after infer, after match, after GN)
+    pending = []
 
-        def run_step():
-            # replay, snapshot the static result buffers (pack = one cat kernel), and let RCCL gather the
-            # snapshot on its own stream while the next replay computes; at most one gather in flight
-            graph.replay()
+    def run_step(timed=False):
+        m = [ev() for _ in range(4)] if timed else None
+        if m: m[0].record()
+        if graphs is not None:
+            graphs[0].replay()
+        else:
+            state["o1"], state["o2"] = leg_infer()
+        if m: m[1].record()
+        if graphs is not None:
+            graphs[1].replay()
+        else:
+            state["idx"], state["valid"] = leg_match()
+        if m: m[2].record()
+        if graphs is not None:
+            graphs[2].replay()
+        else:
+            state["gn"] = leg_gn(state["idx"], state["valid"])
+        if m:
+            m[3].record()
+            marks.append(m)
+        if dist is not None:
+            # snapshot the result buffers (pack = one cat kernel) and let RCCL gather the snapshot on its own
+            # stream while the next step computes; at most one gather in flight
             if pending:
                 pending.pop().wait()
-            pending.append(m3dist.all_gather_results(wire(graph_out), async_op=True))
+            pending.append(m3dist.all_gather_results(wire(state["o1"], state["o2"], state["idx"], state["valid"],
+                                                          state["gn"][0]), async_op=True))
 
     for _ in range(args.warmup):
         run_step()
 
     def barrier():
         if dist is not None:
-            if graph is not None and pending:
+            if pending:
                 pending.pop().wait()                               # the last step's gather belongs to the timed region
             dist.barrier()
         torch.cuda.synchronize()
@@ -183,30 +218,64 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        run_step()
+        run_step(timed=True)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    stage_ms = {k: sum(m[i].elapsed_time(m[i + 1]) for m in marks) / len(marks)
+                for i, k in enumerate(("infer", "match", "gn"))}
+    stage_ms["sum"] = sum(stage_ms.values())
 
-    # ---- untimed instrumented passes: per-stage times and per-launch MFMA kernel timing --------------
-    step(stage_ms)
+    # ---- did the match and GN legs do the work they name? ------------------------------------------------
+    poses, T_rel, info, vo = state["gn"]
+    match_valid_frac = float(state["valid"].float().mean())
+    valid_frac = float(vo.float().mean())
+    pose_err = float(np.abs(T_rel.double().cpu().numpy() - sc["T_true"][None]).max())
+    if match_valid_frac < 0.5 or valid_frac < 0.5:
+        raise SystemExit(f"bench invalid: match_valid_frac={match_valid_frac:.3f} valid_frac={valid_frac:.3f} (< 0.5): "
+                         "the matcher / Gauss-Newton legs would be timed on rejected points")
+
+    # ---- untimed instrumented pass (eager, launches serialised): per-launch device time by kernel family ----
     ops.PROFILE = []
+    _ffi.PROFILE = {}
+    _ffi.PROFILE_NAMES = ("m3_prep_iter_proj", "m3_iter_proj", "m3_refine_matches", "m3_match_epilogue",
+                          "m3_track_gather_batch", "m3_track_gn_ray_dist_batch")
     conc, net.concurrent_heads = net.concurrent_heads, False      # per-launch timing wants the launches serialised
-    step()
+    leg_infer(); i2, v2 = leg_match(); leg_gn(i2, v2)
     torch.cuda.synchronize()
     net.concurrent_heads = conc
     prof, ops.PROFILE = ops.PROFILE, None
+    cprof, _ffi.PROFILE = _ffi.PROFILE, None
     by_kind = {}
     for kind, flops, e0, e1, nbytes in prof:
         d = by_kind.setdefault(kind, [0.0, 0.0, 0, 0.0])
         d[0] += flops; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1; d[3] += nbytes
     g = by_kind.get("gemm256", [0.0, 1.0, 1, 0.0])
-    traffic = pmc_traffic_per_launch(("k_gemm256<0",))
+    traffic, traffic_src = pmc_traffic(("k_gemm256<0",))
     gemm_tflops = g[0] / g[1] / 1e12
     model_flops = net.flops_per_pair(H, W) * P
+    # HBM-bound kernel families: algorithmic bytes per call from SURVEY 8d (per pair at 512x512, fp32) x P pairs
+    MB = 1e6
+    iters = int(tcfg["max_iters"])
+    hbm_rows = {
+        "m3_prep_iter_proj": ("k_prep", 21.0 * MB * P, 1),
+        "m3_iter_proj": ("k_iter_proj (+ k_iter_reduce / k_iter_limit, early-stop second pass)", 17.0 * MB * P, 1),
+        "m3_refine_matches": ("k_refine_lds<24> / k_refine<24>", 54.5 * MB * P, 1),
+        "m3_match_epilogue": ("k_epilogue", 9.7 * MB * P, 1),
+        "m3_track_gather_batch": ("k_track_gather", (3.15 + 4 * 1.05 + 2.1 + 0.26 + 3.15 + 1.05 + 0.52) * MB * P, 1),
+        "m3_track_gn_ray_dist_batch": (f"k_track_accum + k_track_solve, per GN iteration ({iters} per call)", 8.7 * MB * P, iters),
+    }
+    hbm = {}
+    for name, (kern, nbytes, div) in hbm_rows.items():
+        evs = cprof.get(name, [])
+        if not evs:
+            continue
+        us = sum(a.elapsed_time(b) for a, b in evs) / len(evs) / div * 1e3
+        hbm[name] = {"kernels": kern, "algorithmic_bytes": nbytes, "avg_us": us, "achieved": nbytes / us / 1e3,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / us / 1e3 / HBM_PEAK_GBS}
 
     result = {
         "metric": "keyframe-pairs/sec (512x512 two-view infer+match+GN)",
@@ -220,59 +289,61 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "bf16",
-        "data": "synthetic 512x512 textured pairs; seeded random-init weights (no checkpoint available offline)",
+        "data": "synthetic: 512x512 textured pairs through the network (seeded random-init weights, no checkpoint available "
+                "offline); matcher + Gauss-Newton on smooth synthetic two-view scenes of the same size (SURVEY 8d configs 2-3)",
         "config": {"workload": f"{P} keyframe pairs/GPU at 512x512 (BASELINE configs[3] per-GPU shard): "
-                               "two-view MASt3R ViT-L infer + iter_proj/refine match + 10-iter GN tracking"
-                               + ("" if world == 1 else " + RCCL all-gather of results"),
-                   "pairs_per_gpu": P, "global_pairs": world * P, "image": [H, W], "gn_iters": tcfg["max_iters"],
-                   "parallelism": f"pair-sharded x{world}", "launch": ("hipGraph replay" + ("" if dist is None else " + RCCL all-gather of the previous step overlapped on the communicator stream")) if graph is not None else "eager"},
+                               "two-view MASt3R ViT-L infer (bf16 trunk, fp16 heads, fp32 accumulate) + iter_proj/refine match "
+                               "+ 10-iter GN tracking" + ("" if world == 1 else " + RCCL all-gather of results"),
+                   "pairs_per_gpu": P, "global_pairs": world * P, "image": [H, W], "gn_iters": iters,
+                   "parallelism": f"pair-sharded x{world}",
+                   "launch": ("3 hipGraph replays per step (infer | match | GN)" + ("" if dist is None else " + RCCL all-gather of the previous step overlapped on the communicator stream")) if graphs is not None else "eager"},
         "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+        "stage_ms_note": "device time between stream events recorded around the three graph replays of every TIMED step (mean); sum ~ ms_per_step",
+        "match_valid_frac": round(match_valid_frac, 4),
+        "valid_frac": round(valid_frac, 4),
+        "gn_pose_max_abs_err_vs_true_sim3": pose_err,
         "model_tflop_per_step": model_flops / 1e12,
-        "roofline": {"bound": "mfma", "kernel": "k_gemm256 (bf16 MFMA GEMM, 256x256x64 / 256x192x64 ping-pong tiles; dense launches only - "
+        "roofline": {"bound": "mfma", "kernel": "k_gemm256 (16-bit MFMA GEMM, 256x256x64 / 256x192x64 ping-pong tiles; dense launches only - "
                                                 "its implicit-GEMM conv launches and the small-problem kernel are listed under other_kernels_tflops)",
                      "achieved": gemm_tflops, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": gemm_tflops / MFMA_BF16_PEAK_TFLOPS,
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE passes "
-                                                         "of this command, profiles/r01_pmc_traffic.json)",
+                                                         f"of this command, profiles/{traffic_src})",
                      "algorithmic_bytes_per_launch": g[3] / max(g[2], 1),
                      "launches": g[2], "avg_launch_us": g[1] / max(g[2], 1) * 1e6,
                      "other_kernels_tflops": {k: v[0] / v[1] / 1e12 for k, v in by_kind.items() if k != "gemm256"},
                      "all_mfma_kernels_tflops": sum(v[0] for v in by_kind.values()) / sum(v[1] for v in by_kind.values()) / 1e12},
+        "hbm_rooflines": hbm,
     }
 
     if world == 1 and not args.no_b1:
-        # random weights give meaningless geometry (scattered gathers), so the matcher is
-        # ALSO timed on a smooth synthetic two-view scene of the same size (what real pointmaps look like)
-        sc = synthetic.geometric_pair(H, W, seed=0, batch=1)
-        gt = lambda k: torch.from_numpy(sc[k]).to(dev).repeat(P, 1, 1, 1)
-        gX11, gX21, gD11, gD21 = gt("X11"), gt("X21"), gt("D11"), gt("D21")
+        # for the record: the same matcher on what the random-weight network emits (scattered gathers)
+        o1, o2 = state["o1"], state["o2"]
         for _ in range(2):
-            matching.match(gX11, gX21, gD11, gD21)
+            matching.match(o1["pts3d"], o2["pts3d"], o1["desc"], o2["desc"])
         e0, e1 = ev(), ev()
         e0.record()
         for _ in range(5):
-            matching.match(gX11, gX21, gD11, gD21)
+            matching.match(o1["pts3d"], o2["pts3d"], o1["desc"], o2["desc"])
         e1.record(); torch.cuda.synchronize()
-        result["match_ms_geometric_scene"] = round(e0.elapsed_time(e1) / 5, 3)
+        result["match_ms_on_random_weight_network_output"] = round(e0.elapsed_time(e1) / 5, 3)
 
     if world == 1 and not args.no_b1 and P != 1:
         # BASELINE configs[1]: one pair per step (latency regime), same pipeline, graph-replayed
         a1, b1 = im1[:1].contiguous(), im2[:1].contiguous()
+        s1 = {k: (v[:1].contiguous() if isinstance(v, torch.Tensor) else v) for k, v in sc.items()}
 
         def step1():
-            o1, o2 = net.reconstruct_batch(a1, b1)
-            idx, valid = matching.match(o1["pts3d"], o2["pts3d"], o1["desc"], o2["desc"])
-            Xf, Qk, vo, vk, cnt = tracker.track_gather(
-                o1["pts3d"].reshape(1, n, 3), o1["conf"].reshape(1, n), o2["conf"].reshape(1, n),
-                o1["desc_conf"].reshape(1, n), o2["desc_conf"].reshape(1, n), idx, valid.reshape(1, n),
-                tcfg["C_conf"], tcfg["Q_conf"])
-            return tracker.opt_pose_ray_dist_sim3(Xf, o2["pts3d"].reshape(1, n, 3), ident, ident, Qk, vo, tcfg,
-                                                  fixed_iters=True)
+            net.reconstruct_batch(a1, b1)
+            i1, v1 = matching.match(s1["X11"], s1["X21"], s1["D11"], s1["D21"])
+            Xf, Qk, vo1, vk, cnt = tracker.track_gather(s1["X11"].reshape(1, n, 3), s1["Cf"], s1["Ck"], s1["Qf"], s1["Qk"],
+                                                        i1, v1.reshape(1, n), tcfg["C_conf"], tcfg["Q_conf"])
+            return tracker.opt_pose_ray_dist_sim3(Xf, s1["Xk"], ident, ident, Qk, vo1, tcfg, fixed_iters=True)
         for _ in range(2):
             step1()
         torch.cuda.synchronize()
         run1 = step1
-        if graph is not None:
+        if graphs is not None:
             g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 keep = step1()

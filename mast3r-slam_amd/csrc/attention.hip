@@ -111,7 +111,7 @@ k_attn(const AttnArgs a) {
         const int buf = t & 1;
         if (t + 1 < nt) { stage(t + 1, buf ^ 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        m3gemm::lds_barrier();                  // every wave's K/V loads of tile t have landed
         const unsigned char *Ks = lds + buf * 2 * kTileBytes, *Vs = Ks + kTileBytes;
 
         // ---- S^T = K . Q^T : s[qt][kt] holds keys kt*16 + g*4 + r of query lq ------------------
@@ -206,7 +206,7 @@ k_attn(const AttnArgs a) {
                 for (int qt = 0; qt < QT; ++qt)
                     o[qt][dt] = mfma16<DT>(vf.v, pf[qt][kk], o[qt][dt]);
             }
-        __builtin_amdgcn_s_barrier();
+        m3gemm::lds_barrier();                  // all K/V fragment reads of this tile returned before it is restaged
     }
 
     // ---- finalize: O[q][dt*16 + g*4 + r] = o / l ---------------------------------------------------

@@ -120,7 +120,7 @@ k_gemm(const GemmArgs gin) {
             if constexpr (NT == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        lds_barrier();                          // every wave's loads of tile kt have landed
         const unsigned char *As = lds + buf * kStageBytes;
         const unsigned char *Ws = As + BM * BK * 2;
 #pragma unroll
@@ -141,7 +141,7 @@ k_gemm(const GemmArgs gin) {
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = mfma16<DT>(wf[j], af[i], acc[i][j]);
         }
-        __builtin_amdgcn_s_barrier();      // all waves done reading `buf` before it is restaged
+        lds_barrier();                          // all waves done reading `buf` (reads RETURNED) before it is restaged
     }
 
     if constexpr (EPI == EPI_RELU_HEAD4) {

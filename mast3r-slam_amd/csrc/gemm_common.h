@@ -79,6 +79,20 @@ __device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
                                      (__attribute__((address_space(3))) unsigned *)lds_wave_base, 16, 0, 0);
 }
 
+// Workgroup barrier that LDS traffic cannot cross.  For LLVM `__builtin_amdgcn_s_barrier()` touches no memory, so
+// the scheduler is free to move ds_reads - and the s_waitcnt that retires them - across it: in the round-1 build the
+// end-of-K-tile barrier of k_gemm<.., 64> and of k_attn was issued BEFORE the wave's last fragment reads had
+// returned, so a faster wave could re-stage the buffer (LDS-DMA of tile t+2) under them.  Seen as 1-3 wrong 64x64
+// tiles per 1000 (one K-tile's rows of one wave stale) at 4-5 workgroups per CU, never at 1-2.  This form pins the
+// order: everything before (incl. the MFMAs that consume the reads) stays before, own LDS ops are retired, then
+// the barrier, and nothing after moves up.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 struct GemmArgs {
     const bf16_t *A;        // [M,K] bf16 (dense) or NHWC image (conv)
     const bf16_t *W;        // [N,K] bf16

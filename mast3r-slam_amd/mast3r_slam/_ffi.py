@@ -98,10 +98,24 @@ def check(t: torch.Tensor, dtype, name: str, shape=None) -> torch.Tensor:
     return t.contiguous()
 
 
+# When set to a dict, every `call` of an entry point listed in PROFILE_NAMES appends a (start, end) pair of
+# events recorded on the current stream around the launch sequence of that call (bench.py's per-kernel-family
+# device times of the matcher and the Gauss-Newton solve).
+PROFILE = None
+PROFILE_NAMES = ()
+
+
 def call(name: str, *args):
     """Call an int-returning entry point; non-zero status -> RuntimeError."""
     L = lib()
+    prof = PROFILE is not None and name in PROFILE_NAMES
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = getattr(L, name)(*args)
+    if prof:
+        e1.record()
+        PROFILE.setdefault(name, []).append((e0, e1))
     if rc != 0:
         msg = L.m3_status_string(rc).decode()
         herr = L.m3_last_hip_error().decode()

@@ -465,3 +465,23 @@ def test_non_square_512x384_pair(tiny, dev):
     finally:
         config.reset_config()
     assert idx.shape == (1, h * wd) and valid.shape == (1, h * wd, 1)
+
+
+@pytest.mark.parametrize("shape", [(1344, 3072, 1024), (672, 3072, 1024), (2688, 2304, 768)])
+def test_small_tile_gemm_is_race_free_at_high_occupancy(dev, shape):
+    """Regression for an LDS write-after-read race: the 64x64-tile kernel runs 4-5 workgroups
+    per CU; its end-of-K-tile barrier used to be scheduled ahead of the wait for the wave's last fragment reads, so
+    a neighbour could re-stage the buffer under them - 1-3 tiles per 1000 came out with one K-tile of stale rows
+    (O(1) errors, different tiles every launch).  Every launch must reproduce bf16(fp32-epilogue result) exactly."""
+    from mast3r_slam import _ffi
+    m, n, k = shape
+    g = torch.Generator(device="cpu").manual_seed(m)
+    a = torch.randn(m, k, generator=g).bfloat16().to(dev)
+    w = (torch.randn(n, k, generator=g) * 0.05).bfloat16().to(dev)
+    b = torch.randn(n, generator=g).to(dev)
+    assert _ffi.lib().m3_gemm_pick_tile(m, n, 1) == 64
+    want = ops.gemm(a, w, b, ops.EPI_F32).bfloat16()
+    for run in range(12):
+        out = ops.gemm(a, w, b, ops.EPI_BF16)
+        bad = int((out != want).sum())
+        assert bad == 0, f"launch {run}: {bad} elements differ"

@@ -479,7 +479,7 @@ def test_small_tile_gemm_is_race_free_at_high_occupancy(dev, shape):
     a = torch.randn(m, k, generator=g).bfloat16().to(dev)
     w = (torch.randn(n, k, generator=g) * 0.05).bfloat16().to(dev)
     b = torch.randn(n, generator=g).to(dev)
-    assert _ffi.lib().m3_gemm_pick_tile(m, n, 1) == 64
+    assert _ffi.lib().m3_gemm_pick_tile(m, n, 1) in (64, 128)          # the small-problem kernel (2-5 workgroups per CU)
     want = ops.gemm(a, w, b, ops.EPI_F32).bfloat16()
     for run in range(12):
         out = ops.gemm(a, w, b, ops.EPI_BF16)

@@ -48,27 +48,29 @@ int m3_gemm_dt(const void *A, const void *W, const float *bias, void *C, const v
  * 256-row ping-pong kernel with 256- / 192-wide tiles, 128 or 64 = the small-problem kernel. */
 int m3_gemm_pick_tile(int M, int N, int groups);
 
-/* Projection GEMM with RoPE-2D fused into the epilogue: C(bf16) = rope(A . W^T + bias) on the
+/* Projection GEMM with RoPE-2D fused into the epilogue: C(16-bit) = rope(A . W^T + bias) on the
  * 64-wide heads in columns [0, rope_cols) (q|k of a q|k|v projection), plain bias add beyond.
- * Row m is token m % tokens_per_image of its image; tables as in m3_rope2d_bf16.  N % 64 == 0. */
+ * Row m is token m % tokens_per_image of its image; rope_tok f32 [tokens_per_image][2][2][16] holds, per
+ * token and axis (0: its y position, 1: its x position), 16 cosines then 16 sines for the frequencies
+ * base^(-i/16) - i.e. rope_tok[t][a][0|1][i] = cos_sin[pos_yx[t][a]][i][0|1] of m3_rope2d_bf16's tables,
+ * gathered once per image size; 16-byte aligned.  N % 64 == 0. */
 int m3_gemm_bf16_rope(const void *A, const void *W, const float *bias, void *C, int M, int N, int K,
-                      int ldc, const int32_t *pos_yx, const float *cos_sin, int tokens_per_image,
-                      int rope_cols, void *stream);
+                      int ldc, const float *rope_tok, int tokens_per_image, int rope_cols, void *stream);
 int m3_gemm_rope_dt(const void *A, const void *W, const float *bias, void *C, int M, int N, int K,
-                    int ldc, const int32_t *pos_yx, const float *cos_sin, int tokens_per_image,
-                    int rope_cols, int dtype, void *stream);
+                    int ldc, const float *rope_tok, int tokens_per_image, int rope_cols, int dtype,
+                    void *stream);
 
 /* Two same-shape GEMMs in one launch (the two decoder branches have different weights): group g
  * (0/1) computes C + g*c_gstride = epi((A + g*a_gstride) . W[g]^T + bias[g]); strides in elements.
  * epilogue may be any M3_EPI_* including M3_EPI_BF16_ROPE (= 6; then the RoPE tables are required). */
 int m3_gemm_bf16_grouped2(const void *A, const void *W0, const void *W1, const float *bias0,
                           const float *bias1, void *C, const void *R, int M, int N, int K, int ldc,
-                          int64_t a_gstride, int64_t c_gstride, int epilogue, const int32_t *pos_yx,
-                          const float *cos_sin, int tokens_per_image, int rope_cols, void *stream);
+                          int64_t a_gstride, int64_t c_gstride, int epilogue, const float *rope_tok,
+                          int tokens_per_image, int rope_cols, void *stream);
 int m3_gemm_grouped2_dt(const void *A, const void *W0, const void *W1, const float *bias0,
                         const float *bias1, void *C, const void *R, int M, int N, int K, int ldc,
-                        int64_t a_gstride, int64_t c_gstride, int epilogue, const int32_t *pos_yx,
-                        const float *cos_sin, int tokens_per_image, int rope_cols, int dtype, void *stream);
+                        int64_t a_gstride, int64_t c_gstride, int epilogue, const float *rope_tok,
+                        int tokens_per_image, int rope_cols, int dtype, void *stream);
 
 /* 3x3 convolution, padding 1, stride 1 or 2, as an implicit GEMM: X bf16 NHWC [B,H,W,Cin],
  * W bf16 [Cout,3,3,Cin], Y NHWC [B,OH,OW,Cout].  Cin % 64 == 0, Cout % 4 == 0.  zero16: 16

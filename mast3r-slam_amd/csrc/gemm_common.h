@@ -104,8 +104,7 @@ struct GemmArgs {
     // conv geometry
     int H, Wd, Cin, OH, OW, stride;
     // fused RoPE-2D epilogue (EPI_BF16_ROPE): columns < rope_cols are 64-wide heads to rotate
-    const int *pos_yx;      // [tokens_per_image, 2]
-    const float *cos_sin;   // [max_pos, 16, 2]
+    const float *rope_tok;  // [tokens_per_image, 2 (y|x), 2 (cos|sin), 16]
     int tokens_per_image, rope_cols;
     // grouped launch (blockIdx.y = group): group 1 uses W2/bias2 and A/C/R advanced by the strides
     const bf16_t *W2;
@@ -174,39 +173,64 @@ __device__ __forceinline__ void store_tile(const GemmArgs &g, f32x4 v, int m, in
     }
 }
 
-// Fused RoPE-2D on one 16-row x (16*NJ)-column accumulator strip that starts on a 32-column boundary:
+// Fused RoPE-2D on 16-row x (16*NJ)-column accumulator strips that start on a 32-column boundary:
 // t[0..NJ-1] are the 16-column tiles, lane holds columns 16*j + 4*(lane>>4) + e.  Every 32-column
 // block is half a head: even blocks rotate with the token's y, odd blocks with x; element i pairs
 // with i+16, i.e. tile 2b with tile 2b+1 in the SAME lane and register.  Bias is added first.
+// Coefficients come from a PER-TOKEN table rope_tok[tokens_per_image][2 (y|x)][2 (cos|sin)][16 freq] f32
+// (256 B per token, L2-resident): two independent 16-byte reads per (row, block), no position lookup in
+// front of it and no branch around it - the first version (position table -> cos/sin table, both behind
+// per-row branches) made every row a dependent chain of two L2 round trips: 128 us instead of 93 us for
+// the 16384 x 3072 x 1024 projection.
+struct RopeCoef { float4 c, s; };               // cos / sin of frequencies fi .. fi+3
+template <int NJ>
+__device__ __forceinline__ void rope_load(const GemmArgs &g, RopeCoef (&cf)[NJ / 2], int m, int n_base, int lane) {
+    const int mm = m < g.M ? m : g.M - 1;
+    const int tok = mm % g.tokens_per_image;
+    const int fi = (lane >> 4) * 4;
+#pragma unroll
+    for (int blk = 0; blk < NJ / 2; ++blk) {
+        if (n_base + 32 * blk >= g.rope_cols) continue;                 // wave-uniform: v columns are not rotated
+        const int axis = ((n_base + 32 * blk) >> 5) & 1;                 // 0: y, 1: x
+        const float *row = g.rope_tok + (size_t)(tok * 2 + axis) * 32 + fi;
+        cf[blk].c = *reinterpret_cast<const float4 *>(row);
+        cf[blk].s = *reinterpret_cast<const float4 *>(row + 16);
+    }
+}
+// (bias add +) rotation on packed pairs: 8 v_pk_* per 32-column block instead of 16 + 16 scalar ops
+template <int NJ>
+__device__ __forceinline__ void rope_apply(const GemmArgs &g, f32x4 *t, const RopeCoef (&cf)[NJ / 2], const float4 *bj,
+                                           int n_base) {
+#pragma unroll
+    for (int blk = 0; blk < NJ / 2; ++blk) {
+        f32x4 &a = t[2 * blk], &b = t[2 * blk + 1];
+        const float4 ba = bj[2 * blk], bb = bj[2 * blk + 1];
+        const f32x2 a0 = f32x2{a[0], a[1]} + f32x2{ba.x, ba.y}, a1 = f32x2{a[2], a[3]} + f32x2{ba.z, ba.w};
+        const f32x2 b0 = f32x2{b[0], b[1]} + f32x2{bb.x, bb.y}, b1 = f32x2{b[2], b[3]} + f32x2{bb.z, bb.w};
+        if (n_base + 32 * blk >= g.rope_cols) {                         // wave-uniform
+            a = f32x4{a0.x, a0.y, a1.x, a1.y}; b = f32x4{b0.x, b0.y, b1.x, b1.y};
+            continue;
+        }
+        const f32x2 c0 = {cf[blk].c.x, cf[blk].c.y}, c1 = {cf[blk].c.z, cf[blk].c.w};
+        const f32x2 s0 = {cf[blk].s.x, cf[blk].s.y}, s1 = {cf[blk].s.z, cf[blk].s.w};
+        const f32x2 ra0 = __builtin_elementwise_fma(a0, c0, -(b0 * s0)), ra1 = __builtin_elementwise_fma(a1, c1, -(b1 * s1));
+        const f32x2 rb0 = __builtin_elementwise_fma(b0, c0, a0 * s0), rb1 = __builtin_elementwise_fma(b1, c1, a1 * s1);
+        a = f32x4{ra0.x, ra0.y, ra1.x, ra1.y}; b = f32x4{rb0.x, rb0.y, rb1.x, rb1.y};
+    }
+}
+// unaligned fallback: bias + rotation of one strip in place
 template <int NJ>
 __device__ __forceinline__ void rope_strip(const GemmArgs &g, f32x4 *t, int m, int n_base, int lane) {
     if (m >= g.M) return;
     const int fi = (lane >> 4) * 4;
-    if (g.bias) {
+    float4 bj[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            if (n_base + j * 16 + fi >= g.N) continue;
-            const float4 b = *reinterpret_cast<const float4 *>(g.bias + n_base + j * 16 + fi);
-            t[j][0] += b.x; t[j][1] += b.y; t[j][2] += b.z; t[j][3] += b.w;
-        }
-    }
-    const int2 pos = *reinterpret_cast<const int2 *>(g.pos_yx + 2 * (m % g.tokens_per_image));
-#pragma unroll
-    for (int blk = 0; blk < NJ / 2; ++blk) {
-        const int n_blk = n_base + 32 * blk;
-        if (n_blk >= g.rope_cols) continue;
-        const int p = ((n_blk >> 5) & 1) ? pos.y : pos.x;    // pos_yx = (y, x): .x is y
-        const float4 *cs = reinterpret_cast<const float4 *>(g.cos_sin + ((size_t)p * 16 + fi) * 2);
-        const float4 c01 = cs[0], c23 = cs[1];               // (cos,sin) of freq fi, fi+1 | fi+2, fi+3
-        const float cc[4] = {c01.x, c01.z, c23.x, c23.z}, ss[4] = {c01.y, c01.w, c23.y, c23.w};
-        f32x4 &a = t[2 * blk], &b = t[2 * blk + 1];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float x1 = a[e], x2 = b[e];
-            a[e] = x1 * cc[e] - x2 * ss[e];
-            b[e] = x2 * cc[e] + x1 * ss[e];
-        }
-    }
+    for (int j = 0; j < NJ; ++j)
+        bj[j] = (g.bias && n_base + j * 16 + fi < g.N) ? *reinterpret_cast<const float4 *>(g.bias + n_base + j * 16 + fi)
+                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+    RopeCoef cf[NJ / 2];
+    rope_load<NJ>(g, cf, m, n_base, lane);
+    rope_apply<NJ>(g, t, cf, bj, n_base);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -246,57 +270,74 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int n = n_base + j * 16 + gq * 4;
-        bj[j] = (EPI != EPI_BF16_ROPE && g.bias && n < g.N) ? *reinterpret_cast<const float4 *>(g.bias + n)
-                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        bj[j] = (g.bias && n < g.N) ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (F32LDS) {
         constexpr int RS = NJ * 64 + 16;                          // 16*NJ fp32 + 16 bytes of padding
-        constexpr int PR = 32;                                    // rows per pass (2 accumulator row tiles)
+        constexpr bool RESID = (EPI == EPI_F32_ACCUM || EPI == EPI_BF16_ADD);
+        constexpr int PT = RESID ? 1 : 2;                         // accumulator row tiles per pass (residual tiles are
+        constexpr int PR = 16 * PT;                               // double-buffered in registers: keep a pass small)
+        constexpr int CPR = F32OUT ? NJ * 4 : NJ * 2;             // 16-byte output chunks per row (4 fp32 / 8 x 16-bit columns)
+        constexpr int NIT = PR * CPR / 64;
+        // Residual tile of a pass: read row-contiguous, 16 B per lane, from CLAMPED addresses with no branch
+        // around the loads, and one pass AHEAD of its use - the first version loaded each chunk inside the
+        // bounds test, i.e. one exposed L2/HBM round trip per chunk (32 per wave): 18.6 us of a 52 us launch.
+        uint4 q[2][RESID ? NIT : 1];
+        auto load_resid = [&](int pass, uint4 (&dst)[RESID ? NIT : 1]) {
+            if constexpr (RESID) {
 #pragma unroll
-        for (int pass = 0; pass < NI / 2; ++pass) {
+                for (int it = 0; it < NIT; ++it) {
+                    const int c = it * 64 + lane, rl = c / CPR, ch = c - rl * CPR;
+                    int m = m_base + pass * PR + rl, n = n_base + ch * (F32OUT ? 4 : 8);
+                    m = m < g.M ? m : g.M - 1;
+                    n = n < g.N ? n : 0;
+                    const size_t off = (size_t)m * g.ldc + n;
+                    dst[it] = F32OUT ? *reinterpret_cast<const uint4 *>(reinterpret_cast<const float *>(g.R) + off)
+                                     : *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16_t *>(g.R) + off);
+                }
+            }
+        };
+        load_resid(0, q[0]);
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
+        for (int pass = 0; pass < NI / PT; ++pass) {
+            if (pass + 1 < NI / PT) load_resid(pass + 1, q[(pass + 1) & 1]);
+#pragma unroll
+            for (int ii = 0; ii < PT; ++ii)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const f32x4 v = acc[pass * 2 + ii][j];
+                    const f32x4 v = acc[pass * PT + ii][j];
                     *reinterpret_cast<float4 *>(wlds + (ii * 16 + r) * RS + (j * 16 + gq * 4) * 4) =
                         make_float4(v[0] + bj[j].x, v[1] + bj[j].y, v[2] + bj[j].z, v[3] + bj[j].w);
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (F32OUT) {
-                constexpr int CPR = NJ * 4;                       // 16-byte chunks (4 columns) per row
 #pragma unroll
-                for (int it = 0; it < PR * CPR / 64; ++it) {
+                for (int it = 0; it < NIT; ++it) {
                     const int c = it * 64 + lane, rl = c / CPR, ch = c - rl * CPR;
                     float4 v = *reinterpret_cast<const float4 *>(wlds + rl * RS + ch * 16);
                     const int m = m_base + pass * PR + rl, n = n_base + ch * 4;
-                    if (m < g.M && n < g.N) {
-                        const size_t off = (size_t)m * g.ldc + n;
-                        if (EPI == EPI_F32_ACCUM) {
-                            const float4 q = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(g.R) + off);
-                            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-                        }
-                        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(g.C) + off) = v;
+                    if (EPI == EPI_F32_ACCUM) {
+                        const uint4 u = q[pass & 1][it];
+                        v.x += __uint_as_float(u.x); v.y += __uint_as_float(u.y); v.z += __uint_as_float(u.z); v.w += __uint_as_float(u.w);
                     }
+                    if (m < g.M && n < g.N)
+                        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + n) = v;
                 }
             } else {                                              // EPI_BF16_ADD: 8 columns per lane
-                constexpr int CPR = NJ * 2;
 #pragma unroll
-                for (int it = 0; it < PR * CPR / 64; ++it) {
+                for (int it = 0; it < NIT; ++it) {
                     const int c = it * 64 + lane, rl = c / CPR, ch = c - rl * CPR;
                     const float4 a = *reinterpret_cast<const float4 *>(wlds + rl * RS + ch * 32);
                     const float4 b = *reinterpret_cast<const float4 *>(wlds + rl * RS + ch * 32 + 16);
                     const int m = m_base + pass * PR + rl, n = n_base + ch * 8;
-                    if (m < g.M && n < g.N) {
-                        const size_t off = (size_t)m * g.ldc + n;
-                        const uint4 q = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16_t *>(g.R) + off);
-                        uint4 o;
-                        o.x = pack16<DT>(a.x + lo16<DT>(q.x), a.y + hi16<DT>(q.x));
-                        o.y = pack16<DT>(a.z + lo16<DT>(q.y), a.w + hi16<DT>(q.y));
-                        o.z = pack16<DT>(b.x + lo16<DT>(q.z), b.y + hi16<DT>(q.z));
-                        o.w = pack16<DT>(b.z + lo16<DT>(q.w), b.w + hi16<DT>(q.w));
-                        *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(g.C) + off) = o;
-                    }
+                    const uint4 u = q[pass & 1][it];
+                    uint4 o;
+                    o.x = pack16<DT>(a.x + lo16<DT>(u.x), a.y + hi16<DT>(u.x));
+                    o.y = pack16<DT>(a.z + lo16<DT>(u.y), a.w + hi16<DT>(u.y));
+                    o.z = pack16<DT>(b.x + lo16<DT>(u.z), b.y + hi16<DT>(u.z));
+                    o.w = pack16<DT>(b.z + lo16<DT>(u.w), b.w + hi16<DT>(u.w));
+                    if (m < g.M && n < g.N)
+                        *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(g.C) + (size_t)m * g.ldc + n) = o;
                 }
             }
             asm volatile("" ::: "memory");
@@ -307,14 +348,19 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
         constexpr int PR = 16 * TP, CPR = NJ * 2;                 // rows per pass, 16-byte chunks (8 columns) per row
 #pragma unroll
         for (int pass = 0; pass < NI / TP; ++pass) {
+            RopeCoef cf[EPI == EPI_BF16_ROPE ? TP : 1][NJ / 2];
+            if constexpr (EPI == EPI_BF16_ROPE) {                 // all coefficient reads of the pass in flight at once
+#pragma unroll
+                for (int ii = 0; ii < TP; ++ii) rope_load<NJ>(g, cf[ii], m_base + (pass * TP + ii) * 16 + r, n_base, lane);
+            }
 #pragma unroll
             for (int ii = 0; ii < TP; ++ii) {
                 const int i = pass * TP + ii;
-                if (EPI == EPI_BF16_ROPE) rope_strip<NJ>(g, acc[i], m_base + i * 16 + r, n_base, lane);
+                if constexpr (EPI == EPI_BF16_ROPE) rope_apply<NJ>(g, acc[i], cf[ii], bj, n_base);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     f32x4 v = acc[i][j];
-                    v[0] += bj[j].x; v[1] += bj[j].y; v[2] += bj[j].z; v[3] += bj[j].w;
+                    if constexpr (EPI != EPI_BF16_ROPE) { v[0] += bj[j].x; v[1] += bj[j].y; v[2] += bj[j].z; v[3] += bj[j].w; }
                     if (EPI == EPI_BF16_GELU) {
                         const f32x2 lo = gelu_erf2(f32x2{v[0], v[1]}), hi = gelu_erf2(f32x2{v[2], v[3]});
                         v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;

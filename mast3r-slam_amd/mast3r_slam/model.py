@@ -282,7 +282,7 @@ class Mast3rFull:
             cs = torch.stack([ang.cos(), ang.sin()], dim=-1).to(self.device).contiguous()       # [n,16,2]
             gy, gx = torch.meshgrid(torch.arange(gh), torch.arange(gw), indexing="ij")
             pos = torch.stack([gy.reshape(-1), gx.reshape(-1)], -1).to(torch.int32).to(self.device).contiguous()
-            self._rope_cache[key] = (pos, cs)
+            self._rope_cache[key] = ops.rope_token_table(pos, cs)                 # [T,2,2,16] per token: axis, cos|sin, frequency
         return self._rope_cache[key]
 
     def _as_images(self, img) -> torch.Tensor:
@@ -297,10 +297,10 @@ class Mast3rFull:
             raise ValueError(f"images must be [B,H,W,3] with H,W multiples of 16, got {tuple(img.shape)}")
         return img.to(self.device).contiguous()
 
-    def _self_attn(self, xn, p, heads, nb, t, pos, cs):
+    def _self_attn(self, xn, p, heads, nb, t, rtok):
         P = self.P
         c = heads * 64
-        qkv = ops.gemm_rope(xn, P[p + ".qkv.w"], P[p + ".qkv.b"], pos, cs, t, 2 * c)    # [M,3c], q|k rotated
+        qkv = ops.gemm_rope(xn, P[p + ".qkv.w"], P[p + ".qkv.b"], rtok, 2 * c)          # [M,3c], q|k rotated
         out = torch.empty((nb * t, c), dtype=xn.dtype, device=xn.device)
         ops.attention(qkv, qkv[:, c:], qkv[:, 2 * c:], out, nbatch=nb, heads=heads, tq=t, tk=t,
                       q_row_stride=3 * c, kv_row_stride=3 * c, o_row_stride=c, q_batch_stride=t * 3 * c,
@@ -316,12 +316,12 @@ class Mast3rFull:
         gh, gw = h // 16, w // 16
         t = gh * gw
         dt = self.tdt
-        pos, cs = self._rope(gh, gw)
+        rtok = self._rope(gh, gw)
         x = ops.gemm(ops.patchify16(imgs_u8, dt), P["patch.w"], P["patch.b"], ops.EPI_F32)   # fp32 residual stream
         for i in range(c["enc_depth"]):
             p = f"enc_blocks.{i}"
             xn = ops.layernorm(x, P[p + ".norm1.g"], P[p + ".norm1.b"], dtype=dt)
-            a = self._self_attn(xn, p + ".attn", c["enc_heads"], b, t, pos, cs)
+            a = self._self_attn(xn, p + ".attn", c["enc_heads"], b, t, rtok)
             ops.gemm(a, P[p + ".attn.proj.w"], P[p + ".attn.proj.b"], ops.EPI_F32_ACCUM, out=x, resid=x)
             xn = ops.layernorm(x, P[p + ".norm2.g"], P[p + ".norm2.b"], dtype=dt)
             hdn = ops.gemm(xn, P[p + ".mlp.fc1.w"], P[p + ".mlp.fc1.b"], ops.EPI_BF16_GELU)
@@ -344,7 +344,7 @@ class Mast3rFull:
         P, c = self.P, self.cfg
         gh, gw = grid
         t = gh * gw
-        pos, cs = self._rope(gh, gw)
+        rtok = self._rope(gh, gw)
         D, heads = c["dec_dim"], c["dec_heads"]
         m = npairs * t
         dev = f1.device
@@ -368,11 +368,11 @@ class Mast3rFull:
             yn = ops.layernorm_grouped2(x, *W(i, "norm_y.g")[:1], W(i, "norm_y.b")[0], W(i, "norm_y.g")[1],
                                         W(i, "norm_y.b")[1], swap=True, dtype=dt)
             kv = ops.gemm_grouped2(yn, *W(i, "cross_attn.kv.w"), *W(i, "cross_attn.kv.b"), ops.EPI_BF16_ROPE,
-                                   rope=(pos, cs, t, D))                                  # [2,M,2D], k rotated
+                                   rope=(rtok, D))                                  # [2,M,2D], k rotated
             # self-attention
             xn = ops.layernorm_grouped2(x, W(i, "norm1.g")[0], W(i, "norm1.b")[0], W(i, "norm1.g")[1], W(i, "norm1.b")[1], dtype=dt)
             qkv = ops.gemm_grouped2(xn, *W(i, "attn.qkv.w"), *W(i, "attn.qkv.b"), ops.EPI_BF16_ROPE,
-                                    rope=(pos, cs, t, 2 * D)).view(2 * m, 3 * D)
+                                    rope=(rtok, 2 * D)).view(2 * m, 3 * D)
             a = torch.empty((2, m, D), dtype=dt, device=dev)
             ops.attention(qkv, qkv[:, D:], qkv[:, 2 * D:], a, nbatch=2 * npairs, heads=heads, tq=t, tk=t,
                           q_row_stride=3 * D, kv_row_stride=3 * D, o_row_stride=D, q_batch_stride=t * 3 * D,
@@ -381,7 +381,7 @@ class Mast3rFull:
             # cross-attention
             xn = ops.layernorm_grouped2(x, W(i, "norm2.g")[0], W(i, "norm2.b")[0], W(i, "norm2.g")[1], W(i, "norm2.b")[1], dtype=dt)
             q = ops.gemm_grouped2(xn, *W(i, "cross_attn.projq.w"), *W(i, "cross_attn.projq.b"), ops.EPI_BF16_ROPE,
-                                  rope=(pos, cs, t, D)).view(2 * m, D)
+                                  rope=(rtok, D)).view(2 * m, D)
             kvf = kv.view(2 * m, 2 * D)
             a = torch.empty((2, m, D), dtype=dt, device=dev)
             ops.attention(q, kvf, kvf[:, D:], a, nbatch=2 * npairs, heads=heads, tq=t, tk=t, q_row_stride=D,

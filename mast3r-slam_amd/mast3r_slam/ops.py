@@ -92,8 +92,17 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, epi: int = EPI_BF16, out=N
     return out
 
 
-def gemm_rope(a, w, bias, pos_yx, cos_sin, tokens_per_image: int, rope_cols: int):
-    """bf16 out[M,N] = a @ w.T + bias with RoPE-2D applied to the 64-wide heads in columns < rope_cols."""
+def rope_token_table(pos_yx, cos_sin):
+    """pos_yx int [T,2] (y,x), cos_sin f32 [max_pos,16,2] -> per-token table f32 [T,2,2,16] = (token, axis y|x,
+    cos|sin, frequency): what the fused RoPE epilogue reads, no position lookup on the device."""
+    return cos_sin[pos_yx.long()].transpose(-1, -2).contiguous()
+
+
+def gemm_rope(a, w, bias, rope_tok, rope_cols: int):
+    """16-bit out[M,N] = a @ w.T + bias with RoPE-2D applied to the 64-wide heads in columns < rope_cols;
+    rope_tok f32 [tokens_per_image,2,2,16] (rope_token_table)."""
+    rope_tok = _ffi.check(rope_tok, torch.float32, "rope_tok", (None, 2, 2, 16))
+    tokens_per_image = rope_tok.shape[0]
     a = _ffi.check(a, H16, "a")
     w = _ffi.check(w, H16, "w")
     dt = _same16(a, w)
@@ -102,7 +111,7 @@ def gemm_rope(a, w, bias, pos_yx, cos_sin, tokens_per_image: int, rope_cols: int
     out = torch.empty((m, n), dtype=a.dtype, device=a.device)
     e0 = _prof_begin()
     _ffi.call("m3_gemm_rope_dt", _ffi.ptr(a), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(out), m, n, k, n,
-              _ffi.ptr(pos_yx), _ffi.ptr(cos_sin), tokens_per_image, rope_cols, dt, _ffi.stream_ptr())
+              _ffi.ptr(rope_tok), tokens_per_image, rope_cols, dt, _ffi.stream_ptr())
     _prof_end(e0, _gemm_kind(m, n), 2.0 * m * n * k, 2.0 * (m * k + n * k + m * n))
     return out
 
@@ -283,7 +292,7 @@ def add(a, b):
 
 def gemm_grouped2(a, w0, w1, b0, b1, epi=EPI_BF16, out=None, resid=None, rope=None):
     """Two same-shape GEMMs in one launch.  a [2,M,K] bf16, weights [N,K] x2 -> out [2,M,N].
-    rope = (pos_yx, cos_sin, tokens_per_image, rope_cols) with epi=EPI_BF16_ROPE."""
+    rope = (rope_tok [T,2,2,16] f32, rope_cols) with epi=EPI_BF16_ROPE."""
     a = _ffi.check(a, H16, "a")
     if a.dim() != 3 or a.shape[0] != 2:
         raise ValueError(f"a must be [2,M,K], got {tuple(a.shape)}")
@@ -299,10 +308,14 @@ def gemm_grouped2(a, w0, w1, b0, b1, epi=EPI_BF16, out=None, resid=None, rope=No
         raise ValueError("bad `out`")
     if resid is not None and (resid.dtype != odt or tuple(resid.shape) != (2, m, n) or not resid.is_contiguous()):
         raise ValueError("bad `resid`")
-    pos, cs, tpi, rc = rope if rope is not None else (None, None, 0, 0)
+    rtok, rc = rope if rope is not None else (None, 0)
+    tpi = 0
+    if rtok is not None:
+        rtok = _ffi.check(rtok, torch.float32, "rope_tok", (None, 2, 2, 16))
+        tpi = rtok.shape[0]
     e0 = _prof_begin()
     _ffi.call("m3_gemm_grouped2_dt", _ffi.ptr(a), _ffi.ptr(w0), _ffi.ptr(w1), _ffi.ptr(b0), _ffi.ptr(b1), _ffi.ptr(out),
-              _ffi.ptr(resid), m, n, k, n, m * k, m * n, epi, _ffi.ptr(pos), _ffi.ptr(cs), tpi, rc, dt, _ffi.stream_ptr())
+              _ffi.ptr(resid), m, n, k, n, m * k, m * n, epi, _ffi.ptr(rtok), tpi, rc, dt, _ffi.stream_ptr())
     _prof_end(e0, _gemm_kind(m, n, 2), 4.0 * m * n * k,
               2.0 * (2.0 * (m * k + n * k) + out.element_size() * m * n * (1 if resid is None else 2)))
     return out

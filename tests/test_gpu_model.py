@@ -405,7 +405,7 @@ def test_gemm_with_fused_rope_epilogue(dev, m_n_k):
     rot = OM.rope2d(ref[:, :rope_cols].reshape(m // t, t, heads, 64).transpose(1, 2), pos, cos, sin)
     ref = torch.cat([rot.transpose(1, 2).reshape(m, rope_cols), ref[:, rope_cols:]], 1)
     cs = torch.stack([cos, sin], -1).to(dev).contiguous()
-    out = ops.gemm_rope(a.to(dev), w.to(dev), b.to(dev), pos.to(torch.int32).to(dev), cs, t, rope_cols)
+    out = ops.gemm_rope(a.to(dev), w.to(dev), b.to(dev), ops.rope_token_table(pos.to(dev), cs), rope_cols)
     assert _rel(out, ref) < 3e-3
 
 

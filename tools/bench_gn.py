@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Gauss-Newton legs alone on the benchmark scene (P = 8 pairs x 262144 points): tracking solve (10 iterations) and
+one backend block pass at config-5 scale.  Run under rocprofv3 --kernel-trace --stats for per-kernel times."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "mast3r-slam_amd")]
+import numpy as np, torch
+import bench
+from mast3r_slam import config, matching, synthetic, tracker
+dev = torch.device("cuda:0")
+P, n = 8, 512 * 512
+config.set_config({"matching": {"use_simple": False}})
+sc = bench.make_scene(synthetic, P, 0, dev)
+tcfg = config.get_config()["tracking"]
+ident = torch.tensor([0, 0, 0, 0, 0, 0, 1, 1], dtype=torch.float32, device=dev)
+idx, valid = matching.match(sc["X11"], sc["X21"], sc["D11"], sc["D21"])
+def gn():
+    Xf, Qk, vo, vk, cnt = tracker.track_gather(sc["X11"].reshape(P, n, 3), sc["Cf"], sc["Ck"], sc["Qf"], sc["Qk"], idx, valid.reshape(P, n), tcfg["C_conf"], tcfg["Q_conf"])
+    return tracker.opt_pose_ray_dist_sim3(Xf, sc["Xk"], ident, ident, Qk, vo, tcfg, fixed_iters=True)
+for _ in range(3):
+    gn()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    out = gn()
+e1.record(); torch.cuda.synchronize()
+print(f"track_gather + 10-iteration GN solve, P={P}: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us;  T_rel[0] = {out[1][0].tolist()}")
+for _ in range(5):
+    matching.match(sc["X11"], sc["X21"], sc["D11"], sc["D21"])
+torch.cuda.synchronize()

@@ -47,3 +47,32 @@ __device__ __forceinline__ unsigned m3_wave_max(unsigned v) {
     }
     return v;
 }
+
+// ---- 36 float64 sums per thread -> one row per 256-thread workgroup, fixed order, through LDS --------------
+// A float64 shuffle tree costs 36 x 6 x 2 ds_bpermute + 216 adds per wave (a third of the Gauss-Newton
+// accumulation kernels at 8 points per thread).  Here every lane stores its 36 values (row = sum, column = lane;
+// rows padded to 65 doubles so the column reads of lanes 0..35 fall on distinct banks), lane i < 36 adds row i
+// with four independent chains, threads 0..35 add the four wave totals: 36 stores + 64 loads + 64 adds per wave.
+__device__ __forceinline__ void m3_block_reduce36(const double *acc, double *__restrict__ out) {
+    constexpr int kS = 36, kW = 4, kStride = 65;
+    __shared__ double red[kW][kS][kStride];
+    __shared__ double tot[kW][kS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < kS; ++i) red[wv][i][lane] = acc[i];
+    __syncthreads();
+    if (lane < kS) {
+        const double *row = red[wv][lane];
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 64; k += 4) { s0 += row[k]; s1 += row[k + 1]; s2 += row[k + 2]; s3 += row[k + 3]; }
+        tot[wv][lane] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    if (threadIdx.x < kS) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < kW; ++w) s += tot[w][threadIdx.x];
+        out[threadIdx.x] = s;
+    }
+}

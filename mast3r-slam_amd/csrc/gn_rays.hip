@@ -33,12 +33,63 @@ __host__ __device__ inline int gn_chunks(int P) {
     return c < 1 ? 1 : (c > kMaxChunks ? kMaxChunks : c);
 }
 
+// One point of edge (i, j): adds its 36 sums to h (fp32) in the UNROTATED tangent frame.  The pose Jacobian of
+// the transformed point Y = Tij . Xj is JX = [R_i / s_i | B(Y) R_i | Y] = M'(Y) G with M' = [I / s_i | B | Y] and
+// G = blockdiag(R_i, R_i, 1) constant per edge (gauss_newton.py:164-213), so the kernel accumulates M'^T A M' and
+// M'^T b - the same congruence as the tracking solve - and k_gn_reduce applies G once per edge: no quaternion
+// rotation per point.  A = sum_c w_c D_c D_c^T with D = d(residual)/dY (identity for the 3-D residuals).
+// Returns false when the point is gated out.
+template <int MODE>
+__device__ __forceinline__ bool gn_point(const Pose<float> &Tij, float s_inv, const V3<float> &Xi, const V3<float> &Xj,
+                                         float qc, float inv_sigma, const CalibParams &cal, float *h) {
+    const V3<float> Y = act(Tij, Xj);
+    float err[3] = {Y.x - Xi.x, Y.y - Xi.y, Y.z - Xi.z};
+    float sqrt_w = inv_sigma * __builtin_amdgcn_sqrtf(qc);
+    if (MODE == 1)                                      // gauss_newton_points.py:103-107: 1/(|Xi| + 1e-6)
+        sqrt_w *= __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(dot(Xi, Xi)) + 1e-6f);
+    float d0x = 1.f, d0z = 0.f, d1y = 1.f, d1z = 0.f, d2z = 1.f;
+    if (MODE == 2) {                                    // gauss_newton_calib.py:118-176
+        if (!(Y.z > cal.z_eps) || !(Xi.z > cal.z_eps)) return false;
+        const float zj = 1.0f / Y.z, zi = 1.0f / Xi.z;
+        const float pju = cal.fx * Y.x * zj + cal.cx, pjv = cal.fy * Y.y * zj + cal.cy;
+        const float piu = cal.fx * Xi.x * zi + cal.cx, piv = cal.fy * Xi.y * zi + cal.cy;
+        if (!(pju >= cal.border && pju < cal.width - cal.border && pjv >= cal.border && pjv < cal.height - cal.border))
+            return false;
+        err[0] = (pju - piu) * cal.inv_sigma_pixel;
+        err[1] = (pjv - piv) * cal.inv_sigma_pixel;
+        err[2] = (logf(Y.z) - logf(Xi.z)) * cal.inv_sigma_depth;
+        sqrt_w = sqrtf(qc);
+        d0x = cal.fx * zj * cal.inv_sigma_pixel; d0z = -cal.fx * Y.x * zj * zj * cal.inv_sigma_pixel;
+        d1y = cal.fy * zj * cal.inv_sigma_pixel; d1z = -cal.fy * Y.y * zj * zj * cal.inv_sigma_pixel;
+        d2z = zj * cal.inv_sigma_depth;
+    }
+    const float w2 = sqrt_w * sqrt_w;
+    float w[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float we = fabsf(sqrt_w * err[c]);
+        w[c] = ((we < 1.345f) ? 1.0f : (MODE == 2 ? 1.345f / we : 1.345f * __builtin_amdgcn_rcpf(we))) * w2;
+    }
+    // D rows: (d0x, 0, d0z), (0, d1y, d1z), (0, 0, d2z)
+    const float Axx = w[0] * d0x * d0x, Axz = w[0] * d0x * d0z, Ayy = w[1] * d1y * d1y, Ayz = w[1] * d1y * d1z;
+    const float Azz = w[0] * d0z * d0z + w[1] * d1z * d1z + w[2] * d2z * d2z;
+    const float e0 = w[0] * err[0], e1 = w[1] * err[1], e2 = w[2] * err[2];
+    const V3<float> b{e0 * d0x, e1 * d1y, e0 * d0z + e1 * d1z + e2 * d2z};
+    accum_congruence(Y, Axx, 0.f, Axz, Ayy, Ayz, Azz, b, s_inv, 1.0f, h);
+    h[35] += 1.0f;
+    return true;
+}
+
+// 4 consecutive points of the edge per lane and trip: validity (4 bytes), Q, idx, C_j and X_j come in as dwordx4
+// loads with the next trip's loads issued before this trip's arithmetic; only X_i / C_i at the match index are
+// gathers.  fp32 sums over the <= 4 points, one float64 fold per trip (see k_track_accum).
+template <int MODE>
 __global__ void __launch_bounds__(kThreads)
 k_gn_blocks(const float *__restrict__ Twc, const float *__restrict__ Xs, const float *__restrict__ Cs,
             const int32_t *__restrict__ ii, const int32_t *__restrict__ jj, const int32_t *__restrict__ idx,
             const uint8_t *__restrict__ valid, const float *__restrict__ Q, double *__restrict__ part,
             const double *__restrict__ done, int K, int P, int chunks, float inv_sigma, float C_thresh,
-            float Q_thresh, int point_mode, const CalibParams cal) {
+            float Q_thresh, const CalibParams cal) {
     if (done && done[0] != 0.0) return;
     const int e = blockIdx.y, chunk = blockIdx.x;
     const int ix = ii[e], jx = jj[e];
@@ -52,106 +103,112 @@ k_gn_blocks(const float *__restrict__ Twc, const float *__restrict__ Xs, const f
         Tij.t = {(float)Tij_d.t.x, (float)Tij_d.t.y, (float)Tij_d.t.z};
         Tij.q = {(float)Tij_d.q.x, (float)Tij_d.q.y, (float)Tij_d.q.z, (float)Tij_d.q.w};
         Tij.s = (float)Tij_d.s;
-        const Q4<float> qi_inv{-(float)Ti.q.x, -(float)Ti.q.y, -(float)Ti.q.z, (float)Ti.q.w};
         const float s_inv = (float)(1.0 / Ti.s);
-        // translation columns of Jj are per-edge constants: R_i^T e_c / s_i
-        const V3<float> jt[3] = {s_inv * qrot(qi_inv, V3<float>{1.f, 0.f, 0.f}),
-                                 s_inv * qrot(qi_inv, V3<float>{0.f, 1.f, 0.f}),
-                                 s_inv * qrot(qi_inv, V3<float>{0.f, 0.f, 1.f})};
         const float *Xi_base = Xs + (size_t)ix * P * 3, *Xj_base = Xs + (size_t)jx * P * 3;
         const float *Ci = Cs + (size_t)ix * P, *Cj = Cs + (size_t)jx * P;
         const size_t eo = (size_t)e * P;
-        for (int k = chunk * kThreads + threadIdx.x; k < P; k += chunks * kThreads) {
-            if (!valid[eo + k]) continue;
-            const float qc = Q[eo + k];
-            int id = idx[eo + k];
+        auto one = [&](int k, bool vld, float qc, int id, float cj, const V3<float> &Xj, float *h) {
+            if (!vld) return;
             if (id < 0) id += P;
             id = id < 0 ? 0 : (id >= P ? P - 1 : id);
-            if (!(qc > Q_thresh) || !(Ci[id] > C_thresh) || !(Cj[k] > C_thresh)) continue;
-            const V3<float> Xi{Xi_base[3 * id], Xi_base[3 * id + 1], Xi_base[3 * id + 2]};
-            const V3<float> Xj{Xj_base[3 * k], Xj_base[3 * k + 1], Xj_base[3 * k + 2]};
-            const V3<float> Y = act(Tij, Xj);
-            float err[3] = {Y.x - Xi.x, Y.y - Xi.y, Y.z - Xi.z};
-            float sqrt_w = inv_sigma * sqrtf(qc);
-            if (point_mode == 1)                            // gauss_newton_points.py:103-107: 1/(|Xi| + 1e-6)
-                sqrt_w *= 1.0f / (sqrtf(dot(Xi, Xi)) + 1e-6f);
-            // rows of d(residual)/dX (identity for the 3-D residuals)
-            float d0x = 1.f, d0z = 0.f, d1y = 1.f, d1z = 0.f, d2z = 1.f;
-            if (point_mode == 2) {                          // gauss_newton_calib.py:118-176
-                if (!(Y.z > cal.z_eps) || !(Xi.z > cal.z_eps)) continue;
-                const float zj = 1.0f / Y.z, zi = 1.0f / Xi.z;
-                const float pju = cal.fx * Y.x * zj + cal.cx, pjv = cal.fy * Y.y * zj + cal.cy;
-                const float piu = cal.fx * Xi.x * zi + cal.cx, piv = cal.fy * Xi.y * zi + cal.cy;
-                if (!(pju >= cal.border && pju < cal.width - cal.border && pjv >= cal.border &&
-                      pjv < cal.height - cal.border)) continue;
-                err[0] = (pju - piu) * cal.inv_sigma_pixel;
-                err[1] = (pjv - piv) * cal.inv_sigma_pixel;
-                err[2] = (logf(Y.z) - logf(Xi.z)) * cal.inv_sigma_depth;
-                sqrt_w = sqrtf(qc);
-                d0x = cal.fx * zj * cal.inv_sigma_pixel; d0z = -cal.fx * Y.x * zj * zj * cal.inv_sigma_pixel;
-                d1y = cal.fy * zj * cal.inv_sigma_pixel; d1z = -cal.fy * Y.y * zj * zj * cal.inv_sigma_pixel;
-                d2z = zj * cal.inv_sigma_depth;
+            if (!(qc > Q_thresh) || !(Ci[id] > C_thresh) || !(cj > C_thresh)) return;
+            gn_point<MODE>(Tij, s_inv, V3<float>{Xi_base[3 * id], Xi_base[3 * id + 1], Xi_base[3 * id + 2]}, Xj, qc,
+                           inv_sigma, cal, h);
+        };
+        const bool vec = (P % 4 == 0) && ((reinterpret_cast<size_t>(Xs) | reinterpret_cast<size_t>(Cs) | reinterpret_cast<size_t>(Q) |
+                                           reinterpret_cast<size_t>(idx)) % 16 == 0) && (reinterpret_cast<size_t>(valid) % 4 == 0);
+        if (vec) {
+            const int groups = P / 4, stride = chunks * kThreads;
+            int gi = chunk * kThreads + threadIdx.x;
+            float4 xj[3], q4, c4;
+            int4 i4;
+            unsigned v = 0;
+            auto load = [&](int g) {
+                const float4 *px = reinterpret_cast<const float4 *>(Xj_base) + 3 * (size_t)g;
+                xj[0] = px[0]; xj[1] = px[1]; xj[2] = px[2];
+                q4 = reinterpret_cast<const float4 *>(Q + eo)[g];
+                c4 = reinterpret_cast<const float4 *>(Cj)[g];
+                i4 = reinterpret_cast<const int4 *>(idx + eo)[g];
+                v = reinterpret_cast<const unsigned *>(valid + eo)[g];
+            };
+            if (gi < groups) load(gi);
+            while (gi < groups) {
+                const float4 x0 = xj[0], x1 = xj[1], x2 = xj[2], qq = q4, cc = c4;
+                const int4 id4 = i4;
+                const unsigned vv = v;
+                const int nx = gi + stride;
+                if (nx < groups) load(nx);
+                float h[kSums];
+#pragma unroll
+                for (int i = 0; i < kSums; ++i) h[i] = 0.f;
+                one(4 * gi + 0, vv & 0x000000ffu, qq.x, id4.x, cc.x, V3<float>{x0.x, x0.y, x0.z}, h);
+                one(4 * gi + 1, vv & 0x0000ff00u, qq.y, id4.y, cc.y, V3<float>{x0.w, x1.x, x1.y}, h);
+                one(4 * gi + 2, vv & 0x00ff0000u, qq.z, id4.z, cc.z, V3<float>{x1.z, x1.w, x2.x}, h);
+                one(4 * gi + 3, vv & 0xff000000u, qq.w, id4.w, cc.w, V3<float>{x2.y, x2.z, x2.w}, h);
+#pragma unroll
+                for (int i = 0; i < kSums; ++i) acc[i] += (double)h[i];
+                gi = nx;
             }
-            const float w2 = sqrt_w * sqrt_w;
-            const V3<float> br[3] = {{0.f, Y.z, -Y.y}, {-Y.z, 0.f, Y.x}, {Y.y, -Y.x, 0.f}};
-            const float Yc[3] = {Y.x, Y.y, Y.z};
-            // pose Jacobian of the transformed point, row k: [R_i^T e_k / s_i | R_i^T br_k | Y_k]
-            float JX[3][7];
+        } else {
+            for (int k = chunk * kThreads + threadIdx.x; k < P; k += chunks * kThreads) {
+                float h[kSums];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const V3<float> jr = qrot(qi_inv, br[k]);
-                JX[k][0] = jt[k].x; JX[k][1] = jt[k].y; JX[k][2] = jt[k].z;
-                JX[k][3] = jr.x; JX[k][4] = jr.y; JX[k][5] = jr.z; JX[k][6] = Yc[k];
+                for (int i = 0; i < kSums; ++i) h[i] = 0.f;
+                one(k, valid[eo + k] != 0, Q[eo + k], idx[eo + k], Cj[k], V3<float>{Xj_base[3 * k], Xj_base[3 * k + 1], Xj_base[3 * k + 2]}, h);
+#pragma unroll
+                for (int i = 0; i < kSums; ++i) acc[i] += (double)h[i];
             }
-            // accumulate straight into the float64 registers with a closed-form index (a temporary
-            // float h[] indexed by a running counter was mis-compiled in tracking.hip)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float we = fabsf(sqrt_w * err[c]);
-                const float w = ((we < 1.345f) ? 1.0f : 1.345f / we) * w2;
-                float J[7];
-#pragma unroll
-                for (int i = 0; i < 7; ++i)
-                    J[i] = (c == 0) ? d0x * JX[0][i] + d0z * JX[2][i]
-                         : (c == 1) ? d1y * JX[1][i] + d1z * JX[2][i]
-                                    : d2z * JX[2][i];
-#pragma unroll
-                for (int i = 0; i < 7; ++i) {
-                    const float wj = w * J[i];
-#pragma unroll
-                    for (int j = i; j < 7; ++j) acc[i * 7 - (i * (i - 1)) / 2 + (j - i)] += (double)(wj * J[j]);
-                    acc[28 + i] += (double)(wj * err[c]);
-                }
-            }
-            acc[35] += 1.0;
         }
     }
-    __shared__ double red[kThreads / 64][kSums];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < kSums; ++i) {
-        const double s = m3_wave_sum(acc[i]);
-        if (lane == 0) red[wv][i] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < kSums) {
-        double s = 0.0;
-#pragma unroll
-        for (int w = 0; w < kThreads / 64; ++w) s += red[w][threadIdx.x];
-        part[((size_t)e * chunks + chunk) * kSums + threadIdx.x] = s;
-    }
+    m3_block_reduce36(acc, part + ((size_t)e * chunks + chunk) * kSums);
 }
 
-// fixed-order reduction over the chunks of one edge
+// Fixed-order reduction over the chunks of one edge, then the per-edge constant frame change
+// H = G^T H' G, g = G^T g' with G = blockdiag(R_i, R_i, 1) (see gn_point), in float64.
 __global__ void __launch_bounds__(64)
 k_gn_reduce(const double *__restrict__ part, double *__restrict__ blocks, const double *__restrict__ done,
-            int chunks) {
+            const float *__restrict__ Twc, const int32_t *__restrict__ ii, int K, int chunks) {
     if (done && done[0] != 0.0) return;
-    const int e = blockIdx.x;
-    if (threadIdx.x >= kSums) return;
+    const int e = blockIdx.x, t = threadIdx.x;
+    __shared__ double Hp[7][7], gp[7], G[7][7];
     double s = 0.0;
-    for (int c = 0; c < chunks; ++c) s += part[((size_t)e * chunks + c) * kSums + threadIdx.x];
-    blocks[(size_t)e * kSums + threadIdx.x] = s;
+    if (t < kSums)
+        for (int c = 0; c < chunks; ++c) s += part[((size_t)e * chunks + c) * kSums + t];
+    if (t < 28) {
+        int r = 0, k = t;
+        while (k >= 7 - r) { k -= 7 - r; ++r; }
+        Hp[r][r + k] = s; Hp[r + k][r] = s;
+    } else if (t < 35) gp[t - 28] = s;
+    else if (t == 35) blocks[(size_t)e * kSums + 35] = s;
+    if (t < 49) G[t / 7][t % 7] = (t / 7 == t % 7 && t == 48) ? 1.0 : 0.0;
+    __syncthreads();
+    const int ix = ii[e];
+    if (t == 0 && ix >= 0 && ix < K) {
+        const Pose<double> Ti = load_pose<double>(Twc + 8 * ix);
+        const V3<double> r0 = qrot(Ti.q, V3<double>{1.0, 0.0, 0.0}), r1 = qrot(Ti.q, V3<double>{0.0, 1.0, 0.0}),
+                         r2 = qrot(Ti.q, V3<double>{0.0, 0.0, 1.0});          // columns of R_i
+        const double R[3][3] = {{r0.x, r1.x, r2.x}, {r0.y, r1.y, r2.y}, {r0.z, r1.z, r2.z}};
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) { G[a][b] = R[a][b]; G[3 + a][3 + b] = R[a][b]; }
+    }
+    __syncthreads();
+    if (t < 49) {
+        const int r = t / 7, c = t % 7;
+        if (r <= c) {
+            double h = 0.0;
+            for (int a = 0; a < 7; ++a) {
+                double u = 0.0;
+                for (int b = 0; b < 7; ++b) u += Hp[a][b] * G[b][c];
+                h += G[a][r] * u;
+            }
+            blocks[(size_t)e * kSums + r * 7 - (r * (r - 1)) / 2 + (c - r)] = h;
+        }
+    } else if (t < 56) {
+        const int r = t - 49;
+        double v = 0.0;
+        for (int a = 0; a < 7; ++a) v += G[a][r] * gp[a];
+        blocks[(size_t)e * kSums + 28 + r] = v;
+    }
 }
 
 // Dense system from the per-edge blocks (gauss_newton.py:220-251): an edge (i, j) adds +Hjj to the diagonal
@@ -308,9 +365,14 @@ int launch_blocks(const float *Twc, const float *Xs, const float *Cs, const int3
     if (chunks > gn_chunks(P)) chunks = gn_chunks(P);
     if (chunks < 1) chunks = 1;
     const float inv_sigma = (float)(1.0 / (double)sigma_ray);
-    hipLaunchKernelGGL(k_gn_blocks, dim3(chunks, E), dim3(kThreads), 0, st, Twc, Xs, Cs, ii, jj, idx, valid, Q,
-                       ws, done, K, P, chunks, inv_sigma, C_thresh, Q_thresh, point_mode, cal);
-    hipLaunchKernelGGL(k_gn_reduce, dim3(E), dim3(64), 0, st, (const double *)ws, blocks, done, chunks);
+    const dim3 grid(chunks, E), blk(kThreads);
+    if (point_mode == 0)
+        hipLaunchKernelGGL(k_gn_blocks<0>, grid, blk, 0, st, Twc, Xs, Cs, ii, jj, idx, valid, Q, ws, done, K, P, chunks, inv_sigma, C_thresh, Q_thresh, cal);
+    else if (point_mode == 1)
+        hipLaunchKernelGGL(k_gn_blocks<1>, grid, blk, 0, st, Twc, Xs, Cs, ii, jj, idx, valid, Q, ws, done, K, P, chunks, inv_sigma, C_thresh, Q_thresh, cal);
+    else
+        hipLaunchKernelGGL(k_gn_blocks<2>, grid, blk, 0, st, Twc, Xs, Cs, ii, jj, idx, valid, Q, ws, done, K, P, chunks, inv_sigma, C_thresh, Q_thresh, cal);
+    hipLaunchKernelGGL(k_gn_reduce, dim3(E), dim3(64), 0, st, (const double *)ws, blocks, done, Twc, ii, K, chunks);
     M3_CHECK_LAUNCH("m3_gn_rays_blocks");
     return M3_OK;
 }

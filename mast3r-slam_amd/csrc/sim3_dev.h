@@ -153,3 +153,29 @@ template <int NN> __device__ inline bool solve_small(double (*A)[NN], double *b,
     }
     return true;
 }
+
+// ---- normal-equation contribution of one point whose Jacobian rows are J_c = M(p) a_c --------------------------
+// M(p) = [st * I ; [p]x ; p^T]  (7 x 3: J = [st * a, p x a, a . p] - Sim(3) tangent order translation, rotation,
+// scale).  With A = sum_c w_c a_c a_c^T (3 x 3 symmetric) and b = sum_c w_c r_c a_c:
+//     H = M A M^T  (28 upper-triangular entries, row-major: h[0..27]),   g = gs * M b  (h[28..34])
+// i.e. 36 FMAs for (A, b) + ~60 for the congruence instead of (28 + 7) products per residual row.
+__device__ __forceinline__ void accum_congruence(const V3<float> &p, float Axx, float Axy, float Axz, float Ayy,
+                                                 float Ayz, float Azz, const V3<float> &b, float st, float gs,
+                                                 float *h) {
+    const V3<float> Ap{Axx * p.x + Axy * p.y + Axz * p.z, Axy * p.x + Ayy * p.y + Ayz * p.z, Axz * p.x + Ayz * p.y + Azz * p.z};
+    const V3<float> c0 = cross(p, V3<float>{Axx, Axy, Axz}), c1 = cross(p, V3<float>{Axy, Ayy, Ayz}),
+                    c2 = cross(p, V3<float>{Axz, Ayz, Azz});                       // H_t,omega[i][j] = st * c_i[j]
+    const V3<float> w0 = cross(p, V3<float>{c0.x, c1.x, c2.x}), w1 = cross(p, V3<float>{c0.y, c1.y, c2.y}),
+                    w2 = cross(p, V3<float>{c0.z, c1.z, c2.z});                    // H_omega,omega[i][j] = w_i[j]
+    const V3<float> pAp = cross(p, Ap), pb = cross(p, b);
+    const float st2 = st * st;
+    h[0] += st2 * Axx; h[1] += st2 * Axy; h[2] += st2 * Axz; h[3] += st * c0.x; h[4] += st * c0.y; h[5] += st * c0.z; h[6] += st * Ap.x;
+    h[7] += st2 * Ayy; h[8] += st2 * Ayz; h[9] += st * c1.x; h[10] += st * c1.y; h[11] += st * c1.z; h[12] += st * Ap.y;
+    h[13] += st2 * Azz; h[14] += st * c2.x; h[15] += st * c2.y; h[16] += st * c2.z; h[17] += st * Ap.z;
+    h[18] += w0.x; h[19] += w0.y; h[20] += w0.z; h[21] += pAp.x;
+    h[22] += w1.y; h[23] += w1.z; h[24] += pAp.y;
+    h[25] += w2.z; h[26] += pAp.z;
+    h[27] += dot(p, Ap);
+    h[28] += gs * st * b.x; h[29] += gs * st * b.y; h[30] += gs * st * b.z;
+    h[31] += gs * pb.x; h[32] += gs * pb.y; h[33] += gs * pb.z; h[34] += gs * dot(p, b);
+}

@@ -56,34 +56,7 @@ __global__ void k_track_init(const float *__restrict__ T_WCf, const float *__res
     ws[WS_DONE] = 0.0; ws[WS_ITERS] = 0.0; ws[WS_TAUN] = 0.0; ws[WS_COST] = 0.0; ws[WS_CONV] = 0.0;
 }
 
-// 36 per-thread sums -> one partial row of this workgroup, in a fixed order.  Through LDS, not shuffles: a
-// float64 shuffle tree is 36 x 6 x 2 ds_bpermute + 216 adds per wave (a third of the kernel at 8 points per thread);
-// here every lane stores its 36 values (row i = sum, column = lane; rows padded to 65 doubles so the column reads
-// of lanes 0..35 fall on distinct banks), lane i < 36 adds row i with four independent chains, and the four
-// wave totals are added by threads 0..35: 36 stores + 64 loads + 64 adds per wave.
-constexpr int kRedStride = 65;
-__device__ __forceinline__ void block_reduce_store(const double *acc, double *__restrict__ out) {
-    __shared__ double red[kThreads / 64][kSums][kRedStride];
-    __shared__ double tot[kThreads / 64][kSums];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < kSums; ++i) red[wv][i][lane] = acc[i];
-    __syncthreads();
-    if (lane < kSums) {
-        const double *row = red[wv][lane];
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 64; k += 4) { s0 += row[k]; s1 += row[k + 1]; s2 += row[k + 2]; s3 += row[k + 3]; }
-        tot[wv][lane] = (s0 + s1) + (s2 + s3);
-    }
-    __syncthreads();
-    if (threadIdx.x < kSums) {
-        double s = 0.0;
-#pragma unroll
-        for (int w = 0; w < kThreads / 64; ++w) s += tot[w][threadIdx.x];
-        out[threadIdx.x] = s;
-    }
-}
+__device__ __forceinline__ void block_reduce_store(const double *acc, double *__restrict__ out) { m3_block_reduce36(acc, out); }
 
 // One point's contribution to the 36 sums, ADDED into h (fp32).  Every Jacobian row is J_c = rsi_c * M(p) a_c
 // with M(p) = [I; [p]x; p^T] (7x3: J = [a, p x a, a.p], geometry.py:118-137) and a_c = -(row c of d(ray,dist)/dP),
@@ -122,20 +95,7 @@ __device__ __forceinline__ void track_point(const Pose<float> &T, const V3<float
         b = b + wres * a[c];
         cost += 0.5f * wres * res[c];
     }
-    const V3<float> Ap{Axx * p.x + Axy * p.y + Axz * p.z, Axy * p.x + Ayy * p.y + Ayz * p.z, Axz * p.x + Ayz * p.y + Azz * p.z};
-    const V3<float> c0 = cross(p, V3<float>{Axx, Axy, Axz}), c1 = cross(p, V3<float>{Axy, Ayy, Ayz}),
-                    c2 = cross(p, V3<float>{Axz, Ayz, Azz});                       // H_t,omega[i][j] = c_i[j]
-    const V3<float> w0 = cross(p, V3<float>{c0.x, c1.x, c2.x}), w1 = cross(p, V3<float>{c0.y, c1.y, c2.y}),
-                    w2 = cross(p, V3<float>{c0.z, c1.z, c2.z});                    // H_omega,omega[i][j] = w_i[j]
-    const V3<float> pAp = cross(p, Ap), pb = cross(p, b);
-    h[0] += Axx;  h[1] += Axy;  h[2] += Axz;  h[3] += c0.x;  h[4] += c0.y;  h[5] += c0.z;  h[6] += Ap.x;
-    h[7] += Ayy;  h[8] += Ayz;  h[9] += c1.x;  h[10] += c1.y; h[11] += c1.z; h[12] += Ap.y;
-    h[13] += Azz; h[14] += c2.x; h[15] += c2.y; h[16] += c2.z; h[17] += Ap.z;
-    h[18] += w0.x; h[19] += w0.y; h[20] += w0.z; h[21] += pAp.x;
-    h[22] += w1.y; h[23] += w1.z; h[24] += pAp.y;
-    h[25] += w2.z; h[26] += pAp.z;
-    h[27] += dot(p, Ap);
-    h[28] -= b.x; h[29] -= b.y; h[30] -= b.z; h[31] -= pb.x; h[32] -= pb.y; h[33] -= pb.z; h[34] -= dot(p, b);
+    accum_congruence(p, Axx, Axy, Axz, Ayy, Ayz, Azz, b, 1.0f, -1.0f, h);
     h[35] += cost;
 }
 

@@ -29,3 +29,19 @@ print(f"track_gather + 10-iteration GN solve, P={P}: {e0.elapsed_time(e1) / 10 *
 for _ in range(5):
     matching.match(sc["X11"], sc["X21"], sc["D11"], sc["D21"])
 torch.cuda.synchronize()
+
+# ---- backend blocks at config-5 scale: 64 keyframes x 262144 points, each linked to its previous 3 (both directions)
+from mast3r_slam import kernels
+K_, P_ = 64, 512 * 512
+g = synthetic.gn_graph(K_, P_, 0, seed=17, chain=True, pose_noise=0.0)
+args = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in g]
+E = len(g[3])
+for _ in range(2):
+    kernels.gn_rays_blocks(*args)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(5):
+    kernels.gn_rays_blocks(*args)
+e1.record(); torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / 5 * 1e3
+print(f"gn_rays_blocks {E} directed edges x {P_} points: {us:.0f} us = {E * 10.8e6 / us / 1e6:.2f} TB/s of the 10.8 MB/edge algorithmic traffic")

@@ -102,6 +102,15 @@ int m3_conv3x3_relu_head4_dt(const void *X, const void *W, const float *bias, co
                              float *pts, float *conf, const void *zero16, int B, int H, int Wd, int Cin,
                              int dtype, void *stream);
 
+/* The same tail as a DIRECT convolution with the x2 bilinear (align_corners) upsampling of its input fused in
+ * (public DPT head: head.0 -> Upsample(x2) -> head.2 conv3x3 + ReLU -> head.4 1x1; oracle/model.py dpt_head):
+ * X NHWC [B,H/2,W/2,128] when upsample != 0, else [B,H,W,128]; W [128,3,3,128], W4 [4,128] in the 16-bit dtype.
+ * A workgroup stages the 18x18x128 halo of its 16x16 output tile once in LDS (interpolating it on the way in),
+ * so the full-resolution 128-channel map is neither written nor re-read.  H, W multiples of 16. */
+int m3_dpt_tail_dt(const void *X, const void *W, const float *bias, const void *W4, const float *b4,
+                   float *pts, float *conf, const void *zero16, int B, int H, int Wd, int upsample,
+                   int dtype, void *stream);
+
 /* Fused multi-head attention, head dim 64: O = softmax(scale * Q K^T) V, bf16 in/out, fp32
  * softmax.  Q/K/V/O are addressed as base + batch*batch_stride + token*row_stride + head*64
  * (element units), so q, k, v may live interleaved in one [tokens, 3C] projection buffer.

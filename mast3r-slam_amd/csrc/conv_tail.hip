@@ -1,0 +1,341 @@
+// Tail of the DPT head as ONE direct convolution kernel for gfx950:
+//
+//   [x2 bilinear upsample (align_corners) of the 128-channel head.0 map]  ->  head.2 conv3x3 128->128 + bias + ReLU
+//   ->  head.4 1x1 128->4  ->  pts3d = xyz/|xyz| * expm1(|xyz|), conf = 1 + exp(c)
+//
+// (public DPT head; oracle/model.py dpt_head :177-180, head :186-190).  The implicit-GEMM form (gemm.hip
+// EPI_RELU_HEAD4) gathers every input pixel nine times - once per tap - straight from memory and needs the
+// upsampled 512x512x128 map materialised first: k_upsample2x wrote 537 MB per head and the convolution read it
+// back (9 x through L2).  Here a workgroup owns a 16 x 16 output tile, stages the 18 x 18 x 128 input halo ONCE in
+// LDS - interpolating it on the way in when the upsample is fused, so the full-resolution map never exists - and
+// runs the nine taps as 128 x 128 GEMM slices from LDS: 1.27 x the compulsory input traffic instead of 9 x, no
+// upsample kernel, no 1 GB round trip.
+//
+// Workgroup = 512 threads = 8 waves on a 16 (rows) x 32 (pixels) output tile: wave (wp, wc) owns rows 4wp..4wp+3
+// (8 MFMA row tiles of 16 pixels) x output channels 64wc..64wc+63 (4 column tiles) = 32 accumulator tiles, the
+// 256 x 256 GEMM tile's shape (24 ds_read_b128 per 64 MFMAs).  The 128 input channels are processed as two halves:
+// per half, the 18 x 34 x 64-channel halo (78 KiB, 128-byte pixel rows with the GEMM kernels' bank-conflict-free
+// XOR swizzle) is staged once, then nine taps x 64 channels of weights (16 KiB each, double-buffered LDS-DMA) are
+// multiplied from LDS.  Weights streamed per workgroup: 288 KiB per 512 pixels (a 16 x 16 tile version streamed
+// them per 256 pixels and was bound by exactly that L2 -> LDS traffic: 2.4 GB per launch, 913 us).
+#include "gemm_common.h"
+
+using namespace m3gemm;
+
+namespace {
+
+constexpr int kThreads = 512;
+constexpr int TH = 16, TW = 32;                 // output tile
+constexpr int HH = TH + 2, HW = TW + 2;         // halo 18 x 34
+constexpr int kHaloPix = HH * HW;               // 612
+constexpr int kHaloBytes = kHaloPix * 128;      // 78 336: one 64-channel half, 128 B per pixel
+constexpr int kWStage = 128 * 128;              // 16 384: [128 out][64 in] of one tap
+constexpr int PH = 11, PW = 19;                 // input patch behind an upsampled halo (pixels)
+constexpr int kPatchBytes = (PH * PW * 128 + 1023) / 1024 * 1024;   // 27 648: whole 1 KiB LDS-DMA wave-instructions
+constexpr int kLdsBytes = kHaloBytes + 2 * kWStage + kPatchBytes;   // 138 752
+
+struct TailArgs {
+    const bf16_t *X;        // NHWC [B, IH, IW, 128]: IH = H (no upsample) or H / 2 (fused x2 upsample)
+    const bf16_t *Wc;       // [128][3][3][128]
+    const float *bias;      // [128] or null
+    const bf16_t *W4;       // [4][128]
+    const float *b4;        // [4]
+    float *pts, *conf;      // [B,H,W,3], [B,H,W]
+    const bf16_t *zero16;
+    int B, H, W, IH, IW;
+};
+
+template <int DT, bool UPS>
+__global__ void __launch_bounds__(kThreads, 2)
+k_conv_tail(const TailArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char *halo = lds, *wst = lds + kHaloBytes, *patch = lds + kHaloBytes + 2 * kWStage;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave >> 1, wc = wave & 1;                 // pixel-row group (4 rows), output-channel half
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = a.H / TH;
+    const int nwg = tiles_x * tiles_y * a.B;
+    const int bid = xcd_remap(blockIdx.x, nwg);              // neighbouring tiles (shared halo rows) on one XCD
+    const int b = bid / (tiles_x * tiles_y), trem = bid - b * tiles_x * tiles_y;
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const bf16_t *img = a.X + (size_t)b * a.IH * a.IW * 128;
+
+    // weights of (tap, input half) -> stage buf: 128 rows x 8 chunks' = 1024 slots, 2 per thread
+    auto stage_w = [&](int tap, int half, int buf) {
+        unsigned char *base = wst + buf * kWStage;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int slot = i * kThreads + tid;
+            const int row = slot >> 3, cp = slot & 7;
+            const int c = half * 8 + (cp ^ ((row >> 1) & 7));
+            glds16(a.Wc + ((size_t)row * 9 + tap) * 128 + c * 8, base + i * (kThreads * 16) + wave * 1024);
+        }
+    };
+    // x2 bilinear (align_corners): the 18 x 34 halo of the H x W image blends an (at most) 11 x 19 input patch
+    const float sy = UPS && a.H > 1 ? (float)(a.IH - 1) / (float)(a.H - 1) : 0.f;
+    const float sx = UPS && a.W > 1 ? (float)(a.IW - 1) / (float)(a.W - 1) : 0.f;
+    const int py0 = (int)((float)max(oy0 - 1, 0) * sy), px0 = (int)((float)max(ox0 - 1, 0) * sx);
+    auto stage_patch = [&](int half) {          // 209 pixels x 8 chunks = 1672 slots -> 27 wave-instructions (padded)
+        for (int wi = wave; wi < (PH * PW * 8 + 63) / 64; wi += kThreads / 64) {
+            int slot = wi * 64 + lane;
+            slot = slot < PH * PW * 8 ? slot : PH * PW * 8 - 1;
+            const int pp = slot >> 3, c = slot & 7;
+            const int y = min(py0 + pp / PW, a.IH - 1), x = min(px0 + pp % PW, a.IW - 1);
+            glds16(img + ((size_t)y * a.IW + x) * 128 + (half * 8 + c) * 8, patch + wi * 1024);
+        }
+    };
+    auto stage_halo_direct = [&](int half) {    // 612 pixels x 8 chunks' = 4896 slots = 76.5 wave-instructions
+        for (int wi = wave; wi < (kHaloPix * 8 + 63) / 64; wi += kThreads / 64) {
+            int slot = wi * 64 + lane;
+            const bool live = slot < kHaloPix * 8;
+            slot = live ? slot : kHaloPix * 8 - 1;
+            const int pix = slot >> 3, cp = slot & 7;
+            const int hy = pix / HW, hx = pix - hy * HW;
+            const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
+            const int c = half * 8 + (cp ^ ((pix >> 1) & 7));
+            const bool in = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const void *src = in ? (const void *)(img + ((size_t)iy * a.IW + ix) * 128 + c * 8) : (const void *)a.zero16;
+            // the last wave-instruction is half full: its upper 32 lanes would land in the weight stage - use a plain store
+            if (wi * 64 + 64 <= kHaloPix * 8) glds16(src, halo + wi * 1024);
+            else if (live) *reinterpret_cast<uint4 *>(halo + (size_t)slot * 16) = *reinterpret_cast<const uint4 *>(src);
+        }
+    };
+    auto blend_halo = [&]() {                    // patch (LDS) -> halo (LDS), same arithmetic as k_upsample2x
+        for (int slot = tid; slot < kHaloPix * 8; slot += kThreads) {
+            const int pix = slot >> 3, cp = slot & 7;
+            const int hy = pix / HW, hx = pix - hy * HW;
+            const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
+            const int c = cp ^ ((pix >> 1) & 7);
+            uint4 o = make_uint4(0u, 0u, 0u, 0u);
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+                const float fy = iy * sy, fx = ix * sx;
+                int y0 = (int)fy, x0 = (int)fx;
+                y0 = min(y0, a.IH - 1); x0 = min(x0, a.IW - 1);
+                const int y1 = min(y0 + 1, a.IH - 1), x1 = min(x0 + 1, a.IW - 1);
+                const float wy = fy - (float)y0, wx = fx - (float)x0;
+                const unsigned char *p = patch + c * 16;
+                union U { uint4 q; unsigned w[4]; } q00, q01, q10, q11, r;
+                q00.q = *reinterpret_cast<const uint4 *>(p + ((y0 - py0) * PW + (x0 - px0)) * 128);
+                q01.q = *reinterpret_cast<const uint4 *>(p + ((y0 - py0) * PW + (x1 - px0)) * 128);
+                q10.q = *reinterpret_cast<const uint4 *>(p + ((y1 - py0) * PW + (x0 - px0)) * 128);
+                q11.q = *reinterpret_cast<const uint4 *>(p + ((y1 - py0) * PW + (x1 - px0)) * 128);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float tl = lo16<DT>(q00.w[k]) * (1.f - wx) + lo16<DT>(q01.w[k]) * wx;
+                    const float bl = lo16<DT>(q10.w[k]) * (1.f - wx) + lo16<DT>(q11.w[k]) * wx;
+                    const float th = hi16<DT>(q00.w[k]) * (1.f - wx) + hi16<DT>(q01.w[k]) * wx;
+                    const float bh = hi16<DT>(q10.w[k]) * (1.f - wx) + hi16<DT>(q11.w[k]) * wx;
+                    r.w[k] = pack16<DT>(tl * (1.f - wy) + bl * wy, th * (1.f - wy) + bh * wy);
+                }
+                o = r.q;
+            }
+            *reinterpret_cast<uint4 *>(halo + (size_t)slot * 16) = o;
+        }
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fch = lane >> 4;
+    int w_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = wc * 64 + j * 16 + frow;
+        w_off[j] = r * 128 + ((fch ^ ((r >> 1) & 7)) << 4);
+    }
+
+    // Step g = half * 9 + tap multiplies 64 input channels of one tap (64 MFMAs per wave) from weight stage g & 1;
+    // the weights of step g + 1 are prefetched during step g into the other stage.  Waves 0-3 ("ping", the first wave
+    // of every SIMD) and 4-7 ("pong") run   READ(ks0) | MFMA(ks0) | READ(ks1) | MFMA(ks1)   one phase apart with a
+    // workgroup barrier per phase - the ping-pong schedule of gemm256.hip: while one wave of a SIMD issues its 32 MFMAs
+    // the other issues its 12 ds_read_b128 (a version with every wave in the same phase took 54 us per tile against
+    // 18 us of MFMA issue).
+    const int group = wave >> 2;
+    bf16x8 af[8], wf[4];
+    auto read_frags = [&](int g, int ks) {
+        const int tap = g >= 9 ? g - 9 : g;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const unsigned char *wsrc = wst + (g & 1) * kWStage;
+        const int flip = ks << 6;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8 *>(wsrc + (w_off[j] ^ flip));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pix = (wp * 4 + (i >> 1) + ky) * HW + (i & 1) * 16 + frow + kx;
+            af[i] = *reinterpret_cast<const bf16x8 *>(halo + ((pix * 128 + ((fch ^ ((pix >> 1) & 7)) << 4)) ^ flip));
+        }
+    };
+    auto mfma_all = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<DT>(wf[j], af[i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto phase_end = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto phase_end_wait = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto prefetch_w = [&](int g) { if (g + 1 < 18) stage_w((g + 1) % 9, (g + 1) / 9, (g + 1) & 1); };
+    // nine steps on the halo half that is in LDS; both groups execute the same number of barriers (4 * 9 + 1)
+    auto run_half = [&](int half) {
+        if (group == 0) {
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                const int g = half * 9 + tap;
+                read_frags(g, 0);                              // phase 0
+                prefetch_w(g);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                phase_end();
+                mfma_all();                                    // phase 1
+                phase_end();
+                read_frags(g, 1);                              // phase 2
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                phase_end();
+                mfma_all();                                    // phase 3
+                phase_end_wait();
+            }
+            phase_end();                                       // the pong group's drain phase
+        } else {
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                const int g = half * 9 + tap;
+                if (tap > 0) mfma_all();                       // phase 0: k-step 1 of the previous tap
+                phase_end();
+                read_frags(g, 0);                              // phase 1
+                prefetch_w(g);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                phase_end();
+                mfma_all();                                    // phase 2
+                phase_end();
+                read_frags(g, 1);                              // phase 3
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                phase_end_wait();
+            }
+            mfma_all();                                        // drain: k-step 1 of the last tap
+            phase_end();
+        }
+    };
+
+    stage_w(0, 0, 0);
+    if (UPS) stage_patch(0); else stage_halo_direct(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    if (UPS) {
+        blend_halo();
+        lds_barrier();
+        stage_patch(1);                                       // streams in under the nine taps of half 0
+    }
+    run_half(0);                                              // ends behind a barrier: every read of halo half 0 is done
+    if (UPS) blend_halo();                                    // (its patch was waited for by the steps' vmcnt(0))
+    else { stage_halo_direct(1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    lds_barrier();
+    run_half(1);
+
+    // ---- epilogue: h = relu(acc + bias) in fp32, raw[o] = sum_n h[n] W4[o][n] + b4[o], pointmap post-processing ----
+    const int r = lane & 15, gq = lane >> 4;
+    float part[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) part[i][o] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = wc * 64 + j * 16 + gq * 4;
+        const float4 bq = a.bias ? *reinterpret_cast<const float4 *>(a.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float w4[4][4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const uint2 q = *reinterpret_cast<const uint2 *>(a.W4 + (size_t)o * 128 + n);
+            w4[o][0] = lo16<DT>(q.x); w4[o][1] = hi16<DT>(q.x); w4[o][2] = lo16<DT>(q.y); w4[o][3] = hi16<DT>(q.y);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 v = acc[i][j];
+            const float h[4] = {fmaxf(v[0] + bq.x, 0.f), fmaxf(v[1] + bq.y, 0.f), fmaxf(v[2] + bq.z, 0.f), fmaxf(v[3] + bq.w, 0.f)};
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                part[i][o] += (h[0] * w4[o][0] + h[1] * w4[o][1]) + (h[2] * w4[o][2] + h[3] * w4[o][3]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float v = part[i][o];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            part[i][o] = v;
+        }
+    // both channel halves' partial sums through LDS, then ONE pixel per lane: lane (r, gq) of wave (wp, wc) finishes
+    // accumulator row tile i = 4 wc + gq (the first version left the 8 x (sqrt, expm1, exp) of a row to 16 lanes of
+    // every second wave)
+    float *red = reinterpret_cast<float *>(wst);             // weight stages are dead after the last barrier
+    if (gq == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<float4 *>(red + (((wp * 2 + wc) * 8 + i) * 16 + r) * 4) = make_float4(part[i][0], part[i][1], part[i][2], part[i][3]);
+    }
+    __syncthreads();
+    {
+        const int i = 4 * wc + gq;
+        const float4 p0 = *reinterpret_cast<const float4 *>(red + (((wp * 2 + 0) * 8 + i) * 16 + r) * 4);
+        const float4 p1 = *reinterpret_cast<const float4 *>(red + (((wp * 2 + 1) * 8 + i) * 16 + r) * 4);
+        const int oy = oy0 + wp * 4 + (i >> 1), ox = ox0 + (i & 1) * 16 + r;
+        if (ox < a.W) {                                       // W = 16 (mod 32): the tile's right half is outside
+            const float x = p0.x + p1.x + a.b4[0], y = p0.y + p1.y + a.b4[1];
+            const float z = p0.z + p1.z + a.b4[2], c = p0.w + p1.w + a.b4[3];
+            const float d = sqrtf(x * x + y * y + z * z);
+            const float sc = expm1f(d) / fmaxf(d, 1e-8f);
+            const size_t m = ((size_t)b * a.H + oy) * a.W + ox;
+            a.pts[3 * m + 0] = x * sc; a.pts[3 * m + 1] = y * sc; a.pts[3 * m + 2] = z * sc;
+            a.conf[m] = 1.0f + expf(c);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// X: NHWC [B, H/2, W/2, 128] when upsample != 0 (the x2 bilinear, align_corners upsampling is done on the fly),
+// else [B, H, W, 128].  H, W multiples of 16.
+int m3_dpt_tail_dt(const void *X, const void *Wc, const float *bias, const void *W4, const float *b4, float *pts,
+                   float *conf, const void *zero16, int B, int H, int W, int upsample, int dtype, void *stream) {
+    M3_REQUIRE(X && Wc && W4 && b4 && pts && conf && zero16 && B > 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0);
+    M3_REQUIRE((dtype == DT_BF16 || dtype == DT_F16) && (!upsample || (H % 2 == 0 && W % 2 == 0)));
+    M3_REQUIRE((int64_t)B * H * W < (1ll << 31));
+    TailArgs a;
+    a.X = (const bf16_t *)X; a.Wc = (const bf16_t *)Wc; a.bias = bias; a.W4 = (const bf16_t *)W4; a.b4 = b4;
+    a.pts = pts; a.conf = conf; a.zero16 = (const bf16_t *)zero16; a.B = B; a.H = H; a.W = W;
+    a.IH = upsample ? H / 2 : H; a.IW = upsample ? W / 2 : W;
+    const dim3 grid((unsigned)((H / TH) * ((W + TW - 1) / TW) * B)), blk(kThreads);
+    hipStream_t st = (hipStream_t)stream;
+#define M3_TAIL(DTV, UP)                                                                                         \
+    do {                                                                                                         \
+        static bool attr_set = false;                                                                            \
+        if (!attr_set) {                                                                                         \
+            M3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_tail<DTV, UP>),              \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes), "m3_dpt_tail/attr"); \
+            attr_set = true;                                                                                     \
+        }                                                                                                        \
+        hipLaunchKernelGGL((k_conv_tail<DTV, UP>), grid, blk, kLdsBytes, st, a);                                 \
+    } while (0)
+    if (dtype == DT_F16) { if (upsample) M3_TAIL(DT_F16, true); else M3_TAIL(DT_F16, false); }
+    else { if (upsample) M3_TAIL(DT_BF16, true); else M3_TAIL(DT_BF16, false); }
+#undef M3_TAIL
+    M3_CHECK_LAUNCH("m3_dpt_tail");
+    return M3_OK;
+}
+
+}  // extern "C"

@@ -452,12 +452,14 @@ class Mast3rFull:
         path = self._fusion(p + ".scratch.refinenet3", path, rn[2])
         path = self._fusion(p + ".scratch.refinenet2", path, rn[1])
         path = self._fusion(p + ".scratch.refinenet1", path, rn[0])
-        h0 = ops.upsample2x(ops.conv3x3(path, P[p + ".head.0.w"], P[p + ".head.0.b"], ops.EPI_BF16))
+        h0 = ops.conv3x3(path, P[p + ".head.0.w"], P[p + ".head.0.b"], ops.EPI_BF16)
         ch = P[p + ".head.2.w"].shape[0]
-        if ch == 128 and P[p + ".head.4.w"].shape == (4, 128):
-            # head.2 conv + ReLU, head.4 1x1 and the pointmap post-processing in one launch
-            pts, conf = ops.conv3x3_relu_head4(h0, P[p + ".head.2.w"], P[p + ".head.2.b"], P[p + ".head.4.w"], P[p + ".head.4.b"])
+        if ch == 128 and h0.shape[-1] == 128 and P[p + ".head.4.w"].shape == (4, 128):
+            # x2 upsample + head.2 conv + ReLU + head.4 1x1 + pointmap post-processing in ONE direct-convolution launch:
+            # the full-resolution 128-channel map (537 MB per head at 8 pairs) is never written or read
+            pts, conf = ops.dpt_tail(h0, P[p + ".head.2.w"], P[p + ".head.2.b"], P[p + ".head.4.w"], P[p + ".head.4.b"], upsample=True)
         else:
+            h0 = ops.upsample2x(h0)
             h2 = ops.conv3x3(h0, P[p + ".head.2.w"], P[p + ".head.2.b"], ops.EPI_BF16_RELU)
             b, h, w, ch = h2.shape
             raw = ops.gemm(h2.view(-1, ch), P[p + ".head.4.w"], P[p + ".head.4.b"], ops.EPI_F32)

@@ -48,11 +48,16 @@ def _gemm_kind(m, n, groups=1):
     return "gemm256" if int(_ffi.lib().m3_gemm_pick_tile(m, n, groups)) >= 192 else "gemm_small"
 
 
-def _prof_end(e0, kind, flops, nbytes=0.0):
+PROFILE_SHAPES = None      # optional list: (kind, description) per profiled launch, same order as PROFILE
+
+
+def _prof_end(e0, kind, flops, nbytes=0.0, desc=""):
     if e0 is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         PROFILE.append((kind, flops, e0, e1, nbytes))
+        if PROFILE_SHAPES is not None:
+            PROFILE_SHAPES.append((kind, desc))
 
 
 def zero_page(dev):
@@ -88,7 +93,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, epi: int = EPI_BF16, out=N
     _ffi.call("m3_gemm_dt", _ffi.ptr(a), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(out), _ffi.ptr(resid),
               m, n, k, ldc, epi, dt, _ffi.stream_ptr())
     esz = out.element_size()
-    _prof_end(e0, _gemm_kind(m, n), 2.0 * m * n * k, 2.0 * (m * k + n * k) + esz * m * n * (1 if resid is None else 2))
+    _prof_end(e0, _gemm_kind(m, n), 2.0 * m * n * k, 2.0 * (m * k + n * k) + esz * m * n * (1 if resid is None else 2),
+              f"gemm {m}x{n}x{k} epi{epi} {a.dtype}")
     return out
 
 
@@ -141,7 +147,8 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, epi: int = EPI_BF16, st
               _ffi.ptr(zero_page(x.device)), b, h, wd, cin, cout, stride, epi, _ffi.ptr(ws), ws_bytes, dt,
               _ffi.stream_ptr())
     _prof_end(e0, "conv3x3", 2.0 * b * oh * ow * cout * 9 * cin,
-              2.0 * (b * h * wd * cin + cout * 9 * cin) + out.element_size() * b * oh * ow * cout * (1 if resid is None else 2))
+              2.0 * (b * h * wd * cin + cout * 9 * cin) + out.element_size() * b * oh * ow * cout * (1 if resid is None else 2),
+              f"conv3x3 {b}x{h}x{wd} {cin}->{cout} s{stride} epi{epi} splitk_ws={ws_bytes}")
     return out
 
 
@@ -161,7 +168,32 @@ def conv3x3_relu_head4(x: torch.Tensor, w: torch.Tensor, bias, w4: torch.Tensor,
     e0 = _prof_begin()
     _ffi.call("m3_conv3x3_relu_head4_dt", _ffi.ptr(x), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(w4), _ffi.ptr(b4),
               _ffi.ptr(pts), _ffi.ptr(conf), _ffi.ptr(zero_page(x.device)), b, h, wd, cin, dt, _ffi.stream_ptr())
-    _prof_end(e0, "conv3x3", 2.0 * b * h * wd * 128 * (9 * cin + 4), 2.0 * (b * h * wd * cin + 128 * 9 * cin) + 16.0 * b * h * wd)
+    _prof_end(e0, "conv3x3", 2.0 * b * h * wd * 128 * (9 * cin + 4), 2.0 * (b * h * wd * cin + 128 * 9 * cin) + 16.0 * b * h * wd,
+              f"conv3x3+head4 {b}x{h}x{wd} {cin}->128->4")
+    return pts, conf
+
+
+def dpt_tail(x: torch.Tensor, w: torch.Tensor, bias, w4: torch.Tensor, b4: torch.Tensor, upsample: bool = True):
+    """DPT tail as one direct-convolution launch: [x2 bilinear upsample of x] -> conv3x3 128->128 + ReLU -> 1x1 -> 4
+    -> (pts3d [B,H,W,3], conf [B,H,W]) f32.  x NHWC [B,H/2,W/2,128] (upsample) or [B,H,W,128]; 16-bit dtype."""
+    x = _ffi.check(x, H16, "x")
+    b, ih, iw, cin = x.shape
+    if cin != 128:
+        raise ValueError(f"dpt_tail needs 128 input channels, got {cin}")
+    w = _ffi.check(w, H16, "w", (128, 3, 3, 128))
+    w4 = _ffi.check(w4, H16, "w4", (4, 128))
+    b4 = _ffi.check(b4, torch.float32, "b4", (4,))
+    dt = _same16(x, w, w4)
+    if bias is not None:
+        bias = _ffi.check(bias, torch.float32, "bias", (128,))
+    h, wd = (2 * ih, 2 * iw) if upsample else (ih, iw)
+    pts = torch.empty((b, h, wd, 3), dtype=torch.float32, device=x.device)
+    conf = torch.empty((b, h, wd), dtype=torch.float32, device=x.device)
+    e0 = _prof_begin()
+    _ffi.call("m3_dpt_tail_dt", _ffi.ptr(x), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(w4), _ffi.ptr(b4), _ffi.ptr(pts),
+              _ffi.ptr(conf), _ffi.ptr(zero_page(x.device)), b, h, wd, 1 if upsample else 0, dt, _ffi.stream_ptr())
+    _prof_end(e0, "conv_tail", 2.0 * b * h * wd * 128 * (9 * 128 + 4), 2.0 * (b * ih * iw * 128 + 128 * 9 * 128) + 16.0 * b * h * wd,
+              f"dpt_tail {b}x{h}x{wd} 128->128->4 upsample={upsample}")
     return pts, conf
 
 

@@ -485,3 +485,37 @@ def test_small_tile_gemm_is_race_free_at_high_occupancy(dev, shape):
         out = ops.gemm(a, w, b, ops.EPI_BF16)
         bad = int((out != want).sum())
         assert bad == 0, f"launch {run}: {bad} elements differ"
+
+
+@pytest.mark.parametrize("dt", DT16)
+@pytest.mark.parametrize("upsample", [False, True])
+@pytest.mark.parametrize("bhw", [(2, 32, 48), (1, 64, 64), (3, 16, 16), (1, 48, 80)])
+def test_dpt_tail_direct_convolution(dev, dt, upsample, bhw):
+    """m3_dpt_tail_dt (x2 upsample fused into the LDS halo staging + conv3x3 + ReLU + 1x1 + pointmap post-processing)
+    against the separate operators (k_upsample2x -> m3_conv3x3_relu_head4: same 16-bit rounding of the upsampled map,
+    fp32 summation order differs) and against a plain torch fp32 chain."""
+    b, h, w = bhw                                                     # OUTPUT size
+    g = torch.Generator(device="cpu").manual_seed(h * 7 + w + int(upsample))
+    ih, iw = (h // 2, w // 2) if upsample else (h, w)
+    x = torch.randn(b, ih, iw, 128, generator=g).to(dt)
+    wc = (torch.randn(128, 3, 3, 128, generator=g) * 0.03).to(dt)
+    bc = torch.randn(128, generator=g) * 0.1
+    w4 = (torch.randn(4, 128, generator=g) * 0.05).to(dt)
+    b4 = torch.randn(4, generator=g) * 0.1
+    d = lambda t: t.to(dev)
+    pts, conf = ops.dpt_tail(d(x), d(wc), d(bc), d(w4), d(b4), upsample=upsample)
+    assert pts.shape == (b, h, w, 3) and conf.shape == (b, h, w)
+    xu = ops.upsample2x(d(x)) if upsample else d(x)
+    pts_u, conf_u = ops.conv3x3_relu_head4(xu, d(wc), d(bc), d(w4), d(b4))
+    # same arithmetic; with the upsample, FMA contraction may round a few interpolated values to the neighbouring 16-bit number
+    tol_u = 0.2 * TOL16[dt] if upsample else 5e-6
+    assert _rel(pts, pts_u) < tol_u and _rel(conf, conf_u) < tol_u
+    xf = x.float().permute(0, 3, 1, 2)
+    if upsample:
+        xf = F.interpolate(xf, scale_factor=2, mode="bilinear", align_corners=True)
+    y = torch.relu(F.conv2d(xf, wc.float().permute(0, 3, 1, 2), bc, padding=1)).permute(0, 2, 3, 1)
+    r = y @ w4.float().T + b4
+    dn = r[..., :3].norm(dim=-1, keepdim=True)
+    tol = 5e-6 if not upsample else TOL16[dt]                          # the interpolated map is rounded to 16 bits once
+    assert _rel(pts, r[..., :3] / dn.clip(min=1e-8) * torch.expm1(dn)) < tol
+    assert _rel(conf, 1 + torch.exp(r[..., 3])) < tol

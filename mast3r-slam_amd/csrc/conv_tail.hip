@@ -14,8 +14,8 @@
 // Workgroup = 512 threads = 8 waves on a 16 (rows) x 32 (pixels) output tile: wave (wp, wc) owns rows 4wp..4wp+3
 // (8 MFMA row tiles of 16 pixels) x output channels 64wc..64wc+63 (4 column tiles) = 32 accumulator tiles, the
 // 256 x 256 GEMM tile's shape (24 ds_read_b128 per 64 MFMAs).  The 128 input channels are processed as two halves:
-// per half, the 18 x 34 x 64-channel halo (78 KiB, 128-byte pixel rows with the GEMM kernels' bank-conflict-free
-// XOR swizzle) is staged once, then nine taps x 64 channels of weights (16 KiB each, double-buffered LDS-DMA) are
+// per half, the 18 x 34 x 64-channel halo (78 KiB, 128-byte pixel rows, 16-byte chunks XOR-swizzled by the halo
+// column) is staged once, then nine taps x 64 channels of weights (16 KiB each, double-buffered LDS-DMA) are
 // multiplied from LDS.  Weights streamed per workgroup: 288 KiB per 512 pixels (a 16 x 16 tile version streamed
 // them per 256 pixels and was bound by exactly that L2 -> LDS traffic: 2.4 GB per launch, 913 us).
 #include "gemm_common.h"
@@ -92,7 +92,7 @@ k_conv_tail(const TailArgs a) {
             const int pix = slot >> 3, cp = slot & 7;
             const int hy = pix / HW, hx = pix - hy * HW;
             const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
-            const int c = half * 8 + (cp ^ ((pix >> 1) & 7));
+            const int c = half * 8 + (cp ^ ((hx >> 1) & 7));
             const bool in = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             const void *src = in ? (const void *)(img + ((size_t)iy * a.IW + ix) * 128 + c * 8) : (const void *)a.zero16;
             // the last wave-instruction is half full: its upper 32 lanes would land in the weight stage - use a plain store
@@ -105,7 +105,7 @@ k_conv_tail(const TailArgs a) {
             const int pix = slot >> 3, cp = slot & 7;
             const int hy = pix / HW, hx = pix - hy * HW;
             const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
-            const int c = cp ^ ((pix >> 1) & 7);
+            const int c = cp ^ ((hx >> 1) & 7);
             uint4 o = make_uint4(0u, 0u, 0u, 0u);
             if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
                 const float fy = iy * sy, fx = ix * sx;
@@ -154,18 +154,30 @@ k_conv_tail(const TailArgs a) {
     // 18 us of MFMA issue).
     const int group = wave >> 2;
     bf16x8 af[8], wf[4];
+    // halo fragment addresses: the swizzle depends on the halo COLUMN only (chunk' = chunk ^ ((hx >> 1) & 7)), so the
+    // per-lane part is one of six column offsets (kx = 0..2, left / right 16-pixel tile) and the rest is uniform:
+    // 12 address instructions per read phase (a per-pixel swizzle cost ~100, as much VALU time as the MFMAs took)
+    int colofs[3][2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int hx = h2 * 16 + frow + kx;
+            colofs[kx][h2] = hx * 128 + ((fch ^ ((hx >> 1) & 7)) << 4);
+        }
     auto read_frags = [&](int g, int ks) {
         const int tap = g >= 9 ? g - 9 : g;
         const int ky = tap / 3, kx = tap - ky * 3;
         const unsigned char *wsrc = wst + (g & 1) * kWStage;
         const int flip = ks << 6;
+        const int c0 = (kx == 0 ? colofs[0][0] : kx == 1 ? colofs[1][0] : colofs[2][0]) ^ flip;
+        const int c1 = (kx == 0 ? colofs[0][1] : kx == 1 ? colofs[1][1] : colofs[2][1]) ^ flip;
+        const unsigned char *rowp = halo + (wp * 4 + ky) * (HW * 128);
 #pragma unroll
         for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8 *>(wsrc + (w_off[j] ^ flip));
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int pix = (wp * 4 + (i >> 1) + ky) * HW + (i & 1) * 16 + frow + kx;
-            af[i] = *reinterpret_cast<const bf16x8 *>(halo + ((pix * 128 + ((fch ^ ((pix >> 1) & 7)) << 4)) ^ flip));
-        }
+        for (int i = 0; i < 8; ++i)
+            af[i] = *reinterpret_cast<const bf16x8 *>(rowp + (i >> 1) * (HW * 128) + ((i & 1) ? c1 : c0));
     };
     auto mfma_all = [&]() {
         __builtin_amdgcn_s_setprio(1);

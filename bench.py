@@ -243,10 +243,8 @@ def main():
     _ffi.PROFILE = {}
     _ffi.PROFILE_NAMES = ("m3_prep_iter_proj", "m3_iter_proj", "m3_refine_matches", "m3_match_epilogue",
                           "m3_track_gather_batch", "m3_track_gn_ray_dist_batch")
-    conc, net.concurrent_heads = net.concurrent_heads, False      # per-launch timing wants the launches serialised
-    leg_infer(); i2, v2 = leg_match(); leg_gn(i2, v2)
+    leg_infer(); i2, v2 = leg_match(); leg_gn(i2, v2)           # single stream: the launches are serialised
     torch.cuda.synchronize()
-    net.concurrent_heads = conc
     prof, ops.PROFILE = ops.PROFILE, None
     cprof, _ffi.PROFILE = _ffi.PROFILE, None
     by_kind = {}

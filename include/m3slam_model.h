@@ -75,6 +75,13 @@ int m3_gemm_grouped2_dt(const void *A, const void *W0, const void *W1, const flo
 /* 3x3 convolution, padding 1, stride 1 or 2, as an implicit GEMM: X bf16 NHWC [B,H,W,Cin],
  * W bf16 [Cout,3,3,Cin], Y NHWC [B,OH,OW,Cout].  Cin % 64 == 0, Cout % 4 == 0.  zero16: 16
  * zero bytes in device memory (source of the padding taps). */
+/* Two same-shape convolutions in one launch (the two DPT heads): X [2,B,H,W,Cin], Y / R [2,B,OH,OW,Cout], group g
+ * uses (W_g, bias_g).  Split-K scratch: 2 x m3_conv3x3_splitk_bytes(B, ...). */
+int m3_conv3x3_grouped2_dt(const void *X, const void *W0, const void *W1, const float *bias0, const float *bias1,
+                           void *Y, const void *R, const void *zero16, int B, int H, int Wd, int Cin, int Cout,
+                           int stride, int epilogue, void *splitk_ws, int64_t splitk_ws_bytes, int dtype,
+                           void *stream);
+
 /* Split-K scratch of m3_conv3x3_bf16: small feature maps with a long K (the 16x16 / 32x32 DPT maps,
  * K = 9*Cin up to 6912) cannot fill the chip with output tiles, so they are multiplied in K-slices
  * into fp32 partial planes which a second kernel sums in a fixed order before applying the epilogue.
@@ -110,6 +117,12 @@ int m3_conv3x3_relu_head4_dt(const void *X, const void *W, const float *bias, co
 int m3_dpt_tail_dt(const void *X, const void *W, const float *bias, const void *W4, const float *b4,
                    float *pts, float *conf, const void *zero16, int B, int H, int Wd, int upsample,
                    int dtype, void *stream);
+
+/* m3_dpt_tail_dt for both heads in one launch: X [2,B,h,w,128], pts [2,B,H,W,3], conf [2,B,H,W]. */
+int m3_dpt_tail_grouped2_dt(const void *X, const void *Wc0, const void *Wc1, const float *bias0, const float *bias1,
+                            const void *W40, const void *W41, const float *b40, const float *b41, float *pts,
+                            float *conf, const void *zero16, int B, int H, int Wd, int upsample, int dtype,
+                            void *stream);
 
 /* Fused multi-head attention, head dim 64: O = softmax(scale * Q K^T) V, bf16 in/out, fp32
  * softmax.  Q/K/V/O are addressed as base + batch*batch_stride + token*row_stride + head*64

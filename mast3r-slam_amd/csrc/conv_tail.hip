@@ -43,11 +43,21 @@ struct TailArgs {
     float *pts, *conf;      // [B,H,W,3], [B,H,W]
     const bf16_t *zero16;
     int B, H, W, IH, IW;
+    // second head (blockIdx.y = 1): its own weights; X / pts / conf advance by one head's extent
+    const bf16_t *Wc2, *W42;
+    const float *bias2, *b42;
 };
 
 template <int DT, bool UPS>
 __global__ void __launch_bounds__(kThreads, 2)
-k_conv_tail(const TailArgs a) {
+k_conv_tail(const TailArgs ain) {
+    TailArgs a = ain;
+    if (blockIdx.y == 1) {
+        a.Wc = ain.Wc2; a.W4 = ain.W42; a.bias = ain.bias2; a.b4 = ain.b42;
+        a.X = ain.X + (size_t)ain.B * ain.IH * ain.IW * 128;
+        a.pts = ain.pts + (size_t)ain.B * ain.H * ain.W * 3;
+        a.conf = ain.conf + (size_t)ain.B * ain.H * ain.W;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char *halo = lds, *wst = lds + kHaloBytes, *patch = lds + kHaloBytes + 2 * kWStage;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -322,16 +332,20 @@ extern "C" {
 
 // X: NHWC [B, H/2, W/2, 128] when upsample != 0 (the x2 bilinear, align_corners upsampling is done on the fly),
 // else [B, H, W, 128].  H, W multiples of 16.
-int m3_dpt_tail_dt(const void *X, const void *Wc, const float *bias, const void *W4, const float *b4, float *pts,
-                   float *conf, const void *zero16, int B, int H, int W, int upsample, int dtype, void *stream) {
+static int dpt_tail_launch(const void *X, const void *Wc, const float *bias, const void *W4, const float *b4,
+                           const void *Wc2, const float *bias2, const void *W42, const float *b42, float *pts,
+                           float *conf, const void *zero16, int B, int H, int W, int upsample, int dtype, void *stream) {
+    const int groups = Wc2 ? 2 : 1;
     M3_REQUIRE(X && Wc && W4 && b4 && pts && conf && zero16 && B > 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0);
+    M3_REQUIRE(groups == 1 || (W42 && b42 && (bias == nullptr) == (bias2 == nullptr)));
     M3_REQUIRE((dtype == DT_BF16 || dtype == DT_F16) && (!upsample || (H % 2 == 0 && W % 2 == 0)));
-    M3_REQUIRE((int64_t)B * H * W < (1ll << 31));
+    M3_REQUIRE((int64_t)groups * B * H * W < (1ll << 31));
     TailArgs a;
+    a.Wc2 = (const bf16_t *)Wc2; a.W42 = (const bf16_t *)W42; a.bias2 = bias2; a.b42 = b42;
     a.X = (const bf16_t *)X; a.Wc = (const bf16_t *)Wc; a.bias = bias; a.W4 = (const bf16_t *)W4; a.b4 = b4;
     a.pts = pts; a.conf = conf; a.zero16 = (const bf16_t *)zero16; a.B = B; a.H = H; a.W = W;
     a.IH = upsample ? H / 2 : H; a.IW = upsample ? W / 2 : W;
-    const dim3 grid((unsigned)((H / TH) * ((W + TW - 1) / TW) * B)), blk(kThreads);
+    const dim3 grid((unsigned)((H / TH) * ((W + TW - 1) / TW) * B), groups), blk(kThreads);
     hipStream_t st = (hipStream_t)stream;
 #define M3_TAIL(DTV, UP)                                                                                         \
     do {                                                                                                         \
@@ -348,6 +362,21 @@ int m3_dpt_tail_dt(const void *X, const void *Wc, const float *bias, const void 
 #undef M3_TAIL
     M3_CHECK_LAUNCH("m3_dpt_tail");
     return M3_OK;
+}
+
+int m3_dpt_tail_dt(const void *X, const void *Wc, const float *bias, const void *W4, const float *b4, float *pts,
+                   float *conf, const void *zero16, int B, int H, int W, int upsample, int dtype, void *stream) {
+    return dpt_tail_launch(X, Wc, bias, W4, b4, nullptr, nullptr, nullptr, nullptr, pts, conf, zero16, B, H, W, upsample,
+                           dtype, stream);
+}
+
+// Both heads in one launch: X [2,B,h,w,128], pts [2,B,H,W,3], conf [2,B,H,W]; head g uses (Wc_g, bias_g, W4_g, b4_g).
+int m3_dpt_tail_grouped2_dt(const void *X, const void *Wc0, const void *Wc1, const float *bias0, const float *bias1,
+                            const void *W40, const void *W41, const float *b40, const float *b41, float *pts,
+                            float *conf, const void *zero16, int B, int H, int W, int upsample, int dtype, void *stream) {
+    M3_REQUIRE(Wc1 != nullptr);
+    return dpt_tail_launch(X, Wc0, bias0, W40, b40, Wc1, bias1, W41, b41, pts, conf, zero16, B, H, W, upsample, dtype,
+                           stream);
 }
 
 }  // extern "C"

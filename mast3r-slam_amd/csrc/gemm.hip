@@ -289,7 +289,9 @@ int pick_splits(int pix_per_image, int N, int K) {
 
 template <int EPI, int DT>
 __global__ void __launch_bounds__(256)
-k_splitk_finish(const GemmArgs g, const float *__restrict__ part, int S) {
+k_splitk_finish(const GemmArgs gin, const float *__restrict__ part, int S) {
+    const GemmArgs g = select_group<EPI>(gin, blockIdx.y);
+    part += (size_t)blockIdx.y * S * gin.M * gin.N;            // partial planes are laid out [group][slice][M][N]
     const int nq = g.N / 4;
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
     const int m = (int)(q / nq), n = (int)(q - (long)m * nq) * 4;
@@ -307,10 +309,11 @@ k_splitk_finish(const GemmArgs g, const float *__restrict__ part, int S) {
 template <int MODE>
 int run_split(const GemmArgs &a, int S, int epi, void *ws, hipStream_t st) {
     GemmArgs p = a;
-    p.C = ws; p.ldc = a.N; p.bias = nullptr; p.R = nullptr; p.splits = S;
+    p.C = ws; p.ldc = a.N; p.bias = nullptr; p.bias2 = nullptr; p.R = nullptr; p.splits = S;
+    p.c_gstride = (long long)S * a.M * a.N;                     // group 1's planes follow group 0's S planes
     const int rc = launch<MODE>(p, EPI_F32, st);
     if (rc != M3_OK) return rc;
-    const dim3 grid((unsigned)m3_cdiv((long)a.M * (a.N / 4), 256L));
+    const dim3 grid((unsigned)m3_cdiv((long)a.M * (a.N / 4), 256L), a.groups > 1 ? a.groups : 1);
 #define M3_F(E) case E:                                                                                        \
         if (a.dt == DT_F16) hipLaunchKernelGGL((k_splitk_finish<E, DT_F16>), grid, dim3(256), 0, st, a, (const float *)ws, S); \
         else hipLaunchKernelGGL((k_splitk_finish<E, DT_BF16>), grid, dim3(256), 0, st, a, (const float *)ws, S);      \
@@ -433,6 +436,32 @@ int m3_conv3x3_dt(const void *X, const void *W, const float *bias, void *Y, cons
         return run_split<1>(a, S, epilogue, splitk_ws, (hipStream_t)stream);
     }
     if (use_256(a.M, a.N)) return m3_launch_gemm256_conv(a, epilogue, (hipStream_t)stream);
+    return launch<1>(a, epilogue, (hipStream_t)stream);
+}
+
+// Two convolutions of identical shape in one launch (the two DPT heads: same maps, different weights):
+// X [2,B,H,W,Cin], W0 / W1, bias0 / bias1, Y (and R) [2,B,OH,OW,Cout].  Split-K scratch: twice m3_conv3x3_splitk_bytes.
+int m3_conv3x3_grouped2_dt(const void *X, const void *W0, const void *W1, const float *bias0, const float *bias1,
+                           void *Y, const void *R, const void *zero16, int B, int H, int Wd, int Cin, int Cout,
+                           int stride, int epilogue, void *splitk_ws, int64_t splitk_ws_bytes, int dtype, void *stream) {
+    M3_REQUIRE(X && W0 && W1 && Y && zero16 && B > 0 && H > 0 && Wd > 0 && Cin > 0 && Cout > 0 && dt_ok(dtype));
+    M3_REQUIRE(Cin % BK == 0 && Cout % 4 == 0 && (stride == 1 || stride == 2) && epilogue != EPI_BF16_ROPE);
+    M3_REQUIRE(!((epilogue == EPI_F32_ACCUM || epilogue == EPI_BF16_ADD) && !R));
+    M3_REQUIRE((bias0 == nullptr) == (bias1 == nullptr));
+    GemmArgs a{};
+    a.A = (const bf16_t *)X; a.W = (const bf16_t *)W0; a.W2 = (const bf16_t *)W1; a.bias = bias0; a.bias2 = bias1;
+    a.C = Y; a.R = R; a.zero16 = (const bf16_t *)zero16;
+    a.H = H; a.Wd = Wd; a.Cin = Cin; a.stride = stride;
+    a.OH = (H + 2 - 3) / stride + 1; a.OW = (Wd + 2 - 3) / stride + 1;
+    a.M = B * a.OH * a.OW; a.N = Cout; a.K = 9 * Cin; a.ldc = Cout; a.dt = dtype;
+    a.groups = 2; a.a_gstride = (long long)B * H * Wd * Cin; a.c_gstride = (long long)a.M * Cout;
+    const int S = pick_splits(a.OH * a.OW, Cout, a.K);
+    if (S > 1) {
+        M3_REQUIRE(splitk_ws && (reinterpret_cast<size_t>(splitk_ws) & 15) == 0 &&
+                   splitk_ws_bytes >= 2 * (int64_t)S * a.M * a.N * 4);
+        return run_split<1>(a, S, epilogue, splitk_ws, (hipStream_t)stream);
+    }
+    if (use_256(a.M, a.N, 2)) return m3_launch_gemm256_conv(a, epilogue, (hipStream_t)stream);
     return launch<1>(a, epilogue, (hipStream_t)stream);
 }
 

@@ -185,8 +185,6 @@ class Mast3rFull:
         self.host_weights = weights if weights is not None else init_random_weights(self.cfg, seed)
         self._prepare(self.host_weights)
         self._rope_cache = {}
-        self.concurrent_heads = os.environ.get("M3_CONCURRENT_HEADS", "1") != "0"
-        self._side = None
 
     @classmethod
     def from_pretrained(cls, resolution: int = 512, precision: str = "bf16", weights_path: Optional[str] = None,
@@ -472,6 +470,67 @@ class Mast3rFull:
         desc, dconf = ops.desc_post(f, npairs, gh * 16, gw * 16)
         return dict(pts3d=pts, conf=conf, desc=desc, desc_conf=dconf)
 
+    # ------------------------------------------------------------------ both heads as 2-group launches
+    def _rcu2(self, x, q):
+        P, h1, h2 = self.P, "downstream_head1", "downstream_head2"
+        W = lambda s: (P[h1 + q + s], P[h2 + q + s])
+        c1 = ops.conv3x3_grouped2(ops.relu(x), *W(".conv1.w"), *W(".conv1.b"), ops.EPI_BF16_RELU)
+        return ops.conv3x3_grouped2(c1, *W(".conv2.w"), *W(".conv2.b"), ops.EPI_BF16_ADD, resid=x)
+
+    def _fusion2(self, q, x0, x1=None):
+        P, h1, h2 = self.P, "downstream_head1", "downstream_head2"
+        out = x0 if x1 is None else ops.add(x0, self._rcu2(x1, q + ".resConfUnit1"))
+        out = self._rcu2(out, q + ".resConfUnit2")
+        g, b, h, w, ch = out.shape
+        out = ops.gemm_grouped2(out.view(2, -1, ch), P[h1 + q + ".out_conv.w"], P[h2 + q + ".out_conv.w"],
+                                P[h1 + q + ".out_conv.b"], P[h2 + q + ".out_conv.b"], ops.EPI_BF16)
+        return ops.upsample2x(out.view(2 * b, h, w, -1)).view(2, b, 2 * h, 2 * w, -1)
+
+    def heads(self, taps1, taps2, npairs: int, grid):
+        """Both heads (DPT + local features) with every operator as ONE 2-group launch (blockIdx.y = head: same
+        shapes, different weights) - the form the decoder already uses.  No side stream: a stream fork here was a
+        second-level fork whenever the caller captured on a forked stream, which segfaults inside ROCm 7.2
+        (tools/incident_r01/nested_capture.py), and the small maps now fill twice the CUs.
+        taps*: 4 tensors [P*T,C] each (head 16-bit type).  Returns (out1, out2) dicts as `head`."""
+        P, c = self.P, self.cfg
+        gh, gw = grid
+        m = npairs * gh * gw
+        h1, h2 = "downstream_head1", "downstream_head2"
+        d = ".dpt"
+        ld = c["layer_dims"]
+        dev = taps1[0].device
+        W = lambda s: (P[h1 + s], P[h2 + s])
+        T = [torch.stack([a, b]) for a, b in zip(taps1, taps2)]                       # [2, M, C]
+        gem = lambda x, s, epi=ops.EPI_BF16, out=None: ops.gemm_grouped2(x, *W(s + ".w"), *W(s + ".b"), epi, out=out)
+        k0, k1 = _ceil64(ld[0]), _ceil64(ld[1])
+        t0 = gem(T[0], d + ".act_postprocess.0.0", out=torch.zeros((2, m, k0), dtype=self.hdt, device=dev) if k0 != ld[0] else None)
+        u0 = gem(t0, d + ".act_postprocess.0.1")
+        l0 = ops.unshuffle(u0.view(2 * m, -1), 2 * npairs, gh, gw, 4, ld[0], k0).view(2, npairs, 4 * gh, 4 * gw, k0)
+        t1 = gem(T[1], d + ".act_postprocess.1.0", out=torch.zeros((2, m, k1), dtype=self.hdt, device=dev) if k1 != ld[1] else None)
+        u1 = gem(t1, d + ".act_postprocess.1.1")
+        l1 = ops.unshuffle(u1.view(2 * m, -1), 2 * npairs, gh, gw, 2, ld[1], k1).view(2, npairs, 2 * gh, 2 * gw, k1)
+        l2 = gem(T[2], d + ".act_postprocess.2.0").view(2, npairs, gh, gw, ld[2])
+        t3 = gem(T[3], d + ".act_postprocess.3.0").view(2, npairs, gh, gw, ld[3])
+        l3 = ops.conv3x3_grouped2(t3, *W(d + ".act_postprocess.3.1.w"), *W(d + ".act_postprocess.3.1.b"), ops.EPI_BF16, stride=2)
+        rn = [ops.conv3x3_grouped2(l, *W(d + f".scratch.layer_rn.{i}.w"), None, None, ops.EPI_BF16)
+              for i, l in enumerate((l0, l1, l2, l3))]
+        path = self._fusion2(d + ".scratch.refinenet4", rn[3])
+        if path.shape[2:4] != rn[2].shape[2:4]:                                          # odd token grids, see `head`
+            path = path[:, :, :rn[2].shape[2], :rn[2].shape[3]].contiguous()
+        path = self._fusion2(d + ".scratch.refinenet3", path, rn[2])
+        path = self._fusion2(d + ".scratch.refinenet2", path, rn[1])
+        path = self._fusion2(d + ".scratch.refinenet1", path, rn[0])
+        h0 = ops.conv3x3_grouped2(path, *W(d + ".head.0.w"), *W(d + ".head.0.b"), ops.EPI_BF16)
+        pts, conf = ops.dpt_tail_grouped2(h0, *W(d + ".head.2.w"), *W(d + ".head.2.b"), *W(d + ".head.4.w"), *W(d + ".head.4.b"),
+                                          upsample=True)
+        q = ".head_local_features"
+        cat = ops.concat2(T[0].view(2 * m, -1), T[3].view(2 * m, -1)).view(2, m, -1)
+        f = gem(gem(cat, q + ".fc1", ops.EPI_BF16_GELU), q + ".fc2")
+        desc, dconf = ops.desc_post(f.view(2 * m, -1), 2 * npairs, gh * 16, gw * 16)
+        H, Wd = gh * 16, gw * 16
+        desc, dconf = desc.view(2, npairs, H, Wd, 24), dconf.view(2, npairs, H, Wd)
+        return tuple(dict(pts3d=pts[v], conf=conf[v], desc=desc[v], desc_conf=dconf[v]) for v in range(2))
+
     # ------------------------------------------------------------------ public two-view API
     def reconstruct_batch(self, imgs1: torch.Tensor, imgs2: torch.Tensor):
         """P pairs at once: uint8 [P,H,W,3] x2 -> (out1, out2), dicts with a leading pair axis.
@@ -487,28 +546,14 @@ class Mast3rFull:
     def decode_heads(self, f1, f2, npairs, grid):
         """Decoder + both heads from cached encoder tokens (bf16 [P*T,1024] each)."""
         taps = self.decode_tokens(f1.reshape(-1, self.embed_dim), f2.reshape(-1, self.embed_dim), npairs, grid)
-        if not self.concurrent_heads:
-            return (self.head("downstream_head1", taps[0], npairs, grid),
-                    self.head("downstream_head2", taps[1], npairs, grid))
-        # The two heads are independent chains with many small-map kernels that cannot fill 256 CUs on
-        # their own: fork head 2 onto a side stream (a parallel branch when the step is graph-captured).
-        # Known limit (ROCm 7.2): ending a graph capture in which the CALLER has itself forked streams around
-        # this call crashes inside hipStreamEndCapture - set `concurrent_heads = False` for such captures.
-        main = torch.cuda.current_stream()
-        if self._side is None:
-            self._side = {}
-        side = self._side.get(main.cuda_stream)            # one side stream per caller stream: independent
-        if side is None:                                    # callers (e.g. two pipelined batches) never share one
-            side = self._side[main.cuda_stream] = torch.cuda.Stream(device=self.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            o2 = self.head("downstream_head2", taps[1], npairs, grid)
-        o1 = self.head("downstream_head1", taps[0], npairs, grid)
-        main.wait_stream(side)
-        if not torch.cuda.is_current_stream_capturing():   # a captured graph owns its memory pool
-            for t in o2.values():
-                t.record_stream(main)
-        return o1, o2
+        if self._grouped_heads_ok():
+            return self.heads(taps[0], taps[1], npairs, grid)
+        return (self.head("downstream_head1", taps[0], npairs, grid), self.head("downstream_head2", taps[1], npairs, grid))
+
+    def _grouped_heads_ok(self) -> bool:
+        """The 2-group head path needs the public head geometry (128-channel tail, 4 outputs)."""
+        P, p = self.P, "downstream_head1.dpt"
+        return P[p + ".head.2.w"].shape == (128, 3, 3, 128) and P[p + ".head.4.w"].shape == (4, 128)
 
     def reconstruct(self, img1, img2):
         """model.reconstruct(img1, img2) (mast3r_utils.py:281,355): uint8 [H,W,3] x2 -> two dicts with

@@ -173,6 +173,55 @@ def conv3x3_relu_head4(x: torch.Tensor, w: torch.Tensor, bias, w4: torch.Tensor,
     return pts, conf
 
 
+def conv3x3_grouped2(x, w0, w1, b0, b1, epi: int = EPI_BF16, stride: int = 1, resid=None):
+    """Two same-shape 3x3 convolutions in one launch (the two DPT heads): x NHWC [2,B,H,W,Cin], group g uses
+    (w_g [Cout,3,3,Cin], b_g) -> [2,B,OH,OW,Cout]."""
+    x = _ffi.check(x, H16, "x")
+    if x.dim() != 5 or x.shape[0] != 2:
+        raise ValueError(f"x must be [2,B,H,W,Cin], got {tuple(x.shape)}")
+    _, b, h, wd, cin = x.shape
+    w0 = _ffi.check(w0, H16, "w0", (None, 3, 3, cin))
+    w1 = _ffi.check(w1, H16, "w1", tuple(w0.shape))
+    dt = _same16(x, w0, w1)
+    cout = w0.shape[0]
+    oh, ow = (h + 2 - 3) // stride + 1, (wd + 2 - 3) // stride + 1
+    odt = torch.float32 if epi in _F32_EPIS else x.dtype
+    out = torch.empty((2, b, oh, ow, cout), dtype=odt, device=x.device)
+    if resid is not None:
+        resid = _ffi.check(resid, odt, "resid", (2, b, oh, ow, cout))
+    ws_bytes = 2 * int(_ffi.lib().m3_conv3x3_splitk_bytes(b, h, wd, cin, cout, stride))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes > 0 else None
+    e0 = _prof_begin()
+    _ffi.call("m3_conv3x3_grouped2_dt", _ffi.ptr(x), _ffi.ptr(w0), _ffi.ptr(w1), _ffi.ptr(b0), _ffi.ptr(b1), _ffi.ptr(out),
+              _ffi.ptr(resid), _ffi.ptr(zero_page(x.device)), b, h, wd, cin, cout, stride, epi, _ffi.ptr(ws), ws_bytes, dt,
+              _ffi.stream_ptr())
+    _prof_end(e0, "conv3x3", 4.0 * b * oh * ow * cout * 9 * cin,
+              2.0 * (2.0 * (b * h * wd * cin + cout * 9 * cin) + out.element_size() * b * oh * ow * cout * (1 if resid is None else 2)),
+              f"conv3x3 x2 {b}x{h}x{wd} {cin}->{cout} s{stride} epi{epi} splitk_ws={ws_bytes}")
+    return out
+
+
+def dpt_tail_grouped2(x, w0, w1, b0, b1, w40, w41, b40, b41, upsample: bool = True):
+    """dpt_tail for both heads in one launch: x [2,B,h,w,128] -> (pts [2,B,H,W,3], conf [2,B,H,W])."""
+    x = _ffi.check(x, H16, "x")
+    if x.dim() != 5 or x.shape[0] != 2 or x.shape[-1] != 128:
+        raise ValueError(f"x must be [2,B,h,w,128], got {tuple(x.shape)}")
+    _, b, ih, iw, _ = x.shape
+    ws = [_ffi.check(w, H16, "w", (128, 3, 3, 128)) for w in (w0, w1)]
+    w4s = [_ffi.check(w, H16, "w4", (4, 128)) for w in (w40, w41)]
+    dt = _same16(x, *ws, *w4s)
+    h, wd = (2 * ih, 2 * iw) if upsample else (ih, iw)
+    pts = torch.empty((2, b, h, wd, 3), dtype=torch.float32, device=x.device)
+    conf = torch.empty((2, b, h, wd), dtype=torch.float32, device=x.device)
+    e0 = _prof_begin()
+    _ffi.call("m3_dpt_tail_grouped2_dt", _ffi.ptr(x), _ffi.ptr(ws[0]), _ffi.ptr(ws[1]), _ffi.ptr(b0), _ffi.ptr(b1),
+              _ffi.ptr(w4s[0]), _ffi.ptr(w4s[1]), _ffi.ptr(b40), _ffi.ptr(b41), _ffi.ptr(pts), _ffi.ptr(conf),
+              _ffi.ptr(zero_page(x.device)), b, h, wd, 1 if upsample else 0, dt, _ffi.stream_ptr())
+    _prof_end(e0, "conv_tail", 4.0 * b * h * wd * 128 * (9 * 128 + 4), 2.0 * (2.0 * (b * ih * iw * 128 + 128 * 9 * 128) + 16.0 * b * h * wd),
+              f"dpt_tail x2 {b}x{h}x{wd} 128->128->4 upsample={upsample}")
+    return pts, conf
+
+
 def dpt_tail(x: torch.Tensor, w: torch.Tensor, bias, w4: torch.Tensor, b4: torch.Tensor, upsample: bool = True):
     """DPT tail as one direct-convolution launch: [x2 bilinear upsample of x] -> conv3x3 128->128 + ReLU -> 1x1 -> 4
     -> (pts3d [B,H,W,3], conf [B,H,W]) f32.  x NHWC [B,H/2,W/2,128] (upsample) or [B,H,W,128]; 16-bit dtype."""
@@ -336,9 +385,10 @@ def gemm_grouped2(a, w0, w1, b0, b1, epi=EPI_BF16, out=None, resid=None, rope=No
     odt = torch.float32 if epi in _F32_EPIS else a.dtype
     if out is None:
         out = torch.empty((2, m, n), dtype=odt, device=a.device)
-    elif out.dtype != odt or tuple(out.shape) != (2, m, n) or not out.is_contiguous():
+    elif out.dtype != odt or out.dim() != 3 or out.shape[0] != 2 or out.shape[1] != m or out.shape[2] < n or not out.is_contiguous():
         raise ValueError("bad `out`")
-    if resid is not None and (resid.dtype != odt or tuple(resid.shape) != (2, m, n) or not resid.is_contiguous()):
+    ldc = out.shape[2]                                           # > n: the extra columns (zero padding) are left alone
+    if resid is not None and (resid.dtype != odt or tuple(resid.shape) != tuple(out.shape) or not resid.is_contiguous()):
         raise ValueError("bad `resid`")
     rtok, rc = rope if rope is not None else (None, 0)
     tpi = 0
@@ -347,7 +397,7 @@ def gemm_grouped2(a, w0, w1, b0, b1, epi=EPI_BF16, out=None, resid=None, rope=No
         tpi = rtok.shape[0]
     e0 = _prof_begin()
     _ffi.call("m3_gemm_grouped2_dt", _ffi.ptr(a), _ffi.ptr(w0), _ffi.ptr(w1), _ffi.ptr(b0), _ffi.ptr(b1), _ffi.ptr(out),
-              _ffi.ptr(resid), m, n, k, n, m * k, m * n, epi, _ffi.ptr(rtok), tpi, rc, dt, _ffi.stream_ptr())
+              _ffi.ptr(resid), m, n, k, ldc, m * k, m * ldc, epi, _ffi.ptr(rtok), tpi, rc, dt, _ffi.stream_ptr())
     _prof_end(e0, _gemm_kind(m, n, 2), 4.0 * m * n * k,
               2.0 * (2.0 * (m * k + n * k) + out.element_size() * m * n * (1 if resid is None else 2)))
     return out

@@ -176,3 +176,37 @@ def test_symmetric_operators_against_the_oracles(tiny, dev):
     assert not np.array_equal(c(idx_i2j), c(idx_j2i))
     for got, k in ((Qii, 0), (Qjj, 2), (Qji, 1), (Qij, 3)):           # return order :533 = (Qii, Qjj, Qji, Qij)
         assert torch.equal(got, Qs[k].reshape(1, n, 1))
+
+
+def test_grouped_heads_equal_separate_heads(tiny, dev):
+    """Mast3rFull.heads (every head operator as one 2-group launch, no side stream) returns the same bits as two
+    Mast3rFull.head calls: all tile shapes accumulate K in the same order, split-K slices depend on the per-image
+    geometry only, and the grouped kernels only add a blockIdx.y -> weights / offsets selection."""
+    cfg, w, net = tiny
+    h, wd = 128, 256
+    im1, im2 = _pair(h, wd, 4)
+    tok, grid = net.encode_tokens(net._as_images(np.concatenate([im1, im2], 0)))
+    m = grid[0] * grid[1]
+    taps = net.decode_tokens(tok[:m], tok[m:], 1, grid)
+    g1, g2 = net.heads(taps[0], taps[1], 1, grid)
+    s1, s2 = net.head("downstream_head1", taps[0], 1, grid), net.head("downstream_head2", taps[1], 1, grid)
+    for g, s in ((g1, s1), (g2, s2)):
+        for k in s:
+            assert torch.equal(g[k], s[k]), k
+    # and a caller that captures on a FORKED stream (the nested-fork capture that used to need concurrent_heads=False)
+    side = torch.cuda.Stream()
+    a = torch.from_numpy(im1).to(dev); b = torch.from_numpy(im2).to(dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            o_side = net.reconstruct_batch(b, a)
+        o_main = net.reconstruct_batch(a, b)
+        cur.wait_stream(side)
+    graph.replay()
+    torch.cuda.synchronize()
+    e_main, e_side = net.reconstruct_batch(a, b), net.reconstruct_batch(b, a)
+    for v in range(2):
+        for k in e_main[v]:
+            assert torch.equal(o_main[v][k], e_main[v][k]) and torch.equal(o_side[v][k], e_side[v][k])

@@ -225,15 +225,32 @@ int m3_gn_rays_retract(float *Twc, const double *dx, const int32_t *local, int K
  * -> T <- exp(dx) T (retract_sim3, sim3_ops.py:229) for the free keyframes.
  * local int32 [K]: keyframe -> free-block index, < 0 = pinned or unused (host builds it
  * from unique(ii,jj) and pin, gauss_newton.py:73-81).  Twc is updated IN PLACE.
- * Hbuf double [dim*dim + 2*dim], dim = 7*num_free <= m3_gn_rays_max_dim().
+ * Hbuf double [m3_gn_rays_hbuf_doubles(dim)], dim = 7*num_free: ANY size - systems up to
+ * m3_gn_rays_max_dim() (448) are factored by one workgroup, larger ones (BASELINE configs[4]: 256
+ * keyframes -> 1785 unknowns) by the blocked Cholesky of gn_chol.hip; either way the loop never
+ * leaves the stream (the reference solves on the host, gauss_newton.py:253-260).
  * info double[4] = (iterations applied, last |dx|, converged/stopped flag, solver failure flag). */
 int m3_gn_rays_max_dim(void);
+int64_t m3_gn_rays_hbuf_doubles(int dim);
 int m3_gn_rays_solve(float *Twc, const float *Xs, const float *Cs, const int32_t *ii,
                      const int32_t *jj, const int32_t *idx, const uint8_t *valid, const float *Q,
                      const int32_t *local, double *blocks, double *ws, double *Hbuf, double *info,
                      int K, int P, int E, int num_free, float sigma_ray, float C_thresh,
                      float Q_thresh, int max_iter, float delta_thresh, int point_mode,
                      const float *calib, void *stream);
+
+/* One Gauss-Newton step from per-edge blocks the caller already has (the edge-sharded solve: every rank
+ * evaluated its own edges, the 36-double blocks were all-gathered): assemble -> factor -> solve -> stop test
+ * -> retract, stream-ordered, stop / failure flags on the device in info (m3_gn_rays_info_init once first). */
+int m3_gn_rays_info_init(double *info, void *stream);
+int m3_gn_rays_step(float *Twc, const double *blocks, const int32_t *ii, const int32_t *jj,
+                    const int32_t *local, double *Hbuf, double *info, int K, int E, int num_free,
+                    float delta_thresh, void *stream);
+
+/* linalg.cholesky_solve (linalg.py:17-50) for a system of any size: (H + shift I) x = b in float64 by blocked
+ * Cholesky (block 64), stream-ordered.  H [dim,dim] row-major (lower triangle read; destroyed), b [dim]
+ * (destroyed), x [dim], ws double[1 + dim]: ws[0] = 0 ok / 1 not positive definite. */
+int m3_chol_solve(double *H, double *b, double *x, double *ws, int dim, double shift, void *stream);
 
 #ifdef __cplusplus
 }

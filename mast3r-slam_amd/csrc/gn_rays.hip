@@ -13,6 +13,10 @@
 #include "common.h"
 #include "sim3_dev.h"
 
+// blocked float64 Cholesky solve (gn_chol.hip)
+int m3_chol_solve_launch(double *H, double *b, double *y, double *x, double *fail, const double *off, int dim, double shift,
+                         hipStream_t st);
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -251,6 +255,41 @@ k_gn_assemble(const double *__restrict__ blocks, const int32_t *__restrict__ ii,
     else if (t < 56 && bcol == a) g[a * 7 + (t - 49)] = gv;
 }
 
+// After the solve (dx in x[0..dim)): |dx|, largest scale step, stop test, retraction T <- exp(dx) T of the free
+// keyframes.  One workgroup; shared by the single-workgroup solver and the blocked one (gn_chol.hip).
+__device__ void gn_step_tail(double *__restrict__ x, float *__restrict__ Twc, const int32_t *__restrict__ local,
+                             double *__restrict__ info, int K, int dim, float delta_thresh, int apply) {
+    const int t = threadIdx.x;
+    __shared__ double nrm2, smax;
+    if (t == 0) {
+        double s = 0.0, m = 0.0;
+        for (int i = 0; i < dim; ++i) {
+            s += x[i] * x[i];
+            if (i % 7 == 6) m = fmax(m, fabs(x[i]));
+        }
+        nrm2 = s; smax = m;
+    }
+    __syncthreads();
+    const double dn = sqrt(nrm2);
+    if (t == 0) info[1] = dn;
+    if (!isfinite(dn) || smax > 30.0) {                     // a scale step e^sigma beyond float range (degenerate
+        if (t == 0) { info[2] = 1.0; info[3] = 1.0; }       // geometry): report failure, keep the poses
+        return;
+    }
+    if (dn < (double)delta_thresh) {                        // stop BEFORE the update (gauss_newton.py:262-265)
+        if (t == 0) info[2] = 1.0;
+        return;
+    }
+    if (!apply) return;
+    for (int kf = t; kf < K; kf += (int)blockDim.x) {
+        const int l = local[kf];
+        if (l < 0) continue;
+        store_pose(Twc + 8 * kf, retract_ops(x + 7 * l, load_pose<double>(Twc + 8 * kf)));
+    }
+    if (t == 0) info[0] += 1.0;
+}
+
+
 // One workgroup: (H + 1e-6 I) dx = -g by in-place Cholesky (lower) + two triangular solves,
 // stop test, then T <- exp(dx) T for the free keyframes.  dx is left in x[0..dim).
 __global__ void __launch_bounds__(kSolveThreads)
@@ -302,33 +341,25 @@ k_gn_step(double *__restrict__ H, double *__restrict__ g, double *__restrict__ x
         for (int i = t; i < k; i += kSolveThreads) x[i] -= H[(size_t)k * dim + i] * xk;
         __syncthreads();
     }
-    __shared__ double nrm2, smax;
-    if (t == 0) {
-        double s = 0.0, m = 0.0;
-        for (int i = 0; i < dim; ++i) {
-            s += x[i] * x[i];
-            if (i % 7 == 6) m = fmax(m, fabs(x[i]));
-        }
-        nrm2 = s; smax = m;
-    }
-    __syncthreads();
-    const double dn = sqrt(nrm2);
-    if (t == 0) info[1] = dn;
-    if (!isfinite(dn) || smax > 30.0) {                     // a scale step e^sigma beyond float range (degenerate
-        if (t == 0) { info[2] = 1.0; info[3] = 1.0; }       // geometry): report failure, keep the poses
+    gn_step_tail(x, Twc, local, info, K, dim, delta_thresh, apply);
+}
+
+// tail of a blocked solve: fail flag of the factorisation -> info, else the common tail
+__global__ void __launch_bounds__(kSolveThreads)
+k_gn_tail(double *__restrict__ x, float *__restrict__ Twc, const int32_t *__restrict__ local, double *__restrict__ info,
+          const double *__restrict__ fail, int K, int dim, float delta_thresh, int apply) {
+    if (info[2] != 0.0) return;
+    if (fail[0] != 0.0) {
+        if (threadIdx.x == 0) { info[2] = 1.0; info[3] = 1.0; }
         return;
     }
-    if (dn < (double)delta_thresh) {                        // stop BEFORE the update (gauss_newton.py:262-265)
-        if (t == 0) info[2] = 1.0;
-        return;
-    }
-    if (!apply) return;
-    for (int kf = t; kf < K; kf += kSolveThreads) {
-        const int l = local[kf];
-        if (l < 0) continue;
-        store_pose(Twc + 8 * kf, retract_ops(x + 7 * l, load_pose<double>(Twc + 8 * kf)));
-    }
-    if (t == 0) info[0] += 1.0;
+    gn_step_tail(x, Twc, local, info, K, dim, delta_thresh, apply);
+}
+
+__global__ void k_gn_neg_rhs(const double *__restrict__ g, double *__restrict__ x, double *__restrict__ fail, int dim) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < dim) x[i] = -g[i];
+    if (i == 0) fail[0] = 0.0;
 }
 
 __global__ void __launch_bounds__(kThreads)
@@ -352,6 +383,27 @@ CalibParams make_calib(const float *c) {
         p.z_eps = c[7]; p.inv_sigma_pixel = 1.0f / c[8]; p.inv_sigma_depth = 1.0f / c[9];
     }
     return p;
+}
+
+
+// One Gauss-Newton step from an assembled system, any size, stream-ordered: dim <= kMaxDim -> the single-workgroup
+// kernel; larger -> blocked Cholesky (gn_chol.hip) + k_gn_tail.  Hbuf = H [dim*dim] | g | x | b | y [dim each] | fail [1]
+// = m3_gn_rays_hbuf_doubles(dim).
+int launch_step(double *Hbuf, float *Twc, const int32_t *local, double *info, int K, int dim, float delta_thresh,
+                int apply, hipStream_t st) {
+    double *H = Hbuf, *g = Hbuf + (size_t)dim * dim, *x = g + dim, *b = x + dim, *y = b + dim, *fail = y + dim;
+    if (dim <= kMaxDim) {
+        hipLaunchKernelGGL(k_gn_step, dim3(1), dim3(kSolveThreads), 0, st, H, g, x, Twc, local, info, K, dim, delta_thresh, apply);
+        M3_CHECK_LAUNCH("m3_gn_rays/step");
+        return M3_OK;
+    }
+    hipLaunchKernelGGL(k_gn_neg_rhs, dim3(m3_cdiv(dim, 256)), dim3(256), 0, st, (const double *)g, b, fail, dim);
+    const int rc = m3_chol_solve_launch(H, b, y, x, fail, info + 2, dim, 1e-6, st);
+    if (rc != M3_OK) return rc;
+    hipLaunchKernelGGL(k_gn_tail, dim3(1), dim3(kSolveThreads), 0, st, x, Twc, local, info, (const double *)fail, K, dim,
+                       delta_thresh, apply);
+    M3_CHECK_LAUNCH("m3_gn_rays/tail");
+    return M3_OK;
 }
 
 int launch_blocks(const float *Twc, const float *Xs, const float *Cs, const int32_t *ii, const int32_t *jj,
@@ -383,6 +435,7 @@ extern "C" {
 
 int m3_gn_rays_chunks(int P) { return gn_chunks(P); }
 int m3_gn_rays_max_dim(void) { return kMaxDim; }
+int64_t m3_gn_rays_hbuf_doubles(int dim) { return (int64_t)dim * dim + 4 * (int64_t)dim + 8; }
 
 int m3_gn_rays_blocks(const float *Twc, const float *Xs, const float *Cs, const int32_t *ii, const int32_t *jj,
                       const int32_t *idx, const uint8_t *valid, const float *Q, double *blocks, double *ws,
@@ -424,9 +477,8 @@ int m3_gn_rays_solve(float *Twc, const float *Xs, const float *Cs, const int32_t
     M3_REQUIRE(point_mode >= 0 && point_mode <= 2 && (point_mode != 2 || calib));
     const CalibParams cal = make_calib(calib);
     const int dim = 7 * num_free;
-    if (dim > kMaxDim) return M3_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    double *H = Hbuf, *g = Hbuf + (size_t)dim * dim, *x = g + dim;
+    double *H = Hbuf, *g = Hbuf + (size_t)dim * dim;          // Hbuf: m3_gn_rays_hbuf_doubles(dim)
     const double *done = info + 2;
     hipLaunchKernelGGL(k_gn_info_init, dim3(1), dim3(64), 0, st, info);
     for (int it = 0; it < max_iter; ++it) {
@@ -435,10 +487,32 @@ int m3_gn_rays_solve(float *Twc, const float *Xs, const float *Cs, const int32_t
         if (rc != M3_OK) return rc;
         hipLaunchKernelGGL(k_gn_assemble, dim3(num_free, num_free), dim3(64), 0, st, (const double *)blocks, ii, jj,
                            local, H, g, done, K, dim, E);
-        hipLaunchKernelGGL(k_gn_step, dim3(1), dim3(kSolveThreads), 0, st, H, g, x, Twc, local, info, K, dim,
-                           delta_thresh, 1);
         M3_CHECK_LAUNCH("m3_gn_rays_solve/iter");
+        rc = launch_step(Hbuf, Twc, local, info, K, dim, delta_thresh, 1, st);
+        if (rc != M3_OK) return rc;
     }
+    return M3_OK;
+}
+
+// One step from blocks that the caller assembled elsewhere (the edge-sharded solve: blocks all-gathered over the
+// ranks): assemble -> factor -> solve -> stop test -> retract, all on the stream; info as in m3_gn_rays_solve
+// (zero it once with m3_gn_rays_info_init before the first step).  Hbuf: m3_gn_rays_hbuf_doubles(7 * num_free).
+int m3_gn_rays_step(float *Twc, const double *blocks, const int32_t *ii, const int32_t *jj, const int32_t *local,
+                    double *Hbuf, double *info, int K, int E, int num_free, float delta_thresh, void *stream) {
+    M3_REQUIRE(Twc && blocks && ii && jj && local && Hbuf && info && K > 0 && E > 0 && num_free > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int dim = 7 * num_free;
+    double *H = Hbuf, *g = Hbuf + (size_t)dim * dim;
+    hipLaunchKernelGGL(k_gn_assemble, dim3(num_free, num_free), dim3(64), 0, st, blocks, ii, jj, local, H, g,
+                       (const double *)(info + 2), K, dim, E);
+    M3_CHECK_LAUNCH("m3_gn_rays_step/assemble");
+    return launch_step(Hbuf, Twc, local, info, K, dim, delta_thresh, 1, st);
+}
+
+int m3_gn_rays_info_init(double *info, void *stream) {
+    M3_REQUIRE(info);
+    hipLaunchKernelGGL(k_gn_info_init, dim3(1), dim3(64), 0, (hipStream_t)stream, info);
+    M3_CHECK_LAUNCH("m3_gn_rays_info_init");
     return M3_OK;
 }
 

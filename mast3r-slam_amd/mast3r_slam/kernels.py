@@ -214,58 +214,57 @@ def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray:
         loc = {n: t[n][sl].contiguous() for n in ("ii", "jj", "idx", "valid", "Q")}
         e_loc = len(mine)
         blocks_loc = torch.empty((e_loc, 36), dtype=torch.float64, device=dev)
-    if dim <= L.m3_gn_rays_max_dim() and not sharded:
-        hbuf = torch.empty(dim * dim + 2 * dim, dtype=torch.float64, device=dev)
+    hbuf = torch.empty(int(L.m3_gn_rays_hbuf_doubles(dim)), dtype=torch.float64, device=dev)
+    if not sharded:
+        # the whole loop (blocks -> assemble -> Cholesky of ANY size -> stop test -> retract) in one stream-ordered call
         _ffi.call("m3_gn_rays_solve", _ffi.ptr(twc), _ffi.ptr(t["Xs"]), _ffi.ptr(t["Cs"]), _ffi.ptr(t["ii"]),
                   _ffi.ptr(t["jj"]), _ffi.ptr(t["idx"]), _ffi.ptr(t["valid"]), _ffi.ptr(t["Q"]), _ffi.ptr(local),
                   _ffi.ptr(blocks), _ffi.ptr(ws), _ffi.ptr(hbuf), _ffi.ptr(info), k, p, e, num_free,
                   float(sigma_ray), float(C_thresh), float(Q_thresh), int(max_iter), float(delta_thresh),
                   int(_point_mode), _calib_ptr(_calib), st)
-        result_info = None
-        if return_info:
-            i = info.cpu().numpy()
-            result_info = dict(iters=int(i[0]), last_dx=float(i[1]), stopped=bool(i[2]), failed=bool(i[3]))
     else:
-        # Large graphs: blocks / assembly / retraction are HIP; the dense factorisation of the
-        # (7F x 7F) system goes through hipSOLVER via torch.linalg (a plain library solve).
-        H = torch.empty((dim, dim), dtype=torch.float64, device=dev)
-        g = torch.empty(dim, dtype=torch.float64, device=dev)
-        iters, last, stopped, failed = 0, 0.0, False, False
+        # edge-sharded: every rank evaluates its own edges, the 36-double blocks are all-gathered, and EVERY rank runs
+        # the same deterministic device step (fixed-order assembly, Cholesky, stop test, retraction) on the gathered
+        # blocks: bit-identical poses on all ranks with no broadcast and no host synchronisation in the loop.  The
+        # stop / failure flags live on the device (info); a stopped solve turns the remaining launches into no-ops.
+        _ffi.call("m3_gn_rays_info_init", _ffi.ptr(info), st)
         for _ in range(max_iter):
-            if sharded:
-                if e_loc:
-                    _ffi.call("m3_gn_rays_blocks", _ffi.ptr(twc), _ffi.ptr(t["Xs"]), _ffi.ptr(t["Cs"]), _ffi.ptr(loc["ii"]),
-                              _ffi.ptr(loc["jj"]), _ffi.ptr(loc["idx"]), _ffi.ptr(loc["valid"]), _ffi.ptr(loc["Q"]),
-                              _ffi.ptr(blocks_loc), _ffi.ptr(ws), k, p, e_loc, float(sigma_ray), float(C_thresh),
-                              float(Q_thresh), int(_point_mode), _calib_ptr(_calib), st)
-                blocks = m3dist.all_gather_rows(blocks_loc, e, group).contiguous()
-            else:
-                _ffi.call("m3_gn_rays_blocks", _ffi.ptr(twc), _ffi.ptr(t["Xs"]), _ffi.ptr(t["Cs"]), _ffi.ptr(t["ii"]),
-                          _ffi.ptr(t["jj"]), _ffi.ptr(t["idx"]), _ffi.ptr(t["valid"]), _ffi.ptr(t["Q"]),
-                          _ffi.ptr(blocks), _ffi.ptr(ws), k, p, e, float(sigma_ray), float(C_thresh),
+            if e_loc:
+                _ffi.call("m3_gn_rays_blocks", _ffi.ptr(twc), _ffi.ptr(t["Xs"]), _ffi.ptr(t["Cs"]), _ffi.ptr(loc["ii"]),
+                          _ffi.ptr(loc["jj"]), _ffi.ptr(loc["idx"]), _ffi.ptr(loc["valid"]), _ffi.ptr(loc["Q"]),
+                          _ffi.ptr(blocks_loc), _ffi.ptr(ws), k, p, e_loc, float(sigma_ray), float(C_thresh),
                           float(Q_thresh), int(_point_mode), _calib_ptr(_calib), st)
-            _ffi.call("m3_gn_rays_assemble", _ffi.ptr(blocks), _ffi.ptr(t["ii"]), _ffi.ptr(t["jj"]),
-                      _ffi.ptr(local), _ffi.ptr(H), _ffi.ptr(g), k, e, num_free, st)
-            H.diagonal().add_(1e-6)
-            Lc, err = torch.linalg.cholesky_ex(H)
-            if int(err) != 0:
-                failed = stopped = True
-                break
-            dx = torch.cholesky_solve((-g)[:, None], Lc)[:, 0].contiguous()
-            if sharded:
-                tdist.broadcast(dx, src=tdist.get_global_rank(group, 0) if group is not tdist.group.WORLD else 0, group=group)
-            last = float(torch.linalg.norm(dx))
-            if not np.isfinite(last) or float(dx.view(-1, 7)[:, 6].abs().max()) > 30.0:
-                failed = stopped = True                      # scale step beyond float range: keep the poses (gn_rays.hip)
-                break
-            if last < delta_thresh:
-                stopped = True
-                break
-            _ffi.call("m3_gn_rays_retract", _ffi.ptr(twc), _ffi.ptr(dx), _ffi.ptr(local), k, st)
-            iters += 1
-        result_info = dict(iters=iters, last_dx=last, stopped=stopped, failed=failed)
+            blocks = m3dist.all_gather_rows(blocks_loc, e, group).contiguous()
+            _ffi.call("m3_gn_rays_step", _ffi.ptr(twc), _ffi.ptr(blocks), _ffi.ptr(t["ii"]), _ffi.ptr(t["jj"]),
+                      _ffi.ptr(local), _ffi.ptr(hbuf), _ffi.ptr(info), k, e, num_free, float(delta_thresh), st)
+    result_info = None
+    if return_info:
+        i = info.cpu().numpy()
+        result_info = dict(iters=int(i[0]), last_dx=float(i[1]), stopped=bool(i[2]), failed=bool(i[3]))
     out = _out(twc, t["np_in"], np.float32)
     return (out, result_info) if return_info else out
+
+
+def cholesky_solve(H, g, reg: float = 1e-6):
+    """backends/mpsgraph/linalg.py:17-50 on the device: x = solve(H + reg I, g) for a symmetric positive-definite H
+    [N,N] (or batched [B,N,N]) of ANY size by the blocked float64 Cholesky of gn_chol.hip.  numpy in -> numpy out,
+    tensors in -> tensor out (float64).  Raises RuntimeError when H + reg I is not positive definite (the reference
+    falls back to lstsq there; no silent downgrade here)."""
+    Hd, np_in = _to_dev(H, torch.float64)
+    gd, _ = _to_dev(g, torch.float64)
+    if Hd.dim() == 3:
+        xs = [cholesky_solve(Hd[i], gd[i].reshape(-1), reg) for i in range(Hd.shape[0])]
+        return _out(torch.stack(xs), np_in)
+    n = Hd.shape[0]
+    if Hd.dim() != 2 or Hd.shape[1] != n or gd.numel() != n:
+        raise ValueError(f"H must be [N,N] and g [N], got {tuple(Hd.shape)} / {tuple(gd.shape)}")
+    Hw, bw = Hd.clone().contiguous(), gd.reshape(-1).clone().contiguous()
+    x = torch.empty(n, dtype=torch.float64, device=Hw.device)
+    ws = torch.empty(n + 1, dtype=torch.float64, device=Hw.device)
+    _ffi.call("m3_chol_solve", _ffi.ptr(Hw), _ffi.ptr(bw), _ffi.ptr(x), _ffi.ptr(ws), n, float(reg), _ffi.stream_ptr())
+    if float(ws[0]) != 0.0:
+        raise RuntimeError("cholesky_solve: H + reg*I is not positive definite")
+    return _out(x, np_in)
 
 
 def gauss_newton_points(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_point: float = 0.01,

@@ -194,3 +194,42 @@ def test_solve_is_bitwise_reproducible(dev):
         dargs = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in args]
         outs = [kernels.gauss_newton_rays(*dargs, max_iter=3).cpu() for _ in range(3)]
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("n", [7, 64, 65, 449, 1785])
+def test_blocked_cholesky_solve_any_size(dev, n):
+    """kernels.cholesky_solve (linalg.py:17-50) through m3_chol_solve: blocked float64 Cholesky, block 64, for sizes
+    below / at / across block boundaries and at BASELINE configs[4]'s 256 keyframes (7 * 255 = 1785 unknowns)."""
+    rng = np.random.default_rng(n)
+    A = rng.normal(size=(n, n))
+    H = A @ A.T / n + np.eye(n) * 0.5
+    g = rng.normal(size=n)
+    x = kernels.cholesky_solve(H, g, 1e-6)
+    ref = np.linalg.solve(H + 1e-6 * np.eye(n), g)
+    assert np.abs(x - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    if n == 65:
+        with pytest.raises(RuntimeError, match="not positive definite"):
+            kernels.cholesky_solve(-H, g, 0.0)
+        xb = kernels.cholesky_solve(np.stack([H, 2 * H]), np.stack([g, g]), 0.0)          # batched form
+        assert np.allclose(xb[1], 0.5 * xb[0], rtol=1e-9, atol=1e-12)
+
+
+def test_large_graph_solve_stays_on_the_device(dev):
+    """70 keyframes -> 483 unknowns > the single-workgroup limit (448): the whole Gauss-Newton loop (blocks, assembly,
+    blocked Cholesky, stop test, retraction) runs as one stream-ordered call and matches the float64 oracle; a
+    converged solve stops by its device flag."""
+    K_, P_ = 70, 4096
+    Twc, Xs, Cs, ii, jj, idx, valid, Q = synthetic.gn_graph(K_, P_, 0, seed=23, chain=True, pose_noise=0.0)
+    rng = np.random.default_rng(1)
+    noisy = Twc.copy()
+    noisy[1:, :3] += rng.normal(size=(K_ - 1, 3)).astype(np.float32) * 0.01
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    args = [t(a) for a in (noisy, Xs, Cs, ii, jj, idx, valid, Q)]
+    out, info = kernels.gauss_newton_rays(*args, max_iter=3, return_info=True)
+    ref = og.gauss_newton_rays(noisy, Xs, Cs, ii, jj, idx, valid, Q, max_iter=3)
+    assert not info["failed"] and info["iters"] >= 1
+    assert np.array_equal(out[0].cpu().numpy(), noisy[0]) and np.abs(out.cpu().numpy() - ref).max() < 5e-4
+    # the device stop flag: a threshold above the first step's norm stops BEFORE the update (gauss_newton.py:262-265)
+    out2, info2 = kernels.gauss_newton_rays(*args, max_iter=5, delta_thresh=1e6, return_info=True)
+    assert info2["stopped"] and not info2["failed"] and info2["iters"] == 0
+    assert np.array_equal(out2.cpu().numpy(), noisy)

@@ -326,6 +326,20 @@ def main():
         e1.record(); torch.cuda.synchronize()
         result["match_ms_on_random_weight_network_output"] = round(e0.elapsed_time(e1) / 5, 3)
 
+    if world == 1 and not args.no_b1:
+        # matcher variant named by north_star: fast reciprocal NN (MASt3R sec. 3.3) on the same scene, 64 x 64 seeds
+        # (subsample 8), fp16 descriptors, device-side loop (3 rounds), per pair; not part of the timed step
+        d1, d2 = sc["D21"][0].half(), sc["D11"][0].half()
+        for _ in range(2):
+            matching.fast_reciprocal_nn_device(d1, d2, subsample=8, max_iter=3)
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(3):
+            p1, p2 = matching.fast_reciprocal_nn_device(d1, d2, subsample=8, max_iter=3)
+        e1.record(); torch.cuda.synchronize()
+        result["fast_nn_matcher"] = {"ms_per_pair": round(e0.elapsed_time(e1) / 3, 3), "reciprocal_pairs": int(p1.numel()),
+                                     "seeds": 4096, "note": "m3_nn_search_mfma, fp16 descriptors, 3 rounds x 2 searches of 4096 x 262144 x 24"}
+
     if world == 1 and not args.no_b1 and P != 1:
         # BASELINE configs[1]: one pair per step (latency regime), same pipeline, graph-replayed
         a1, b1 = im1[:1].contiguous(), im2[:1].contiguous()

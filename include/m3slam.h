@@ -93,6 +93,14 @@ int m3_trunc_i32(const float *p, int32_t *out, int64_t count, void *stream);
 int m3_nn_search(const float *Q, const float *DB, int32_t *idx_out, float *score_out, uint64_t *keys_ws,
                  int B, int S, int N, int D, void *stream);
 
+/* The same search on the matrix cores (v_mfma_f32_16x16x32_f16, one k-step covers D <= 32): operands are packed to
+ * K-padded fp16 first - fp16 descriptors (in_f16 = 1, BASELINE configs[4] "fp16 features") take 1 MFMA per 16 x 16
+ * scores with exact products; fp32 descriptors (in_f16 = 0) are split hi + lo and take 3 (score error <= 2^-24 for
+ * unit vectors).  Ties to the lowest n as above.  pack_ws: m3_nn_pack_bytes(...) bytes, 16-byte aligned. */
+int64_t m3_nn_pack_bytes(int B, int S, int N, int in_f16);
+int m3_nn_search_mfma(const void *Q, const void *DB, int32_t *idx_out, float *score_out, uint64_t *keys_ws,
+                      void *pack_ws, int B, int S, int N, int D, int in_f16, void *stream);
+
 /* ------------------------------------------------------------------ tracking */
 
 /* FrameTracker.track glue (tracker.py:88-113, _get_points_poses :177-214): for each

@@ -112,21 +112,67 @@ def match(X11, X21, D11, D21, idx_1_to_2_init=None):
 # ---------------------------------------------------------------------------------------------------
 # Fast reciprocal nearest-neighbour matching (named by BASELINE.json; MASt3R, Leroy et al. 2024, sec. 3.3).
 # The reference tree has no implementation: semantics and oracle are this repo's.
-def nn_search(Q: torch.Tensor, DB: torch.Tensor, return_score: bool = False):
-    """Q [B,S,D], DB [B,N,D] f32 -> idx int32 [B,S] = argmax_n <Q[b,s], DB[b,n]> (fp32 FMA chain in k order,
-    ties to the lowest n) through m3_nn_search (brute force; a lane owns a query, database rows are scalar
-    loads)."""
-    Q = _ffi.check(Q, torch.float32, "Q")
-    DB = _ffi.check(DB, torch.float32, "DB")
+def nn_search(Q: torch.Tensor, DB: torch.Tensor, return_score: bool = False, method: str = "mfma"):
+    """Q [B,S,D], DB [B,N,D] -> idx int32 [B,S] = argmax_n <Q[b,s], DB[b,n]>, ties to the lowest n.
+    method "mfma" (default): m3_nn_search_mfma - the scores are a GEMM on v_mfma_f32_16x16x32_f16; fp16 inputs
+    (descriptors stored as fp16) take one MFMA per 16 x 16 scores with exact products, fp32 inputs are split hi + lo
+    (3 MFMAs, error <= 2^-24 for unit vectors).  method "fma": m3_nn_search, the fp32 FMA-chain kernel (fp32 only)."""
+    if method not in ("mfma", "fma"):
+        raise ValueError("method must be 'mfma' or 'fma'")
+    dts = (torch.float32, torch.float16) if method == "mfma" else torch.float32
+    Q = _ffi.check(Q, dts, "Q")
+    DB = _ffi.check(DB, dts, "DB")
+    if Q.dtype != DB.dtype:
+        raise TypeError(f"Q and DB must have the same dtype, got {Q.dtype} / {DB.dtype}")
     if Q.dim() != 3 or DB.dim() != 3 or Q.shape[0] != DB.shape[0] or Q.shape[2] != DB.shape[2]:
         raise ValueError(f"Q [B,S,D] / DB [B,N,D] expected, got {tuple(Q.shape)} / {tuple(DB.shape)}")
     b, s, d = Q.shape
+    n = DB.shape[1]
     idx = torch.empty((b, s), dtype=torch.int32, device=Q.device)
     score = torch.empty((b, s), dtype=torch.float32, device=Q.device) if return_score else None
     keys = torch.empty((b, s), dtype=torch.int64, device=Q.device)
-    _ffi.call("m3_nn_search", _ffi.ptr(Q), _ffi.ptr(DB), _ffi.ptr(idx), _ffi.ptr(score), _ffi.ptr(keys), b, s, DB.shape[1],
-              d, _ffi.stream_ptr())
+    if method == "fma":
+        _ffi.call("m3_nn_search", _ffi.ptr(Q), _ffi.ptr(DB), _ffi.ptr(idx), _ffi.ptr(score), _ffi.ptr(keys), b, s, n, d,
+                  _ffi.stream_ptr())
+    else:
+        f16 = 1 if Q.dtype == torch.float16 else 0
+        ws = torch.empty(int(_ffi.lib().m3_nn_pack_bytes(b, s, n, f16)), dtype=torch.uint8, device=Q.device)
+        _ffi.call("m3_nn_search_mfma", _ffi.ptr(Q), _ffi.ptr(DB), _ffi.ptr(idx), _ffi.ptr(score), _ffi.ptr(keys), _ffi.ptr(ws),
+                  b, s, n, d, f16, _ffi.stream_ptr())
     return (idx, score) if return_score else idx
+
+
+def fast_reciprocal_nn_device(D1: torch.Tensor, D2: torch.Tensor, subsample: int = 8, max_iter: int = 10):
+    """fast_reciprocal_nn with the whole loop on the device: no host synchronisation per round.  Every round runs
+    on the full seed set (converged seeds are masked, a seed that moved continues from where it landed) and the
+    converged pairs are collected into fixed-size buffers; ONE synchronisation at the end (the final `unique`).
+    Same result set as the shrinking-active-set version for the same max_iter.  D1, D2 [H,W,D] fp32 or fp16."""
+    if D1.dim() != 3 or D2.dim() != 3 or D1.shape[2] != D2.shape[2]:
+        raise ValueError("D1, D2 must be [H,W,D] with the same D")
+    h1, w1, d = D1.shape
+    f1, f2 = D1.reshape(1, -1, d).contiguous(), D2.reshape(1, -1, d).contiguous()
+    dev = D1.device
+    ys = torch.arange(subsample // 2, h1, subsample, device=dev)
+    xs = torch.arange(subsample // 2, w1, subsample, device=dev)
+    cur = (ys[:, None] * w1 + xs[None, :]).reshape(-1)
+    s = cur.numel()
+    if s == 0:
+        e = torch.empty(0, dtype=torch.int64, device=dev)
+        return e, e
+    active = torch.ones(s, dtype=torch.bool, device=dev)
+    got1 = torch.full((max_iter, s), -1, dtype=torch.int64, device=dev)
+    got2 = torch.full((max_iter, s), -1, dtype=torch.int64, device=dev)
+    for r in range(max_iter):
+        xy2 = nn_search(f1[:, cur], f2)[0].long()
+        back = nn_search(f2[:, xy2], f1)[0].long()
+        conv = (back == cur) & active
+        got1[r] = torch.where(conv, cur, got1[r])
+        got2[r] = torch.where(conv, xy2, got2[r])
+        active = active & ~conv
+        cur = torch.where(active, back, cur)
+    keep = got1.reshape(-1) >= 0
+    pairs = torch.unique(torch.stack([got1.reshape(-1)[keep], got2.reshape(-1)[keep]], 1), dim=0)   # the one host sync
+    return pairs[:, 0], pairs[:, 1]
 
 
 def fast_reciprocal_nn(D1: torch.Tensor, D2: torch.Tensor, subsample: int = 8, max_iter: int = 10):

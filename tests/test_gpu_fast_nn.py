@@ -18,12 +18,14 @@ def _unit(rng, n, d):
     return v / np.linalg.norm(v, axis=1, keepdims=True)
 
 
-@pytest.mark.parametrize("s,n,d", [(1, 1, 24), (300, 5000, 24), (4096, 16384, 24), (257, 777, 16), (64, 1000, 32)])
-def test_nn_search_vs_float64_oracle(dev, s, n, d):
+@pytest.mark.parametrize("method", ["mfma", "fma"])
+@pytest.mark.parametrize("s,n,d", [(1, 1, 24), (300, 5000, 24), (4096, 16384, 24), (257, 777, 16), (64, 1000, 32), (600, 70001, 24)])
+def test_nn_search_vs_float64_oracle(dev, s, n, d, method):
     rng = np.random.default_rng(s + n)
     Q, DB = _unit(rng, s, d), _unit(rng, n, d)
     DB[n // 2] = DB[0]                                                       # an exact duplicate: ties go to the lowest index
-    idx, score = matching.nn_search(torch.from_numpy(Q)[None].to(dev), torch.from_numpy(DB)[None].to(dev), return_score=True)
+    idx, score = matching.nn_search(torch.from_numpy(Q)[None].to(dev), torch.from_numpy(DB)[None].to(dev), return_score=True,
+                                    method=method)
     idx, score = idx[0].cpu().numpy(), score[0].cpu().numpy()
     ref, best, second = om.nn_search(Q, DB)
     clear = best - second > 4 * EPS
@@ -32,6 +34,22 @@ def test_nn_search_vs_float64_oracle(dev, s, n, d):
     assert np.all(chosen >= best - 4 * EPS) and np.abs(score - chosen).max() < 4 * EPS
     dup = ref == 0
     assert np.all(idx[dup & clear] == 0)                                     # never the duplicate at n // 2
+
+
+def test_nn_search_fp16_descriptors_are_exact_products(dev):
+    """Descriptors STORED as fp16 (BASELINE configs[4] 'fp16 features'): the MFMA multiplies them exactly and sums in
+    fp32, so against the float64 oracle on the SAME fp16 values only the fp32 summation bound applies."""
+    rng = np.random.default_rng(11)
+    Q, DB = _unit(rng, 1000, 24).astype(np.float16), _unit(rng, 30000, 24).astype(np.float16)
+    DB[20000] = DB[7]
+    idx, score = matching.nn_search(torch.from_numpy(Q)[None].to(dev), torch.from_numpy(DB)[None].to(dev), return_score=True)
+    idx, score = idx[0].cpu().numpy(), score[0].cpu().numpy()
+    ref, best, second = om.nn_search(Q.astype(np.float64), DB.astype(np.float64))
+    clear = best - second > 4 * EPS
+    assert clear.mean() > 0.9 and np.array_equal(idx[clear], ref[clear])
+    chosen = np.einsum("sd,sd->s", Q.astype(np.float64), DB[idx].astype(np.float64))
+    assert np.all(chosen >= best - 4 * EPS) and np.abs(score - chosen).max() < 4 * EPS
+    assert np.all(idx[(ref == 7) & clear] == 7)
 
 
 def test_nn_search_batched_and_rejects_bad_input(dev):
@@ -57,6 +75,12 @@ def test_fast_reciprocal_nn_on_a_smooth_scene(dev):
     r1, r2 = om.fast_reciprocal_nn(D1, D2, subsample=4)
     got = set(zip(i1.cpu().tolist(), i2.cpu().tolist())); ref = set(zip(r1.tolist(), r2.tolist()))
     assert len(ref) > 100 and len(got & ref) >= 0.98 * len(ref) and len(got - ref) <= 0.02 * len(ref)
+    # the sync-free device loop returns the same set, also from fp16 descriptors
+    j1, j2 = matching.fast_reciprocal_nn_device(torch.from_numpy(D1).to(dev), torch.from_numpy(D2).to(dev), subsample=4)
+    assert set(zip(j1.cpu().tolist(), j2.cpu().tolist())) == got
+    k1, k2 = matching.fast_reciprocal_nn_device(torch.from_numpy(D1).to(dev).half(), torch.from_numpy(D2).to(dev).half(), subsample=4)
+    gk = set(zip(k1.cpu().tolist(), k2.cpu().tolist()))
+    assert len(gk & ref) >= 0.95 * len(ref)
     uv = sc["uv_true"][0][i1.cpu().numpy()]                                    # where each matched view-2 pixel truly lands
     x2, y2 = i2.cpu().numpy() % 96, i2.cpu().numpy() // 96
     inside = (uv[:, 0] > 1) & (uv[:, 0] < 94) & (uv[:, 1] > 1) & (uv[:, 1] < 62)

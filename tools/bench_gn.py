@@ -45,3 +45,17 @@ for _ in range(5):
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / 5 * 1e3
 print(f"gn_rays_blocks {E} directed edges x {P_} points: {us:.0f} us = {E * 10.8e6 / us / 1e6:.2f} TB/s of the 10.8 MB/edge algorithmic traffic")
+
+# ---- fast-NN search: 4096 seeds x 262144 pixels x 24 dims
+rng = np.random.default_rng(0)
+def unit(n):
+    v = rng.normal(size=(n, 24)).astype(np.float32); return v / np.linalg.norm(v, axis=1, keepdims=True)
+Qn, DBn = torch.from_numpy(unit(4096))[None].to(dev), torch.from_numpy(unit(262144))[None].to(dev)
+for name, q, d, m in (("fma fp32", Qn, DBn, "fma"), ("mfma fp32 (hi+lo)", Qn, DBn, "mfma"), ("mfma fp16", Qn.half(), DBn.half(), "mfma")):
+    for _ in range(2):
+        matching.nn_search(q, d, method=m)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(10):
+        matching.nn_search(q, d, method=m)
+    e1.record(); torch.cuda.synchronize()
+    print(f"nn_search 4096 x 262144 x 24 [{name}]: {e0.elapsed_time(e1) / 10 * 1e3:.0f} us")

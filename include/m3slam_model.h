@@ -56,9 +56,12 @@ int m3_gemm_pick_tile(int M, int N, int groups);
  * gathered once per image size; 16-byte aligned.  N % 64 == 0. */
 int m3_gemm_bf16_rope(const void *A, const void *W, const float *bias, void *C, int M, int N, int K,
                       int ldc, const float *rope_tok, int tokens_per_image, int rope_cols, void *stream);
+/* _dt forms: columns [0, q_cols) (the q heads; q_cols <= rope_cols) are additionally multiplied by q_scale after the
+ * rotation and before the 16-bit rounding - softmax scale * log2(e) folded into q, which m3_attention_prescaled_dt
+ * expects (q_cols = 0: nothing is scaled). */
 int m3_gemm_rope_dt(const void *A, const void *W, const float *bias, void *C, int M, int N, int K,
-                    int ldc, const float *rope_tok, int tokens_per_image, int rope_cols, int dtype,
-                    void *stream);
+                    int ldc, const float *rope_tok, int tokens_per_image, int rope_cols, int q_cols,
+                    float q_scale, int dtype, void *stream);
 
 /* Two same-shape GEMMs in one launch (the two decoder branches have different weights): group g
  * (0/1) computes C + g*c_gstride = epi((A + g*a_gstride) . W[g]^T + bias[g]); strides in elements.
@@ -70,7 +73,7 @@ int m3_gemm_bf16_grouped2(const void *A, const void *W0, const void *W1, const f
 int m3_gemm_grouped2_dt(const void *A, const void *W0, const void *W1, const float *bias0,
                         const float *bias1, void *C, const void *R, int M, int N, int K, int ldc,
                         int64_t a_gstride, int64_t c_gstride, int epilogue, const float *rope_tok,
-                        int tokens_per_image, int rope_cols, int dtype, void *stream);
+                        int tokens_per_image, int rope_cols, int q_cols, float q_scale, int dtype, void *stream);
 
 /* 3x3 convolution, padding 1, stride 1 or 2, as an implicit GEMM: X bf16 NHWC [B,H,W,Cin],
  * W bf16 [Cout,3,3,Cin], Y NHWC [B,OH,OW,Cout].  Cin % 64 == 0, Cout % 4 == 0.  zero16: 16
@@ -144,6 +147,13 @@ int m3_attention_dt(const void *Q, const void *K, const void *V, void *O, int q_
  * cos_sin f32 [max_pos,16,2]. */
 int m3_rope2d_bf16(void *X, const int32_t *pos_yx, const float *cos_sin, int row_stride, int tokens,
                    int heads, int tokens_per_image, void *stream);
+/* The same with q PRE-SCALED by softmax scale * log2(e) (m3_gemm_rope_dt's q_scale): a score is an exp2 argument as
+ * it leaves the matrix core, the running reference maximum enters the MFMA as its accumulator initialiser, and the
+ * rescale of the output runs only when a tile's maximum exceeds the reference by 2^8 (deferred maximum). */
+int m3_attention_prescaled_dt(const void *Q, const void *K, const void *V, void *O, int q_row_stride,
+                              int kv_row_stride, int o_row_stride, int64_t q_batch_stride,
+                              int64_t kv_batch_stride, int64_t o_batch_stride, int nbatch, int heads,
+                              int Tq, int Tk, int kv_batch_shift, int dtype, void *stream);
 int m3_rope2d_dt(void *X, const int32_t *pos_yx, const float *cos_sin, int row_stride, int tokens,
                  int heads, int tokens_per_image, int dtype, void *stream);
 

@@ -50,7 +50,14 @@ struct AttnArgs {
 // e.g. one pair = 2 images x 16 heads x 8 blocks = 256 workgroups on 256 CUs).
 // Any Tq, Tk >= 1: query rows past Tq are computed on a clamped row and not stored; keys past Tk (last
 // tile only) are staged from the clamped last row and their scores set to -inf before the softmax.
-template <int QT, int DT>
+// PRE: q already carries softmax scale * log2(e) (folded in by the projection GEMM's RoPE epilogue), so a score is
+// an exp2 argument as it leaves the matrix core.  The running reference maximum m_ref of a query enters the S^T MFMA
+// as its accumulator INITIALISER (C = -m_ref, lane-local), i.e. the MFMA returns s - m_ref and p = exp2(that) with no
+// per-score subtract / multiply; m_ref is raised (and o, l rescaled) only when a tile's maximum exceeds it by more
+// than kDefer (wave-uniform, rare after the first tiles; p <= 2^kDefer otherwise).  Row sums as packed adds.
+// Per (tile, query tile): 16 v_fma + 16 v_add fewer of ~90 VALU slots in a VALU-bound kernel.
+constexpr float kDefer = 8.0f;
+template <int QT, int DT, bool PRE>
 __global__ void __launch_bounds__(kThreads, 4)
 k_attn(const AttnArgs a) {
     constexpr int QR = QT * 64;                                 // query rows per workgroup
@@ -117,9 +124,11 @@ k_attn(const AttnArgs a) {
         // ---- S^T = K . Q^T : s[qt][kt] holds keys kt*16 + g*4 + r of query lq ------------------
         f32x4 s[QT][4];
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
+        for (int qt = 0; qt < QT; ++qt) {
+            const float c0 = (PRE && t > 0) ? -m_run[qt] : 0.f;          // PRE: m_run holds m_ref (log2 units)
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int kt = 0; kt < 4; ++kt) s[qt][kt] = f32x4{c0, c0, c0, c0};
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -145,44 +154,97 @@ k_attn(const AttnArgs a) {
 
         // ---- online softmax (row = lane-local query) -------------------------------------------
         bf16x8 pf[QT][2];
+        if constexpr (PRE) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            float mx = s[qt][0][0];
+            for (int qt = 0; qt < QT; ++qt) {
+                float mx = fmaxf(__builtin_fmaxf(s[qt][0][0], s[qt][0][1]), s[qt][0][2]);
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+                for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qt][kt][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[qt], mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * a.scale_log2e);
-            const float mb = m_new * a.scale_log2e;
-            m_run[qt] = m_new;
-            float rs = 0.f;
+                    for (int r = (kt == 0 ? 3 : 0); r < 4; r += 2)
+                        mx = (r + 1 < 4) ? fmaxf(__builtin_fmaxf(mx, s[qt][kt][r]), s[qt][kt][r + 1]) : fmaxf(mx, s[qt][kt][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                if (t == 0) {                                            // first tile: the true maximum becomes the reference
+                    m_run[qt] = mx;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+                    for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(s[qt][kt][r] * a.scale_log2e - mb);
-                    s[qt][kt][r] = p;
-                    rs += p;
+                        for (int r = 0; r < 4; ++r) s[qt][kt][r] -= mx;
+                } else if (__any(mx > kDefer)) {                         // some query outgrew its reference: exact update
+                    const float delta = fmaxf(mx, 0.f);
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+                    m_run[qt] += delta;
+                    l_run[qt] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[qt][kt][r] -= delta;
                 }
-            l_run[qt] = l_run[qt] * alpha + rs;
-            if (!__all(alpha == 1.0f)) {       // exact skip: no row of this wave raised its running max
+                f32x2 rs2 = {0.f, 0.f};
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
+                for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
+                    for (int r = 0; r < 4; ++r) s[qt][kt][r] = __builtin_amdgcn_exp2f(s[qt][kt][r]);
+                    rs2 += f32x2{s[qt][kt][0], s[qt][kt][1]};
+                    rs2 += f32x2{s[qt][kt][2], s[qt][kt][3]};
+                }
+                l_run[qt] += rs2.x + rs2.y;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    union { unsigned u[4]; bf16x8 v; } pk;
+                    pk.u[0] = pack16<DT>(s[qt][2 * kk][0], s[qt][2 * kk][1]);
+                    pk.u[1] = pack16<DT>(s[qt][2 * kk][2], s[qt][2 * kk][3]);
+                    pk.u[2] = pack16<DT>(s[qt][2 * kk + 1][0], s[qt][2 * kk + 1][1]);
+                    pk.u[3] = pack16<DT>(s[qt][2 * kk + 1][2], s[qt][2 * kk + 1][3]);
+                    pf[qt][kk] = pk.v;
+                }
             }
-            // P fragment for k-step kk: element j<4 -> key (2kk)*16 + g*4 + j, j>=4 -> key (2kk+1)*16 + g*4 + j-4
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                union { unsigned u[4]; bf16x8 v; } pk;
-                pk.u[0] = pack16<DT>(s[qt][2 * kk][0], s[qt][2 * kk][1]);
-                pk.u[1] = pack16<DT>(s[qt][2 * kk][2], s[qt][2 * kk][3]);
-                pk.u[2] = pack16<DT>(s[qt][2 * kk + 1][0], s[qt][2 * kk + 1][1]);
-                pk.u[3] = pack16<DT>(s[qt][2 * kk + 1][2], s[qt][2 * kk + 1][3]);
-                pf[qt][kk] = pk.v;
+        } else {
+    #pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                float mx = s[qt][0][0];
+    #pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qt][kt][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m_run[qt], mx);
+                const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * a.scale_log2e);
+                const float mb = m_new * a.scale_log2e;
+                m_run[qt] = m_new;
+                float rs = 0.f;
+    #pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(s[qt][kt][r] * a.scale_log2e - mb);
+                        s[qt][kt][r] = p;
+                        rs += p;
+                    }
+                l_run[qt] = l_run[qt] * alpha + rs;
+                if (!__all(alpha == 1.0f)) {       // exact skip: no row of this wave raised its running max
+    #pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
+                }
+                // P fragment for k-step kk: element j<4 -> key (2kk)*16 + g*4 + j, j>=4 -> key (2kk+1)*16 + g*4 + j-4
+    #pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    union { unsigned u[4]; bf16x8 v; } pk;
+                    pk.u[0] = pack16<DT>(s[qt][2 * kk][0], s[qt][2 * kk][1]);
+                    pk.u[1] = pack16<DT>(s[qt][2 * kk][2], s[qt][2 * kk][3]);
+                    pk.u[2] = pack16<DT>(s[qt][2 * kk + 1][0], s[qt][2 * kk + 1][1]);
+                    pk.u[3] = pack16<DT>(s[qt][2 * kk + 1][2], s[qt][2 * kk + 1][3]);
+                    pf[qt][kk] = pk.v;
+                }
             }
         }
 
@@ -265,9 +327,10 @@ k_rope2d(bf16_t *__restrict__ X, const int *__restrict__ pos_yx, const float *__
 
 extern "C" {
 
-int m3_attention_dt(const void *Q, const void *K, const void *V, void *O, int q_row_stride, int kv_row_stride,
-                    int o_row_stride, int64_t q_batch_stride, int64_t kv_batch_stride, int64_t o_batch_stride,
-                    int nbatch, int heads, int Tq, int Tk, int kv_batch_shift, float scale, int dtype, void *stream) {
+static int attention_launch(const void *Q, const void *K, const void *V, void *O, int q_row_stride, int kv_row_stride,
+                            int o_row_stride, int64_t q_batch_stride, int64_t kv_batch_stride, int64_t o_batch_stride,
+                            int nbatch, int heads, int Tq, int Tk, int kv_batch_shift, float scale, int dtype, bool pre,
+                            void *stream) {
     M3_REQUIRE(Q && K && V && O && nbatch > 0 && heads > 0 && Tq > 0 && Tk > 0);
     M3_REQUIRE((dtype == DT_BF16 || dtype == DT_F16) && ((int64_t)Tq / 64 + 1) * heads * nbatch < (1ll << 31));
     M3_REQUIRE(q_row_stride % 8 == 0 && kv_row_stride % 8 == 0 && o_row_stride % 4 == 0);
@@ -281,15 +344,31 @@ int m3_attention_dt(const void *Q, const void *K, const void *V, void *O, int q_
     const int64_t wg128 = (int64_t)m3_cdiv(Tq, QROWS) * heads * nbatch;
     const int64_t wg64 = (int64_t)m3_cdiv(Tq, 64) * heads * nbatch;
     hipStream_t st = (hipStream_t)stream;
-    if (wg128 >= 512) {
-        if (dtype == DT_F16) hipLaunchKernelGGL((k_attn<2, DT_F16>), dim3((unsigned)wg128), dim3(kThreads), 0, st, a);
-        else hipLaunchKernelGGL((k_attn<2, DT_BF16>), dim3((unsigned)wg128), dim3(kThreads), 0, st, a);
-    } else {
-        if (dtype == DT_F16) hipLaunchKernelGGL((k_attn<1, DT_F16>), dim3((unsigned)wg64), dim3(kThreads), 0, st, a);
-        else hipLaunchKernelGGL((k_attn<1, DT_BF16>), dim3((unsigned)wg64), dim3(kThreads), 0, st, a);
-    }
+#define M3_ATTN(QTV, GRID)                                                                                  \
+    do {                                                                                                    \
+        if (dtype == DT_F16) { if (pre) hipLaunchKernelGGL((k_attn<QTV, DT_F16, true>), dim3((unsigned)(GRID)), dim3(kThreads), 0, st, a); \
+                               else hipLaunchKernelGGL((k_attn<QTV, DT_F16, false>), dim3((unsigned)(GRID)), dim3(kThreads), 0, st, a); } \
+        else { if (pre) hipLaunchKernelGGL((k_attn<QTV, DT_BF16, true>), dim3((unsigned)(GRID)), dim3(kThreads), 0, st, a);              \
+               else hipLaunchKernelGGL((k_attn<QTV, DT_BF16, false>), dim3((unsigned)(GRID)), dim3(kThreads), 0, st, a); }               \
+    } while (0)
+    if (wg128 >= 512) M3_ATTN(2, wg128); else M3_ATTN(1, wg64);
+#undef M3_ATTN
     M3_CHECK_LAUNCH("m3_attention");
     return M3_OK;
+}
+
+int m3_attention_dt(const void *Q, const void *K, const void *V, void *O, int q_row_stride, int kv_row_stride,
+                    int o_row_stride, int64_t q_batch_stride, int64_t kv_batch_stride, int64_t o_batch_stride,
+                    int nbatch, int heads, int Tq, int Tk, int kv_batch_shift, float scale, int dtype, void *stream) {
+    return attention_launch(Q, K, V, O, q_row_stride, kv_row_stride, o_row_stride, q_batch_stride, kv_batch_stride,
+                            o_batch_stride, nbatch, heads, Tq, Tk, kv_batch_shift, scale, dtype, false, stream);
+}
+// q carries softmax scale * log2(e) already (m3_gemm_rope_dt's q_scale): O = softmax2(Q K^T) V with p = 2^(s - m)
+int m3_attention_prescaled_dt(const void *Q, const void *K, const void *V, void *O, int q_row_stride, int kv_row_stride,
+                              int o_row_stride, int64_t q_batch_stride, int64_t kv_batch_stride, int64_t o_batch_stride,
+                              int nbatch, int heads, int Tq, int Tk, int kv_batch_shift, int dtype, void *stream) {
+    return attention_launch(Q, K, V, O, q_row_stride, kv_row_stride, o_row_stride, q_batch_stride, kv_batch_stride,
+                            o_batch_stride, nbatch, heads, Tq, Tk, kv_batch_shift, 1.0f, dtype, true, stream);
 }
 int m3_attention_bf16(const void *Q, const void *K, const void *V, void *O, int q_row_stride, int kv_row_stride,
                       int o_row_stride, int64_t q_batch_stride, int64_t kv_batch_stride, int64_t o_batch_stride,

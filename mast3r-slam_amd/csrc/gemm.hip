@@ -360,14 +360,16 @@ int m3_gemm_bf16(const void *A, const void *W, const float *bias, void *C, const
 }
 
 int m3_gemm_rope_dt(const void *A, const void *W, const float *bias, void *C, int M, int N, int K, int ldc,
-                    const float *rope_tok, int tokens_per_image, int rope_cols, int dtype, void *stream) {
+                    const float *rope_tok, int tokens_per_image, int rope_cols, int q_cols, float q_scale, int dtype,
+                    void *stream) {
     M3_REQUIRE(A && W && C && rope_tok && M > 0 && N > 0 && K > 0 && tokens_per_image > 0 && dt_ok(dtype));
-    M3_REQUIRE((reinterpret_cast<size_t>(rope_tok) & 15) == 0);
+    M3_REQUIRE((reinterpret_cast<size_t>(rope_tok) & 15) == 0 && q_cols >= 0 && q_cols <= rope_cols && q_cols % 64 == 0);
     M3_REQUIRE(K % BK == 0 && N % 64 == 0 && ldc >= N && ldc % 4 == 0 && rope_cols % 64 == 0 && rope_cols <= N);
     GemmArgs a{};
     a.A = (const bf16_t *)A; a.W = (const bf16_t *)W; a.bias = bias; a.C = C;
     a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.dt = dtype;
     a.rope_tok = rope_tok; a.tokens_per_image = tokens_per_image; a.rope_cols = rope_cols;
+    a.q_cols = q_cols; a.q_scale = q_scale;
     const int tile = pick_tile(M, N);
     if (tile >= 192) return m3_launch_gemm256_dense(a, EPI_BF16_ROPE, tile, (hipStream_t)stream);
     if (tile == 64) return launch<0, 64>(a, EPI_BF16_ROPE, (hipStream_t)stream);
@@ -375,7 +377,7 @@ int m3_gemm_rope_dt(const void *A, const void *W, const float *bias, void *C, in
 }
 int m3_gemm_bf16_rope(const void *A, const void *W, const float *bias, void *C, int M, int N, int K, int ldc,
                       const float *rope_tok, int tokens_per_image, int rope_cols, void *stream) {
-    return m3_gemm_rope_dt(A, W, bias, C, M, N, K, ldc, rope_tok, tokens_per_image, rope_cols, DT_BF16, stream);
+    return m3_gemm_rope_dt(A, W, bias, C, M, N, K, ldc, rope_tok, tokens_per_image, rope_cols, 0, 1.0f, DT_BF16, stream);
 }
 
 // Two GEMMs of identical shape in one launch (the two decoder branches / the two heads):
@@ -383,19 +385,20 @@ int m3_gemm_bf16_rope(const void *A, const void *W, const float *bias, void *C, 
 int m3_gemm_grouped2_dt(const void *A, const void *W0, const void *W1, const float *bias0, const float *bias1,
                         void *C, const void *R, int M, int N, int K, int ldc, int64_t a_gstride,
                         int64_t c_gstride, int epilogue, const float *rope_tok,
-                        int tokens_per_image, int rope_cols, int dtype, void *stream) {
+                        int tokens_per_image, int rope_cols, int q_cols, float q_scale, int dtype, void *stream) {
     M3_REQUIRE(A && W0 && W1 && C && M > 0 && N > 0 && K > 0 && dt_ok(dtype));
     M3_REQUIRE(K % BK == 0 && N % 4 == 0 && ldc >= N && ldc % 4 == 0);
     M3_REQUIRE(!((epilogue == EPI_F32_ACCUM || epilogue == EPI_BF16_ADD) && !R));
     M3_REQUIRE((bias0 == nullptr) == (bias1 == nullptr));
     if (epilogue == EPI_BF16_ROPE)
         M3_REQUIRE(rope_tok && (reinterpret_cast<size_t>(rope_tok) & 15) == 0 && tokens_per_image > 0 && N % 64 == 0 &&
-                   rope_cols % 64 == 0 && rope_cols <= N);
+                   rope_cols % 64 == 0 && rope_cols <= N && q_cols >= 0 && q_cols <= rope_cols && q_cols % 64 == 0);
     GemmArgs a{};
     a.A = (const bf16_t *)A; a.W = (const bf16_t *)W0; a.W2 = (const bf16_t *)W1; a.bias = bias0; a.bias2 = bias1;
     a.C = C; a.R = R; a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.dt = dtype;
     a.a_gstride = a_gstride; a.c_gstride = c_gstride; a.groups = 2;
     a.rope_tok = rope_tok; a.tokens_per_image = tokens_per_image; a.rope_cols = rope_cols;
+    a.q_cols = q_cols; a.q_scale = q_scale;
     const int tile = pick_tile(M, N, 2);
     if (tile >= 192) return m3_launch_gemm256_dense(a, epilogue, tile, (hipStream_t)stream);
     if (tile == 64) return launch<0, 64>(a, epilogue, (hipStream_t)stream);
@@ -406,7 +409,7 @@ int m3_gemm_bf16_grouped2(const void *A, const void *W0, const void *W1, const f
                           int64_t c_gstride, int epilogue, const float *rope_tok,
                           int tokens_per_image, int rope_cols, void *stream) {
     return m3_gemm_grouped2_dt(A, W0, W1, bias0, bias1, C, R, M, N, K, ldc, a_gstride, c_gstride, epilogue, rope_tok,
-                               tokens_per_image, rope_cols, DT_BF16, stream);
+                               tokens_per_image, rope_cols, 0, 1.0f, DT_BF16, stream);
 }
 
 int64_t m3_conv3x3_splitk_bytes(int B, int H, int Wd, int Cin, int Cout, int stride) {

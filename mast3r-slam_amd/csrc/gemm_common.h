@@ -106,6 +106,8 @@ struct GemmArgs {
     // fused RoPE-2D epilogue (EPI_BF16_ROPE): columns < rope_cols are 64-wide heads to rotate
     const float *rope_tok;  // [tokens_per_image, 2 (y|x), 2 (cos|sin), 16]
     int tokens_per_image, rope_cols;
+    int q_cols;             // columns < q_cols (the q heads) are multiplied by q_scale after the rotation, before the
+    float q_scale;          // 16-bit rounding: softmax scale * log2(e) folded into q (attention then needs no per-score FMA)
     // grouped launch (blockIdx.y = group): group 1 uses W2/bias2 and A/C/R advanced by the strides
     const bf16_t *W2;
     const float *bias2;
@@ -213,8 +215,12 @@ __device__ __forceinline__ void rope_apply(const GemmArgs &g, f32x4 *t, const Ro
         }
         const f32x2 c0 = {cf[blk].c.x, cf[blk].c.y}, c1 = {cf[blk].c.z, cf[blk].c.w};
         const f32x2 s0 = {cf[blk].s.x, cf[blk].s.y}, s1 = {cf[blk].s.z, cf[blk].s.w};
-        const f32x2 ra0 = __builtin_elementwise_fma(a0, c0, -(b0 * s0)), ra1 = __builtin_elementwise_fma(a1, c1, -(b1 * s1));
-        const f32x2 rb0 = __builtin_elementwise_fma(b0, c0, a0 * s0), rb1 = __builtin_elementwise_fma(b1, c1, a1 * s1);
+        f32x2 ra0 = __builtin_elementwise_fma(a0, c0, -(b0 * s0)), ra1 = __builtin_elementwise_fma(a1, c1, -(b1 * s1));
+        f32x2 rb0 = __builtin_elementwise_fma(b0, c0, a0 * s0), rb1 = __builtin_elementwise_fma(b1, c1, a1 * s1);
+        if (n_base + 32 * blk < g.q_cols) {                             // wave-uniform
+            const f32x2 qs = {g.q_scale, g.q_scale};
+            ra0 = ra0 * qs; ra1 = ra1 * qs; rb0 = rb0 * qs; rb1 = rb1 * qs;
+        }
         a = f32x4{ra0.x, ra0.y, ra1.x, ra1.y}; b = f32x4{rb0.x, rb0.y, rb1.x, rb1.y};
     }
 }

@@ -298,11 +298,12 @@ class Mast3rFull:
     def _self_attn(self, xn, p, heads, nb, t, rtok):
         P = self.P
         c = heads * 64
-        qkv = ops.gemm_rope(xn, P[p + ".qkv.w"], P[p + ".qkv.b"], rtok, 2 * c)          # [M,3c], q|k rotated
+        # [M,3c], q|k rotated; q additionally carries softmax scale * log2(e) (folded in before the 16-bit rounding)
+        qkv = ops.gemm_rope(xn, P[p + ".qkv.w"], P[p + ".qkv.b"], rtok, 2 * c, q_cols=c, q_scale=ops.QK_PRESCALE)
         out = torch.empty((nb * t, c), dtype=xn.dtype, device=xn.device)
         ops.attention(qkv, qkv[:, c:], qkv[:, 2 * c:], out, nbatch=nb, heads=heads, tq=t, tk=t,
                       q_row_stride=3 * c, kv_row_stride=3 * c, o_row_stride=c, q_batch_stride=t * 3 * c,
-                      kv_batch_stride=t * 3 * c, o_batch_stride=t * c)
+                      kv_batch_stride=t * 3 * c, o_batch_stride=t * c, prescaled=True)
         return out
 
     # ------------------------------------------------------------------ encoder
@@ -370,21 +371,21 @@ class Mast3rFull:
             # self-attention
             xn = ops.layernorm_grouped2(x, W(i, "norm1.g")[0], W(i, "norm1.b")[0], W(i, "norm1.g")[1], W(i, "norm1.b")[1], dtype=dt)
             qkv = ops.gemm_grouped2(xn, *W(i, "attn.qkv.w"), *W(i, "attn.qkv.b"), ops.EPI_BF16_ROPE,
-                                    rope=(rtok, 2 * D)).view(2 * m, 3 * D)
+                                    rope=(rtok, 2 * D, D, ops.QK_PRESCALE)).view(2 * m, 3 * D)
             a = torch.empty((2, m, D), dtype=dt, device=dev)
             ops.attention(qkv, qkv[:, D:], qkv[:, 2 * D:], a, nbatch=2 * npairs, heads=heads, tq=t, tk=t,
                           q_row_stride=3 * D, kv_row_stride=3 * D, o_row_stride=D, q_batch_stride=t * 3 * D,
-                          kv_batch_stride=t * 3 * D, o_batch_stride=t * D)
+                          kv_batch_stride=t * 3 * D, o_batch_stride=t * D, prescaled=True)
             ops.gemm_grouped2(a, *W(i, "attn.proj.w"), *W(i, "attn.proj.b"), ops.EPI_F32_ACCUM, out=x, resid=x)
             # cross-attention
             xn = ops.layernorm_grouped2(x, W(i, "norm2.g")[0], W(i, "norm2.b")[0], W(i, "norm2.g")[1], W(i, "norm2.b")[1], dtype=dt)
             q = ops.gemm_grouped2(xn, *W(i, "cross_attn.projq.w"), *W(i, "cross_attn.projq.b"), ops.EPI_BF16_ROPE,
-                                  rope=(rtok, D)).view(2 * m, D)
+                                  rope=(rtok, D, D, ops.QK_PRESCALE)).view(2 * m, D)
             kvf = kv.view(2 * m, 2 * D)
             a = torch.empty((2, m, D), dtype=dt, device=dev)
             ops.attention(q, kvf, kvf[:, D:], a, nbatch=2 * npairs, heads=heads, tq=t, tk=t, q_row_stride=D,
                           kv_row_stride=2 * D, o_row_stride=D, q_batch_stride=t * D, kv_batch_stride=t * 2 * D,
-                          o_batch_stride=t * D)
+                          o_batch_stride=t * D, prescaled=True)
             ops.gemm_grouped2(a, *W(i, "cross_attn.proj.w"), *W(i, "cross_attn.proj.b"), ops.EPI_F32_ACCUM, out=x, resid=x)
             # MLP
             xn = ops.layernorm_grouped2(x, W(i, "norm3.g")[0], W(i, "norm3.b")[0], W(i, "norm3.g")[1], W(i, "norm3.b")[1], dtype=dt)

@@ -104,7 +104,10 @@ def rope_token_table(pos_yx, cos_sin):
     return cos_sin[pos_yx.long()].transpose(-1, -2).contiguous()
 
 
-def gemm_rope(a, w, bias, rope_tok, rope_cols: int):
+QK_PRESCALE = 0.125 * 1.4426950408889634     # softmax scale (head dim 64) * log2(e), folded into q by the RoPE epilogue
+
+
+def gemm_rope(a, w, bias, rope_tok, rope_cols: int, q_cols: int = 0, q_scale: float = 1.0):
     """16-bit out[M,N] = a @ w.T + bias with RoPE-2D applied to the 64-wide heads in columns < rope_cols;
     rope_tok f32 [tokens_per_image,2,2,16] (rope_token_table)."""
     rope_tok = _ffi.check(rope_tok, torch.float32, "rope_tok", (None, 2, 2, 16))
@@ -117,7 +120,7 @@ def gemm_rope(a, w, bias, rope_tok, rope_cols: int):
     out = torch.empty((m, n), dtype=a.dtype, device=a.device)
     e0 = _prof_begin()
     _ffi.call("m3_gemm_rope_dt", _ffi.ptr(a), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(out), m, n, k, n,
-              _ffi.ptr(rope_tok), tokens_per_image, rope_cols, dt, _ffi.stream_ptr())
+              _ffi.ptr(rope_tok), tokens_per_image, rope_cols, int(q_cols), float(q_scale), dt, _ffi.stream_ptr())
     _prof_end(e0, _gemm_kind(m, n), 2.0 * m * n * k, 2.0 * (m * k + n * k + m * n))
     return out
 
@@ -247,17 +250,23 @@ def dpt_tail(x: torch.Tensor, w: torch.Tensor, bias, w4: torch.Tensor, b4: torch
 
 
 def attention(q, k, v, out, *, nbatch, heads, tq, tk, q_row_stride, kv_row_stride, o_row_stride,
-              q_batch_stride, kv_batch_stride, o_batch_stride, kv_batch_shift=0, scale=0.125):
-    """Fused MHA (head dim 64).  q/k/v/out are (views into) bf16 device tensors; the strides are in
-    elements, so q, k, v may be column slices of one projection buffer."""
+              q_batch_stride, kv_batch_stride, o_batch_stride, kv_batch_shift=0, scale=0.125, prescaled=False):
+    """Fused MHA (head dim 64).  q/k/v/out are (views into) 16-bit device tensors; the strides are in
+    elements, so q, k, v may be column slices of one projection buffer.  prescaled=True: q already carries
+    scale * log2(e) (gemm_rope(..., q_cols, q_scale=QK_PRESCALE)); `scale` is then ignored."""
     for name, t in (("q", q), ("k", k), ("v", v), ("out", out)):
         if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype in H16):
             raise TypeError(f"{name}: expected a bf16 / fp16 tensor on the ROCm device")
     dt = _same16(q, k, v, out)
     e0 = _prof_begin()
-    _ffi.call("m3_attention_dt", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q_row_stride,
-              kv_row_stride, o_row_stride, q_batch_stride, kv_batch_stride, o_batch_stride, nbatch, heads, tq, tk,
-              kv_batch_shift, float(scale), dt, _ffi.stream_ptr())
+    if prescaled:
+        _ffi.call("m3_attention_prescaled_dt", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q_row_stride,
+                  kv_row_stride, o_row_stride, q_batch_stride, kv_batch_stride, o_batch_stride, nbatch, heads, tq, tk,
+                  kv_batch_shift, dt, _ffi.stream_ptr())
+    else:
+        _ffi.call("m3_attention_dt", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q_row_stride,
+                  kv_row_stride, o_row_stride, q_batch_stride, kv_batch_stride, o_batch_stride, nbatch, heads, tq, tk,
+                  kv_batch_shift, float(scale), dt, _ffi.stream_ptr())
     _prof_end(e0, "attention", 4.0 * nbatch * heads * tq * tk * 64, 2.0 * nbatch * heads * 64 * (2 * tq + 2 * tk))
     return out
 
@@ -373,7 +382,7 @@ def add(a, b):
 
 def gemm_grouped2(a, w0, w1, b0, b1, epi=EPI_BF16, out=None, resid=None, rope=None):
     """Two same-shape GEMMs in one launch.  a [2,M,K] bf16, weights [N,K] x2 -> out [2,M,N].
-    rope = (rope_tok [T,2,2,16] f32, rope_cols) with epi=EPI_BF16_ROPE."""
+    rope = (rope_tok [T,2,2,16] f32, rope_cols[, q_cols, q_scale]) with epi=EPI_BF16_ROPE."""
     a = _ffi.check(a, H16, "a")
     if a.dim() != 3 or a.shape[0] != 2:
         raise ValueError(f"a must be [2,M,K], got {tuple(a.shape)}")
@@ -390,14 +399,14 @@ def gemm_grouped2(a, w0, w1, b0, b1, epi=EPI_BF16, out=None, resid=None, rope=No
     ldc = out.shape[2]                                           # > n: the extra columns (zero padding) are left alone
     if resid is not None and (resid.dtype != odt or tuple(resid.shape) != tuple(out.shape) or not resid.is_contiguous()):
         raise ValueError("bad `resid`")
-    rtok, rc = rope if rope is not None else (None, 0)
+    rtok, rc, qc, qs = (tuple(rope) + (0, 1.0))[:4] if rope is not None else (None, 0, 0, 1.0)
     tpi = 0
     if rtok is not None:
         rtok = _ffi.check(rtok, torch.float32, "rope_tok", (None, 2, 2, 16))
         tpi = rtok.shape[0]
     e0 = _prof_begin()
     _ffi.call("m3_gemm_grouped2_dt", _ffi.ptr(a), _ffi.ptr(w0), _ffi.ptr(w1), _ffi.ptr(b0), _ffi.ptr(b1), _ffi.ptr(out),
-              _ffi.ptr(resid), m, n, k, ldc, m * k, m * ldc, epi, _ffi.ptr(rtok), tpi, rc, dt, _ffi.stream_ptr())
+              _ffi.ptr(resid), m, n, k, ldc, m * k, m * ldc, epi, _ffi.ptr(rtok), tpi, rc, int(qc), float(qs), dt, _ffi.stream_ptr())
     _prof_end(e0, _gemm_kind(m, n, 2), 4.0 * m * n * k,
               2.0 * (2.0 * (m * k + n * k) + out.element_size() * m * n * (1 if resid is None else 2)))
     return out

@@ -519,3 +519,34 @@ def test_dpt_tail_direct_convolution(dev, dt, upsample, bhw):
     tol = 5e-6 if not upsample else TOL16[dt]                          # the interpolated map is rounded to 16 bits once
     assert _rel(pts, r[..., :3] / dn.clip(min=1e-8) * torch.expm1(dn)) < tol
     assert _rel(conf, 1 + torch.exp(r[..., 3])) < tol
+
+
+@pytest.mark.parametrize("dt", DT16)
+@pytest.mark.parametrize("tq_tk_b_h", [(1024, 1024, 16, 16), (256, 256, 2, 3), (672, 672, 2, 4), (200, 150, 2, 3)])
+def test_attention_prescaled_deferred_max(dev, dt, tq_tk_b_h):
+    """m3_attention_prescaled_dt: q carries scale * log2(e), the running reference maximum enters the S^T MFMA as its
+    accumulator initialiser and is raised only when a tile outgrows it by 2^8.  Forced branches (guide rule 26): a key
+    far down the sequence that dominates one query (rescale at a late tile), a query whose first tile holds its
+    maximum (never rescaled), and growth BELOW the threshold (deferred); full-tensor fp64-style reference."""
+    tq, tk, b, h = tq_tk_b_h
+    g = torch.Generator().manual_seed(tq + h)
+    c = h * 64
+    q = torch.randn(b, tq, c, generator=g)
+    k = torch.randn(b, tk, c, generator=g)
+    v = torch.randn(b, tk, c, generator=g)
+    q[0, 5, :64] = 6.0 * k[0, tk - 3, :64]                      # query 5 / head 0: one late key dominates (score ~ 6 * 64 * 0.18 >> 8)
+    q[0, 7, :64] = 6.0 * k[0, 2, :64]                           # query 7: the dominating key is in the FIRST tile
+    q[0, 9, :64] = 0.35 * k[0, min(70, tk - 1), :64]            # query 9: mild growth in a later tile (below the deferral threshold)
+    qs = (q * ops.QK_PRESCALE).to(dt)
+    kd, vd = k.to(dt), v.to(dt)
+    out = torch.full((b, tq, c), 3.0, dtype=dt, device=dev)
+    ops.attention(qs.to(dev), kd.to(dev), vd.to(dev), out, nbatch=b, heads=h, tq=tq, tk=tk, q_row_stride=c, kv_row_stride=c,
+                  o_row_stride=c, q_batch_stride=tq * c, kv_batch_stride=tk * c, o_batch_stride=tq * c, prescaled=True)
+    qf = qs.double().view(b, tq, h, 64).transpose(1, 2)
+    kf = kd.double().view(b, tk, h, 64).transpose(1, 2)
+    vf = vd.double().view(b, tk, h, 64).transpose(1, 2)
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * math.log(2.0), -1) @ vf).transpose(1, 2).reshape(b, tq, c)
+    tol = 4e-3 if dt == torch.bfloat16 else 6e-4
+    assert torch.isfinite(out).all() and _rel(out, ref) < tol
+    for row in (5, 7, 9):                                        # the forced rows individually (a whole-tensor norm would hide them)
+        assert _rel(out[0, row], ref[0, row]) < 2 * tol, row

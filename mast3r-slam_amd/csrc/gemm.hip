@@ -332,6 +332,12 @@ int run_split(const GemmArgs &a, int S, int epi, void *ws, hipStream_t st) {
 int m3_launch_gemm256_dense(const GemmArgs &a, int epi, int bn, hipStream_t st);
 int m3_launch_gemm256_conv(const GemmArgs &a, int epi, hipStream_t st);
 
+// Large dense tiles go to the ping-pong kernel.  (A one-wave-per-SIMD 256x256 variant with AGPR accumulators was built
+// and measured in round 2 - bit-identical, 20-80 % slower: tools/experiments/gemm4w.hip)
+static int launch_dense_big(const GemmArgs &a, int epi, int tile, hipStream_t st) {
+    return m3_launch_gemm256_dense(a, epi, tile, st);
+}
+
 extern "C" {
 
 int m3_gemm_pick_tile(int M, int N, int groups) {
@@ -350,7 +356,7 @@ int m3_gemm_dt(const void *A, const void *W, const float *bias, void *C, const v
     a.A = (const bf16_t *)A; a.W = (const bf16_t *)W; a.bias = bias; a.C = C; a.R = R;
     a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.dt = dtype;
     const int tile = pick_tile(M, N);
-    if (tile >= 192) return m3_launch_gemm256_dense(a, epilogue, tile, (hipStream_t)stream);
+    if (tile >= 192) return launch_dense_big(a, epilogue, tile, (hipStream_t)stream);
     if (tile == 64) return launch<0, 64>(a, epilogue, (hipStream_t)stream);
     return launch<0>(a, epilogue, (hipStream_t)stream);
 }
@@ -371,7 +377,7 @@ int m3_gemm_rope_dt(const void *A, const void *W, const float *bias, void *C, in
     a.rope_tok = rope_tok; a.tokens_per_image = tokens_per_image; a.rope_cols = rope_cols;
     a.q_cols = q_cols; a.q_scale = q_scale;
     const int tile = pick_tile(M, N);
-    if (tile >= 192) return m3_launch_gemm256_dense(a, EPI_BF16_ROPE, tile, (hipStream_t)stream);
+    if (tile >= 192) return launch_dense_big(a, EPI_BF16_ROPE, tile, (hipStream_t)stream);
     if (tile == 64) return launch<0, 64>(a, EPI_BF16_ROPE, (hipStream_t)stream);
     return launch<0>(a, EPI_BF16_ROPE, (hipStream_t)stream);
 }
@@ -400,7 +406,7 @@ int m3_gemm_grouped2_dt(const void *A, const void *W0, const void *W1, const flo
     a.rope_tok = rope_tok; a.tokens_per_image = tokens_per_image; a.rope_cols = rope_cols;
     a.q_cols = q_cols; a.q_scale = q_scale;
     const int tile = pick_tile(M, N, 2);
-    if (tile >= 192) return m3_launch_gemm256_dense(a, epilogue, tile, (hipStream_t)stream);
+    if (tile >= 192) return launch_dense_big(a, epilogue, tile, (hipStream_t)stream);
     if (tile == 64) return launch<0, 64>(a, epilogue, (hipStream_t)stream);
     return launch<0>(a, epilogue, (hipStream_t)stream);
 }

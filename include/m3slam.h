@@ -68,6 +68,12 @@ int m3_iter_proj(const float *rays_with_grad, const float *pts3d_norm, const flo
 int m3_refine_matches(const float *D11, const float *D21, const int32_t *p_in, int32_t *p_out,
                       int B, int H, int W, int D, int N, int radius, int dilation_max,
                       int chained, void *stream);
+/* Same with both descriptor arrays stored as IEEE half ("fp16 features", BASELINE configs[4]; halves the
+ * kernel's HBM bytes).  Values are widened to fp32 exactly and scored with the same fp32 sequence,
+ * so p_out equals m3_refine_matches on the half-rounded descriptors bit for bit. */
+int m3_refine_matches_f16(const void *D11, const void *D21, const int32_t *p_in, int32_t *p_out,
+                          int B, int H, int W, int D, int N, int radius, int dilation_max,
+                          int chained, void *stream);
 
 /* Tail of match_iterative_proj (matching.py:436-461): gather X11 at clip(p), 3-D distance
  * test, AND with valid_proj, idx = u + W*v.  p_f32 (iter_proj output, truncated like

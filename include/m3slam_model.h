@@ -196,6 +196,9 @@ int m3_pts_post(const float *in, float *pts, float *conf, int64_t P, void *strea
  * (L2-normalised), desc_conf [B,H,W] = exp(channel 24). */
 int m3_desc_post(const void *in, float *desc, float *dconf, int B, int H, int W, void *stream);
 int m3_desc_post_dt(const void *in, float *desc, float *dconf, int B, int H, int W, int dtype, void *stream);
+/* Same with the descriptors stored as IEEE half [B,H,W,24] ("fp16 features", BASELINE configs[4]): the fp32 value
+ * rounded once to nearest-even.  desc_conf stays fp32. */
+int m3_desc_post_f16(const void *in, void *desc_f16, float *dconf, int B, int H, int W, int dtype, void *stream);
 
 #ifdef __cplusplus
 }

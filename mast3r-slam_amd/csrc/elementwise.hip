@@ -219,10 +219,11 @@ k_pts_post(const float *__restrict__ in, float *__restrict__ pts, float *__restr
 }
 
 // feature-MLP output [B*gh*gw, 25*256] bf16 (column c*256 + dy*16 + dx) -> pixel shuffle(16) ->
-// desc [B,H,W,24] f32 L2-normalised, desc_conf [B,H,W] f32 = exp(channel 24).  One thread per pixel.
-template <int DT>
+// desc [B,H,W,24] L2-normalised, desc_conf [B,H,W] f32 = exp(channel 24).  One thread per pixel.
+// F16OUT: the descriptors are stored as IEEE half ("fp16 features", BASELINE configs[4]) - the fp32 value rounded once.
+template <int DT, bool F16OUT>
 __global__ void __launch_bounds__(kThreads)
-k_desc_post(const bf16_t *__restrict__ in, float *__restrict__ desc, float *__restrict__ dconf, int B, int H, int W) {
+k_desc_post(const bf16_t *__restrict__ in, void *__restrict__ desc_out, float *__restrict__ dconf, int B, int H, int W) {
     const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     const int64_t P = (int64_t)B * H * W;
     if (i >= P) return;
@@ -235,9 +236,21 @@ k_desc_post(const bf16_t *__restrict__ in, float *__restrict__ desc, float *__re
 #pragma unroll
     for (int c = 0; c < 24; ++c) n2 += v[c] * v[c];
     const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
-    float4 *o = reinterpret_cast<float4 *>(desc + i * 24);
+    if constexpr (F16OUT) {
+        uint4 *o = reinterpret_cast<uint4 *>(reinterpret_cast<unsigned short *>(desc_out) + i * 24);
 #pragma unroll
-    for (int c = 0; c < 6; ++c) o[c] = make_float4(v[4 * c] * inv, v[4 * c + 1] * inv, v[4 * c + 2] * inv, v[4 * c + 3] * inv);
+        for (int c = 0; c < 3; ++c) {
+            uint32_t w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                w[j] = pack16<DT_F16>(v[8 * c + 2 * j] * inv, v[8 * c + 2 * j + 1] * inv);
+            o[c] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    } else {
+        float4 *o = reinterpret_cast<float4 *>(reinterpret_cast<float *>(desc_out) + i * 24);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) o[c] = make_float4(v[4 * c] * inv, v[4 * c + 1] * inv, v[4 * c + 2] * inv, v[4 * c + 3] * inv);
+    }
     dconf[i] = expf(v[24]);
 }
 
@@ -379,14 +392,24 @@ int m3_pts_post(const float *in, float *pts, float *conf, int64_t P, void *strea
     return M3_OK;
 }
 
-int m3_desc_post_dt(const void *in, float *desc, float *dconf, int B, int H, int W, int dtype, void *stream) {
+static int desc_post_launch(const void *in, void *desc, float *dconf, int B, int H, int W, int dtype, bool f16out, void *stream) {
     M3_REQUIRE(in && desc && dconf && B > 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0);
     M3_DT_OK(dtype);
     const int64_t P = (int64_t)B * H * W;
-    M3_DT_LAUNCH(dtype, k_desc_post, dim3(m3_cdiv(P, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
-                 (const bf16_t *)in, desc, dconf, B, H, W);
+    dim3 grid(m3_cdiv(P, kThreads)), blk(kThreads);
+    hipStream_t st = (hipStream_t)stream;
+#define M3_DP(DTV, F) hipLaunchKernelGGL((k_desc_post<DTV, F>), grid, blk, 0, st, (const bf16_t *)in, desc, dconf, B, H, W)
+    if (dtype == DT_F16) { if (f16out) M3_DP(DT_F16, true); else M3_DP(DT_F16, false); }
+    else { if (f16out) M3_DP(DT_BF16, true); else M3_DP(DT_BF16, false); }
+#undef M3_DP
     M3_CHECK_LAUNCH("m3_desc_post");
     return M3_OK;
+}
+int m3_desc_post_dt(const void *in, float *desc, float *dconf, int B, int H, int W, int dtype, void *stream) {
+    return desc_post_launch(in, desc, dconf, B, H, W, dtype, false, stream);
+}
+int m3_desc_post_f16(const void *in, void *desc_f16, float *dconf, int B, int H, int W, int dtype, void *stream) {
+    return desc_post_launch(in, desc_f16, dconf, B, H, W, dtype, true, stream);
 }
 int m3_desc_post(const void *in, float *desc, float *dconf, int B, int H, int W, void *stream) {
     return m3_desc_post_dt(in, desc, dconf, B, H, W, DT_BF16, stream);

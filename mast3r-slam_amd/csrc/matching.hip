@@ -14,6 +14,7 @@
 //   refine      backends/mpsgraph/kernels.py:496-537 (numpy twin)
 //   epilogue    matching.py:436-461 ; match_simple matching.py:41-90
 #include "common.h"
+#include <hip/hip_fp16.h>
 #include <limits.h>
 
 namespace {
@@ -229,8 +230,43 @@ k_iter_limit(const uint32_t *__restrict__ red, uint32_t *__restrict__ limit, int
 // ---------------------------------------------------------------- refine_matches
 // score = sequential sum_d (q[d]*r[d]) (mul, then add; contraction is off), strict '>' in
 // (dy outer, dx inner) raster order, out-of-bounds candidates skipped.
-template <int D>
-__device__ __forceinline__ void refine_pass(const float *__restrict__ img, const float *q, int H, int W,
+//
+// Descriptor storage TD = float or __half ("fp16 features", BASELINE configs[4]): half descriptors are widened to
+// fp32 exactly (every fp16 value is an fp32 value) and the arithmetic is the same fp32 sequence, so the result is
+// bit-identical to the fp32 path - and to the oracle - run on the half-rounded descriptors; HBM traffic halves
+// (29.3 instead of 54.5 MB per 512x512 map).
+template <typename TD> struct DescIO;
+template <> struct DescIO<float> {
+    static constexpr int kVec = 4;                             // elements per 16-byte load
+    __device__ static __forceinline__ void load16(const float *p, float *o) {
+        const float4 v = *reinterpret_cast<const float4 *>(p);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+    __device__ static __forceinline__ float load1(const float *p) { return *p; }
+};
+template <> struct DescIO<__half> {
+    static constexpr int kVec = 8;
+    __device__ static __forceinline__ void load16(const __half *p, float *o) {
+        const uint4 u = *reinterpret_cast<const uint4 *>(p);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[2 * i] = __half2float(__ushort_as_half((unsigned short)(w[i] & 0xffffu)));
+            o[2 * i + 1] = __half2float(__ushort_as_half((unsigned short)(w[i] >> 16)));
+        }
+    }
+    __device__ static __forceinline__ float load1(const __half *p) { return __half2float(*p); }
+};
+
+template <int D, typename TD>
+__device__ __forceinline__ void load_desc(const TD *__restrict__ p, float *q) {
+    constexpr int V = DescIO<TD>::kVec;
+#pragma unroll
+    for (int k = 0; k < D / V; ++k) DescIO<TD>::load16(p + k * V, q + k * V);
+}
+
+template <int D, typename TD>
+__device__ __forceinline__ void refine_pass(const TD *__restrict__ img, const float *q, int H, int W,
                                             int radius, int dil, int cx, int cy, int &bx, int &by) {
     float best = -INFINITY;
     bx = cx; by = cy;
@@ -240,46 +276,36 @@ __device__ __forceinline__ void refine_pass(const float *__restrict__ img, const
         for (int dx = -radius; dx <= radius; ++dx) {
             const int nx = cx + dx * dil;
             if (nx < 0 || nx >= W) continue;
-            const float4 *r4 = reinterpret_cast<const float4 *>(img + ((size_t)ny * W + nx) * D);
+            float r[D];
+            load_desc<D, TD>(img + ((size_t)ny * W + nx) * D, r);
             float score = 0.0f;
 #pragma unroll
-            for (int k = 0; k < D / 4; ++k) {
-                const float4 v = r4[k];
-                score = score + q[4 * k + 0] * v.x;
-                score = score + q[4 * k + 1] * v.y;
-                score = score + q[4 * k + 2] * v.z;
-                score = score + q[4 * k + 3] * v.w;
-            }
+            for (int k = 0; k < D; ++k) score = score + q[k] * r[k];
             if (score > best) { best = score; bx = nx; by = ny; }
         }
     }
 }
 
-template <int D>
+template <int D, typename TD>
 __global__ void __launch_bounds__(kThreads)
-k_refine(const float *__restrict__ D11, const float *__restrict__ D21, const int32_t *__restrict__ p_in,
+k_refine(const TD *__restrict__ D11, const TD *__restrict__ D21, const int32_t *__restrict__ p_in,
          int32_t *__restrict__ p_out, int H, int W, int N, int radius, int dil_max, int chained, int tiled) {
     const int b = blockIdx.y;
     const int n = point_of_thread(blockIdx.x, threadIdx.x, W, tiled);
     if (n >= N) return;
     const size_t pt = (size_t)b * N + n;
-    const float *img = D11 + (size_t)b * H * W * D;
+    const TD *img = D11 + (size_t)b * H * W * D;
     float q[D];
-    const float4 *q4 = reinterpret_cast<const float4 *>(D21 + pt * D);
-#pragma unroll
-    for (int k = 0; k < D / 4; ++k) {
-        const float4 v = q4[k];
-        q[4 * k] = v.x; q[4 * k + 1] = v.y; q[4 * k + 2] = v.z; q[4 * k + 3] = v.w;
-    }
+    load_desc<D, TD>(D21 + pt * D, q);
     int cx = p_in[pt * 2 + 0], cy = p_in[pt * 2 + 1];
     int bx = cx, by = cy;
     if (chained) {
         for (int dil = dil_max; dil >= 1; --dil) {
-            refine_pass<D>(img, q, H, W, radius, dil, cx, cy, bx, by);
+            refine_pass<D, TD>(img, q, H, W, radius, dil, cx, cy, bx, by);
             cx = bx; cy = by;
         }
     } else {
-        refine_pass<D>(img, q, H, W, radius, 1, cx, cy, bx, by);
+        refine_pass<D, TD>(img, q, H, W, radius, 1, cx, cy, bx, by);
     }
     p_out[pt * 2 + 0] = bx;
     p_out[pt * 2 + 1] = by;
@@ -291,28 +317,25 @@ k_refine(const float *__restrict__ D11, const float *__restrict__ D21, const int
 // its 49 candidates from there instead of issuing 49 x 6 global float4 gathers (the L1-bound part: 9.9 GB
 // of gather traffic for 8 maps).  Same candidates, same order, same arithmetic -> same bits.  Tiles whose
 // region does not fit (scattered matches) take the global path.  LDS pixel stride D + 4 floats (112 B for
-// D = 24) keeps neighbouring pixels on different banks.
+// D = 24) keeps neighbouring pixels on different banks.  Half descriptors are widened while staging: the
+// LDS image and the inner loop are the fp32 ones.
 constexpr int kRefineLdsBytes = 64 * 1024;
 
-template <int D>
+template <int D, typename TD>
 __global__ void __launch_bounds__(kThreads)
-k_refine_lds(const float *__restrict__ D11, const float *__restrict__ D21, const int32_t *__restrict__ p_in,
+k_refine_lds(const TD *__restrict__ D11, const TD *__restrict__ D21, const int32_t *__restrict__ p_in,
              int32_t *__restrict__ p_out, int H, int W, int N, int radius) {
     extern __shared__ float4 tile[];
     __shared__ int bb[4];
     constexpr int PS4 = D / 4 + 1;                          // float4 per staged pixel
     constexpr int kMaxPix = kRefineLdsBytes / (PS4 * 16);
+    constexpr int V = DescIO<TD>::kVec, CH = D / V;         // 16-byte global chunks per pixel
     const int b = blockIdx.y;
     const int n = point_of_thread(blockIdx.x, threadIdx.x, W, 1);      // N == H*W: every thread has a point
     const size_t pt = (size_t)b * N + n;
-    const float *img = D11 + (size_t)b * H * W * D;
+    const TD *img = D11 + (size_t)b * H * W * D;
     float q[D];
-    const float4 *q4 = reinterpret_cast<const float4 *>(D21 + pt * D);
-#pragma unroll
-    for (int k = 0; k < D / 4; ++k) {
-        const float4 v = q4[k];
-        q[4 * k] = v.x; q[4 * k + 1] = v.y; q[4 * k + 2] = v.z; q[4 * k + 3] = v.w;
-    }
+    load_desc<D, TD>(D21 + pt * D, q);
     const int cx = p_in[pt * 2 + 0], cy = p_in[pt * 2 + 1];
     if (threadIdx.x == 0) { bb[0] = INT_MAX; bb[1] = INT_MIN; bb[2] = INT_MAX; bb[3] = INT_MIN; }
     __syncthreads();
@@ -333,12 +356,15 @@ k_refine_lds(const float *__restrict__ D11, const float *__restrict__ D21, const
     const int rw = x1 - x0 + 1, rh = y1 - y0 + 1;
     int bx = cx, by = cy;
     if (rw > 0 && rh > 0 && (long long)rw * rh <= kMaxPix) {            // uniform over the workgroup
-        const int per_row = rw * (D / 4);
+        const int per_row = rw * CH;
         for (int i = threadIdx.x; i < rh * per_row; i += kThreads) {
             const int ry = i / per_row, rem = i - ry * per_row;
-            const int rx = rem / (D / 4), k = rem - rx * (D / 4);
-            tile[(ry * rw + rx) * PS4 + k] =
-                reinterpret_cast<const float4 *>(img + ((size_t)(y0 + ry) * W + x0 + rx) * D)[k];
+            const int rx = rem / CH, k = rem - rx * CH;
+            float v[V];
+            DescIO<TD>::load16(img + ((size_t)(y0 + ry) * W + x0 + rx) * D + k * V, v);
+            float4 *dst = tile + (ry * rw + rx) * PS4 + k * (V / 4);
+#pragma unroll
+            for (int j = 0; j < V / 4; ++j) dst[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
         }
         __syncthreads();
         float best = -INFINITY;
@@ -362,23 +388,24 @@ k_refine_lds(const float *__restrict__ D11, const float *__restrict__ D21, const
             }
         }
     } else {
-        refine_pass<D>(img, q, H, W, radius, 1, cx, cy, bx, by);
+        refine_pass<D, TD>(img, q, H, W, radius, 1, cx, cy, bx, by);
     }
     p_out[pt * 2 + 0] = bx;
     p_out[pt * 2 + 1] = by;
 }
 
 // generic descriptor length (any D >= 1): query re-read from global (L1-resident)
+template <typename TD>
 __global__ void __launch_bounds__(kThreads)
-k_refine_generic(const float *__restrict__ D11, const float *__restrict__ D21,
+k_refine_generic(const TD *__restrict__ D11, const TD *__restrict__ D21,
                  const int32_t *__restrict__ p_in, int32_t *__restrict__ p_out, int H, int W, int D, int N,
                  int radius, int dil_max, int chained) {
     const int b = blockIdx.y;
     const int n = blockIdx.x * kThreads + threadIdx.x;
     if (n >= N) return;
     const size_t pt = (size_t)b * N + n;
-    const float *img = D11 + (size_t)b * H * W * D;
-    const float *q = D21 + pt * D;
+    const TD *img = D11 + (size_t)b * H * W * D;
+    const TD *q = D21 + pt * D;
     int cx = p_in[pt * 2 + 0], cy = p_in[pt * 2 + 1];
     int bx = cx, by = cy;
     const int first = chained ? dil_max : 1;
@@ -391,9 +418,9 @@ k_refine_generic(const float *__restrict__ D11, const float *__restrict__ D21,
             for (int dx = -radius; dx <= radius; ++dx) {
                 const int nx = cx + dx * dil;
                 if (nx < 0 || nx >= W) continue;
-                const float *r = img + ((size_t)ny * W + nx) * D;
+                const TD *r = img + ((size_t)ny * W + nx) * D;
                 float score = 0.0f;
-                for (int k = 0; k < D; ++k) score = score + q[k] * r[k];
+                for (int k = 0; k < D; ++k) score = score + DescIO<TD>::load1(q + k) * DescIO<TD>::load1(r + k);
                 if (score > best) { best = score; bx = nx; by = ny; }
             }
         }
@@ -498,28 +525,45 @@ int m3_iter_proj(const float *rwg, const float *tgt, const float *p_init, float 
     return M3_OK;
 }
 
-int m3_refine_matches(const float *D11, const float *D21, const int32_t *p_in, int32_t *p_out, int B,
-                      int H, int W, int D, int N, int radius, int dilation_max, int chained, void *stream) {
+}  // extern "C"
+
+namespace {
+template <typename TD>
+int refine_launch(const TD *D11, const TD *D21, const int32_t *p_in, int32_t *p_out, int B, int H, int W, int D,
+                  int N, int radius, int dilation_max, int chained, hipStream_t st) {
     M3_REQUIRE(D11 && D21 && p_in && p_out && p_in != p_out);
     M3_REQUIRE(B > 0 && H > 0 && W > 0 && D > 0 && N > 0 && radius >= 0 && B <= 65535);
     M3_REQUIRE((int64_t)H * W < (1ll << 31));
-    hipStream_t st = (hipStream_t)stream;
     const int dmax = dilation_max < 1 ? 1 : dilation_max;
     dim3 grid(m3_cdiv(N, kThreads), B), blk(kThreads);
+    // vector path: 16-byte loads need aligned bases and a pixel stride that is a multiple of 16 bytes
     const bool aligned = (((uintptr_t)D11 | (uintptr_t)D21) & 15) == 0;
     const int tiled = (N == H * W && H % 16 == 0 && W % 16 == 0) ? 1 : 0;
-#define M3_REFINE(DD) hipLaunchKernelGGL(k_refine<DD>, grid, blk, 0, st, D11, D21, p_in, p_out, H, W, N, radius, dmax, chained, tiled)
+#define M3_REFINE(DD) hipLaunchKernelGGL((k_refine<DD, TD>), grid, blk, 0, st, D11, D21, p_in, p_out, H, W, N, radius, dmax, chained, tiled)
     const bool single_pass = !chained || dmax == 1;
     if (aligned && D == 24 && tiled && single_pass && radius <= 4) {
-        hipLaunchKernelGGL(k_refine_lds<24>, grid, blk, kRefineLdsBytes, st, D11, D21, p_in, p_out, H, W, N, radius);
+        hipLaunchKernelGGL((k_refine_lds<24, TD>), grid, blk, kRefineLdsBytes, st, D11, D21, p_in, p_out, H, W, N, radius);
     } else if (aligned && D == 24) M3_REFINE(24);
     else if (aligned && D == 16) M3_REFINE(16);
     else if (aligned && D == 32) M3_REFINE(32);
     else if (aligned && D == 64) M3_REFINE(64);
-    else hipLaunchKernelGGL(k_refine_generic, grid, blk, 0, st, D11, D21, p_in, p_out, H, W, D, N, radius, dmax, chained);
+    else hipLaunchKernelGGL((k_refine_generic<TD>), grid, blk, 0, st, D11, D21, p_in, p_out, H, W, D, N, radius, dmax, chained);
 #undef M3_REFINE
     M3_CHECK_LAUNCH("m3_refine_matches");
     return M3_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int m3_refine_matches(const float *D11, const float *D21, const int32_t *p_in, int32_t *p_out, int B,
+                      int H, int W, int D, int N, int radius, int dilation_max, int chained, void *stream) {
+    return refine_launch<float>(D11, D21, p_in, p_out, B, H, W, D, N, radius, dilation_max, chained, (hipStream_t)stream);
+}
+int m3_refine_matches_f16(const void *D11, const void *D21, const int32_t *p_in, int32_t *p_out, int B,
+                          int H, int W, int D, int N, int radius, int dilation_max, int chained, void *stream) {
+    return refine_launch<__half>((const __half *)D11, (const __half *)D21, p_in, p_out, B, H, W, D, N, radius,
+                                 dilation_max, chained, (hipStream_t)stream);
 }
 
 int m3_match_epilogue(const float *X11, const float *X21, const int32_t *p_i32, const float *p_f32,

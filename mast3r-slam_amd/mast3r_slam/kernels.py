@@ -79,9 +79,13 @@ def iter_proj(rays_with_grad, pts3d_norm, p_init, max_iter: int = 10, lambda_ini
 def refine_matches(D11, D21, p1, radius: int = 3, dilation_max: int = 0, use_metal: bool = True, *,
                    chained: bool = False):
     """kernels.py:463-493.  D11 [B,H,W,D], D21 [B,N,D], p1 [B,N,2] (int; floats are truncated)
-    -> refined int32 [B,N,2].  chained=False: numpy-twin semantics; True: Metal semantics."""
-    d11, np_in = _to_dev(D11, torch.float32)
-    d21, _ = _to_dev(D21, torch.float32)
+    -> refined int32 [B,N,2].  chained=False: numpy-twin semantics; True: Metal semantics.
+    torch.float16 descriptors (both arrays) take the half-storage kernel: same fp32 scoring on the widened values."""
+    half = isinstance(D11, torch.Tensor) and D11.dtype == torch.float16
+    if half and not (isinstance(D21, torch.Tensor) and D21.dtype == torch.float16):
+        raise ValueError("D11 is float16: D21 must be float16 as well")
+    d11, np_in = _to_dev(D11, torch.float16 if half else torch.float32)
+    d21, _ = _to_dev(D21, torch.float16 if half else torch.float32)
     if isinstance(p1, np.ndarray):
         p1 = torch.from_numpy(np.ascontiguousarray(p1)).to(_DEV)
     if p1.dtype.is_floating_point:
@@ -98,8 +102,8 @@ def refine_matches(D11, D21, p1, radius: int = 3, dilation_max: int = 0, use_met
     out = torch.empty_like(p)
     if n == 0:
         return _out(out, np_in)
-    _ffi.call("m3_refine_matches", _ffi.ptr(d11), _ffi.ptr(d21), _ffi.ptr(p), _ffi.ptr(out), b, h, w, d, n,
-              int(radius), int(dilation_max), 1 if chained else 0, _ffi.stream_ptr())
+    _ffi.call("m3_refine_matches_f16" if half else "m3_refine_matches", _ffi.ptr(d11), _ffi.ptr(d21), _ffi.ptr(p),
+              _ffi.ptr(out), b, h, w, d, n, int(radius), int(dilation_max), 1 if chained else 0, _ffi.stream_ptr())
     return _out(out, np_in)
 
 

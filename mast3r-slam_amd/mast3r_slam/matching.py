@@ -87,8 +87,8 @@ def match_iterative_proj(X11, X21, D11, D21, idx_1_to_2_init=None, *, stop_scope
     vp = valid_proj.to(torch.uint8)
     p_int = None
     if cfg.get("use_refine", True) and cfg.get("refine_radius", 3) > 0:
-        D11 = _ffi.check(D11, torch.float32, "D11")
-        D21 = _ffi.check(D21, torch.float32, "D21")
+        D11 = _ffi.check(D11, (torch.float32, torch.float16), "D11")       # float16 = "fp16 features"
+        D21 = _ffi.check(D21, D11.dtype, "D21")
         d = D11.shape[-1]
         p_trunc = torch.empty((b, n, 2), dtype=torch.int32, device=dev)
         _ffi.call("m3_trunc_i32", _ffi.ptr(p1), _ffi.ptr(p_trunc), b * n * 2, _ffi.stream_ptr())

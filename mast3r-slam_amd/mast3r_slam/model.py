@@ -169,7 +169,10 @@ class Mast3rFull:
 
     def __init__(self, weights: Optional[dict] = None, cfg: Optional[dict] = None, device="cuda",
                  resolution: int = 512, precision: str = "bf16", seed: int = 0,
-                 head_precision: Optional[str] = None) -> None:
+                 head_precision: Optional[str] = None, features: str = "fp32") -> None:
+        if features not in ("fp32", "fp16"):
+            raise ValueError(f"features must be 'fp32' or 'fp16', got {features!r}")
+        self.desc_dtype = torch.float16 if features == "fp16" else torch.float32    # storage of the `desc` output
         if precision not in self._PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(self._PRECISIONS)}, got {precision!r}")
         if head_precision is not None and head_precision not in self._PRECISIONS:
@@ -468,7 +471,7 @@ class Mast3rFull:
         cat = ops.concat2(taps[0], taps[3])
         f = ops.gemm(cat, P[q + ".fc1.w"], P[q + ".fc1.b"], ops.EPI_BF16_GELU)
         f = ops.gemm(f, P[q + ".fc2.w"], P[q + ".fc2.b"], ops.EPI_BF16)
-        desc, dconf = ops.desc_post(f, npairs, gh * 16, gw * 16)
+        desc, dconf = ops.desc_post(f, npairs, gh * 16, gw * 16, self.desc_dtype)
         return dict(pts3d=pts, conf=conf, desc=desc, desc_conf=dconf)
 
     # ------------------------------------------------------------------ both heads as 2-group launches
@@ -527,7 +530,7 @@ class Mast3rFull:
         q = ".head_local_features"
         cat = ops.concat2(T[0].view(2 * m, -1), T[3].view(2 * m, -1)).view(2, m, -1)
         f = gem(gem(cat, q + ".fc1", ops.EPI_BF16_GELU), q + ".fc2")
-        desc, dconf = ops.desc_post(f.view(2 * m, -1), 2 * npairs, gh * 16, gw * 16)
+        desc, dconf = ops.desc_post(f.view(2 * m, -1), 2 * npairs, gh * 16, gw * 16, self.desc_dtype)
         H, Wd = gh * 16, gw * 16
         desc, dconf = desc.view(2, npairs, H, Wd, 24), dconf.view(2, npairs, H, Wd)
         return tuple(dict(pts3d=pts[v], conf=conf[v], desc=desc[v], desc_conf=dconf[v]) for v in range(2))

@@ -364,11 +364,16 @@ def pts_post(raw):
     return pts, conf
 
 
-def desc_post(f, b, h, w):
+def desc_post(f, b, h, w, desc_dtype=torch.float32):
+    """Pixel shuffle + L2 normalisation of the feature head: desc [b,h,w,24] (float32, or float16 = "fp16 features"),
+    desc_conf [b,h,w] float32."""
     f = _ffi.check(f, H16, "f", (b * (h // 16) * (w // 16), 6400))
-    desc = torch.empty((b, h, w, 24), dtype=torch.float32, device=f.device)
+    if desc_dtype not in (torch.float32, torch.float16):
+        raise ValueError(f"desc_dtype must be torch.float32 or torch.float16, got {desc_dtype}")
+    desc = torch.empty((b, h, w, 24), dtype=desc_dtype, device=f.device)
     dconf = torch.empty((b, h, w), dtype=torch.float32, device=f.device)
-    _ffi.call("m3_desc_post_dt", _ffi.ptr(f), _ffi.ptr(desc), _ffi.ptr(dconf), b, h, w, DT_CODE[f.dtype], _ffi.stream_ptr())
+    _ffi.call("m3_desc_post_f16" if desc_dtype == torch.float16 else "m3_desc_post_dt", _ffi.ptr(f), _ffi.ptr(desc),
+              _ffi.ptr(dconf), b, h, w, DT_CODE[f.dtype], _ffi.stream_ptr())
     return desc, dconf
 
 

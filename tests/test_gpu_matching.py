@@ -167,3 +167,50 @@ def test_full_size_512_properties(dev):
         assert np.array_equal(p.cpu().numpy(), po) and np.array_equal(vv.cpu().numpy(), vo)
     finally:
         config.reset_config()
+
+
+# ----------------------------------------------------------------- "fp16 features" (BASELINE configs[4])
+@pytest.mark.parametrize("d", [24, 16, 32, 64, 20])
+@pytest.mark.parametrize("chained", [False, True])
+def test_refine_fp16_descriptors_bit_exact_vs_oracle_on_rounded_values(dev, d, chained):
+    """Half-stored descriptors are widened exactly and scored in fp32: the result must equal the oracle (and the
+    fp32 kernel) run on the half-rounded values, bit for bit - the storage type changes bytes moved, not arithmetic."""
+    rng = np.random.default_rng(100 + d)
+    b, h, w, n = 2, 30, 41, 900
+    D11 = rng.normal(size=(b, h, w, d)).astype(np.float16)
+    D21 = rng.normal(size=(b, n, d)).astype(np.float16)
+    p1 = np.stack([rng.integers(-4, w + 4, size=(b, n)), rng.integers(-4, h + 4, size=(b, n))], -1).astype(np.int32)
+    ro = om.refine_matches(D11.astype(np.float32), D21.astype(np.float32), p1, 3, 2, chained=chained)
+    r16 = kernels.refine_matches(_t(D11, dev), _t(D21, dev), _t(p1, dev), 3, 2, chained=chained)
+    r32 = kernels.refine_matches(_t(D11, dev).float(), _t(D21, dev).float(), _t(p1, dev), 3, 2, chained=chained)
+    assert r16.dtype == torch.int32
+    assert np.array_equal(r16.cpu().numpy(), ro)
+    assert torch.equal(r16, r32)
+    with pytest.raises(ValueError, match="float16"):
+        kernels.refine_matches(_t(D11, dev), _t(D21, dev).float(), _t(p1, dev), 3, 2)
+
+
+def test_fp16_features_dense_match_lds_path_and_agreement(dev):
+    """Tiled LDS-staged path (N == H*W, D == 24) with half descriptors: bit-exact against the oracle on the rounded
+    descriptors at a size the oracle finishes in seconds; at 512x512 the half-feature matcher must agree with the
+    fp32-feature matcher on all but near-tie points and land on the true match equally well."""
+    config.set_config({"matching": {"use_simple": False}})
+    try:
+        sc = synthetic.geometric_pair(48, 64, seed=5, batch=2)
+        D11h, D21h = sc["D11"].astype(np.float16), sc["D21"].astype(np.float16)
+        io, vo = om.match_iterative_proj(sc["X11"], sc["X21"], D11h.astype(np.float32), D21h.astype(np.float32), None,
+                                         dilation_max=2)
+        i, v = matching.match(_t(sc["X11"], dev), _t(sc["X21"], dev), _t(D11h, dev), _t(D21h, dev))
+        assert np.array_equal(i.cpu().numpy(), io) and np.array_equal(v.cpu().numpy(), vo)
+        h = w = 512
+        sc = synthetic.geometric_pair(h, w, seed=0, batch=2)
+        X11, X21, D11, D21 = [_t(sc[k], dev) for k in ("X11", "X21", "D11", "D21")]
+        i32, v32 = matching.match(X11, X21, D11, D21)
+        i16, v16 = matching.match(X11, X21, D11.half(), D21.half())
+        both = (v32 & v16)[..., 0]
+        assert float((i32 == i16)[both].float().mean()) > 0.98
+        idx = i16.cpu().numpy(); val = v16.cpu().numpy()[..., 0]
+        err = np.hypot(idx % w - sc["uv_true"][..., 0], idx // w - sc["uv_true"][..., 1])
+        assert val.mean() > 0.9 and np.median(err[val]) < 1.0 and (err[val] < 2.5).mean() > 0.99
+    finally:
+        config.reset_config()

@@ -229,6 +229,8 @@ def test_fp16_storage_variants_of_the_elementwise_ops(dev):
     desc, dconf = ops.desc_post(f.to(dev), 2, 16, 32)
     ps = F.pixel_shuffle(f.float().view(2, 2, 6400).transpose(1, 2).reshape(2, 6400, 1, 2), 16).permute(0, 2, 3, 1)
     assert _rel(desc, ps[..., :24] / ps[..., :24].norm(dim=-1, keepdim=True)) < 1e-6
+    desc16, dconf16 = ops.desc_post(f.to(dev), 2, 16, 32, torch.float16)      # "fp16 features": one rounding of the fp32 value
+    assert desc16.dtype == torch.float16 and torch.equal(desc16, desc.half()) and torch.equal(dconf16, dconf)
     with pytest.raises(TypeError, match="mixed 16-bit"):
         ops.add(r.to(dev), r.bfloat16().to(dev))
 

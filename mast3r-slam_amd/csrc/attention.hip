@@ -14,6 +14,8 @@
 // the row-major V image through ds_read_b64_tr_b16 (hardware transpose), conflict-free with a
 // chunk-pair swizzle.
 #include "gemm_common.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -50,15 +52,26 @@ struct AttnArgs {
 // e.g. one pair = 2 images x 16 heads x 8 blocks = 256 workgroups on 256 CUs).
 // Any Tq, Tk >= 1: query rows past Tq are computed on a clamped row and not stored; keys past Tk (last
 // tile only) are staged from the clamped last row and their scores set to -inf before the softmax.
-// PRE: q already carries softmax scale * log2(e) (folded in by the projection GEMM's RoPE epilogue), so a score is
-// an exp2 argument as it leaves the matrix core.  The running reference maximum m_ref of a query enters the S^T MFMA
-// as its accumulator INITIALISER (C = -m_ref, lane-local), i.e. the MFMA returns s - m_ref and p = exp2(that) with no
-// per-score subtract / multiply; m_ref is raised (and o, l rescaled) only when a tile's maximum exceeds it by more
-// than kDefer (wave-uniform, rare after the first tiles; p <= 2^kDefer otherwise).  Row sums as packed adds.
-// Per (tile, query tile): 16 v_fma + 16 v_add fewer of ~90 VALU slots in a VALU-bound kernel.
+// MODE 0: classic online softmax; scale * log2(e) is applied per score.
+// MODE 1, 2 ("prescaled"): q already carries softmax scale * log2(e) (folded in by the projection GEMM's RoPE
+// epilogue), so a score is an exp2 argument as it leaves the matrix core, and the reference maximum m_ref of a query
+// enters the S^T MFMA as its accumulator INITIALISER (C = -m_ref, lane-local): the MFMA returns s - m_ref.
+//   MODE 1 (safe, any magnitude): the tile maximum is still computed; m_ref is raised (and o, l rescaled) only when it
+//     exceeds the reference by more than kDefer (wave-uniform, rare after the first tiles).  Row sums as packed adds.
+//   MODE 2 (fast, bf16 P operand): the kernel is bound by VALU ISSUE (PMC: VALU + MFMA issue = 96 % of the SIMD
+//     cycles; per tile and wave 64 v_exp_f32 = 512 cycles, as many as its 32 MFMAs), so everything but the exp2 and
+//     the 16-bit packing leaves the VALU: m_ref is the TRUE maximum of the first tile and never recomputed; later
+//     tiles only need exp2(s - m_ref) to stay finite, and bf16 has the fp32 exponent range.  Softmax is invariant to
+//     the reference, so a lagging one costs no accuracy - numerator and denominator carry the same factor.  The row
+//     sums are one more MFMA per (query tile, k-step) against an all-ones A fragment - l accumulates in a matrix-core
+//     register across tiles, already summed over the lane groups, and sums exactly the rounded P that multiplies V.
+//     A per-lane test before the next tile (l > 2^60 -> scale o, l by 2^-64 and move m_ref) keeps the range; if a score
+//     ever exceeds the reference by more than 127 (exp2 overflow - not seen on any network input, but possible in
+//     principle) l ends non-finite and the WHOLE workgroup recomputes its block with the MODE 1 loop.
+#define M3_ATTN_EXP 0
 constexpr float kDefer = 8.0f;
-template <int QT, int DT, bool PRE>
-__global__ void __launch_bounds__(kThreads, 4)
+template <int QT, int DT, int MODE>
+__global__ void __launch_bounds__(kThreads, (MODE == 1 && QT == 2) ? 3 : 4)
 k_attn(const AttnArgs a) {
     constexpr int QR = QT * 64;                                 // query rows per workgroup
     __shared__ __attribute__((aligned(16))) unsigned char lds[kLds];
@@ -105,59 +118,88 @@ k_attn(const AttnArgs a) {
 
     f32x4 o[QT][4];
     float m_run[QT], l_run[QT];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        m_run[qt] = -INFINITY; l_run[qt] = 0.f;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-
     const int nt = (a.Tk + KT - 1) / KT;
-    stage(0, 0);
-    for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nt) { stage(t + 1, buf ^ 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        m3gemm::lds_barrier();                  // every wave's K/V loads of tile t have landed
-        const unsigned char *Ks = lds + buf * 2 * kTileBytes, *Vs = Ks + kTileBytes;
+    const int tq = lq >> 2, tp = lq & 3;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-        // ---- S^T = K . Q^T : s[qt][kt] holds keys kt*16 + g*4 + r of query lq ------------------
-        f32x4 s[QT][4];
+    auto run = [&](auto mode_tag) {
+        constexpr int MD = decltype(mode_tag)::value;
+        f32x4 l_acc[QT];                                          // MODE 2: row sums, accumulated by the matrix core
+        bf16x8 ones;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ones[j] = (short)(DT == DT_BF16 ? 0x3F80 : 0x3C00);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-            const float c0 = (PRE && t > 0) ? -m_run[qt] : 0.f;          // PRE: m_run holds m_ref (log2 units)
+            m_run[qt] = -INFINITY; l_run[qt] = 0.f;
+            l_acc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) s[qt][kt] = f32x4{c0, c0, c0, c0};
+            for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        stage(0, 0);
+        for (int t = 0; t < nt; ++t) {
+            const int buf = t & 1;
+            if (t + 1 < nt) { stage(t + 1, buf ^ 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            m3gemm::lds_barrier();                  // every wave's K/V loads of tile t have landed
+            const unsigned char *Ks = lds + buf * 2 * kTileBytes, *Vs = Ks + kTileBytes;
+
+            if constexpr (MD == 2) {
+                // range keeper for the row sums of the tiles so far (tested here, a tile late, so that the test does
+                // not wait for the matrix core); per query, identical in its 4 lanes
+                bool big = false;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+                for (int qt = 0; qt < QT; ++qt) big |= l_acc[qt][0] > 0x1p60f;
+                if (t > 0 && __any(big)) {
+                    asm volatile("; rare path" ::: "memory");
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                const int r = kt * 16 + lq;
-                const int c = (ks * 4 + g) ^ ((r >> 1) & 7);
-                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + r * 128 + c * 16);
+                    for (int qt = 0; qt < QT; ++qt) {
+                        const bool hit = l_acc[qt][0] > 0x1p60f;
+                        const float alpha = hit ? 0x1p-64f : 1.0f;
+                        m_run[qt] += hit ? 64.0f : 0.0f;
 #pragma unroll
-                for (int qt = 0; qt < QT; ++qt)
-                    s[qt][kt] = mfma16<DT>(kf, qf[qt][ks], s[qt][kt]);
+                        for (int r = 0; r < 4; ++r) l_acc[qt][r] *= alpha;
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
+                    }
+                }
             }
 
-        if (t == nt - 1 && (a.Tk & (KT - 1))) {           // key tail: wave-uniform branch, last tile only
-            const int kbase = t * KT + g * 4;
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (kbase + kt * 16 + r >= a.Tk) s[qt][kt][r] = -INFINITY;
-        }
-
-        // ---- online softmax (row = lane-local query) -------------------------------------------
-        bf16x8 pf[QT][2];
-        if constexpr (PRE) {
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            // ---- S^T = K . Q^T : s[qt][kt] holds keys kt*16 + g*4 + r of query lq ------------------
+            f32x4 s[QT][4];
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
+                const float c0 = (MD >= 1 && t > 0) ? -m_run[qt] : 0.f;          // prescaled: m_run holds m_ref (log2 units)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) s[qt][kt] = f32x4{c0, c0, c0, c0};
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const int r = kt * 16 + lq;
+                    const int c = (ks * 4 + g) ^ ((r >> 1) & 7);
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + r * 128 + c * 16);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        s[qt][kt] = mfma16<DT>(kf, qf[qt][ks], s[qt][kt]);
+                }
+
+            if (t == nt - 1 && (a.Tk & (KT - 1))) {           // key tail: wave-uniform branch, last tile only
+                const int kbase = t * KT + g * 4;
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (kbase + kt * 16 + r >= a.Tk) s[qt][kt][r] = -INFINITY;
+            }
+
+            // ---- online softmax (row = lane-local query) -------------------------------------------
+            bf16x8 pf[QT][2];
+            auto tile_max = [&](int qt) {
                 float mx = fmaxf(__builtin_fmaxf(s[qt][0][0], s[qt][0][1]), s[qt][0][2]);
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
@@ -165,36 +207,10 @@ k_attn(const AttnArgs a) {
                     for (int r = (kt == 0 ? 3 : 0); r < 4; r += 2)
                         mx = (r + 1 < 4) ? fmaxf(__builtin_fmaxf(mx, s[qt][kt][r]), s[qt][kt][r + 1]) : fmaxf(mx, s[qt][kt][r]);
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                if (t == 0) {                                            // first tile: the true maximum becomes the reference
-                    m_run[qt] = mx;
-#pragma unroll
-                    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) s[qt][kt][r] -= mx;
-                } else if (__any(mx > kDefer)) {                         // some query outgrew its reference: exact update
-                    const float delta = fmaxf(mx, 0.f);
-                    const float alpha = __builtin_amdgcn_exp2f(-delta);
-                    m_run[qt] += delta;
-                    l_run[qt] *= alpha;
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
-#pragma unroll
-                    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) s[qt][kt][r] -= delta;
-                }
-                f32x2 rs2 = {0.f, 0.f};
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) s[qt][kt][r] = __builtin_amdgcn_exp2f(s[qt][kt][r]);
-                    rs2 += f32x2{s[qt][kt][0], s[qt][kt][1]};
-                    rs2 += f32x2{s[qt][kt][2], s[qt][kt][3]};
-                }
-                l_run[qt] += rs2.x + rs2.y;
+                return fmaxf(mx, __shfl_xor(mx, 32, 64));
+            };
+            auto pack_p = [&](int qt) {
+                // P fragment for k-step kk: element j<4 -> key (2kk)*16 + g*4 + j, j>=4 -> key (2kk+1)*16 + g*4 + j-4
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     union { unsigned u[4]; bf16x8 v; } pk;
@@ -203,81 +219,162 @@ k_attn(const AttnArgs a) {
                     pk.u[2] = pack16<DT>(s[qt][2 * kk + 1][0], s[qt][2 * kk + 1][1]);
                     pk.u[3] = pack16<DT>(s[qt][2 * kk + 1][2], s[qt][2 * kk + 1][3]);
                     pf[qt][kk] = pk.v;
+                }
+            };
+            if constexpr (MD == 2) {
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    if (t == 0) {                                            // the first tile's true maximum is the reference
+                        const float mx = tile_max(qt);
+                        m_run[qt] = mx;
+#pragma unroll
+                        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) s[qt][kt][r] -= mx;
+                    }
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[qt][kt][r] = __builtin_amdgcn_exp2f(s[qt][kt][r]);
+#if M3_ATTN_EXP == 1
+                    for (int kt = 0; kt < 4; ++kt) for (int r = 0; r < 4; ++r) l_run[qt] += s[qt][kt][r];
+#endif
+                    pack_p(qt);
+                }
+            } else if constexpr (MD == 1) {
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    const float mx = tile_max(qt);
+                    if (t == 0) {                                            // first tile: the true maximum becomes the reference
+                        m_run[qt] = mx;
+#pragma unroll
+                        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) s[qt][kt][r] -= mx;
+                    } else if (__any(mx > kDefer)) {                         // some query outgrew its reference: exact update
+                        asm volatile("; rare path: keep it a branch (if-converted, its 32 subtracts + selects ran on every tile)" ::: "memory");
+                        const float delta = fmaxf(mx, 0.f);
+                        const float alpha = __builtin_amdgcn_exp2f(-delta);
+                        m_run[qt] += delta;
+                        l_run[qt] *= alpha;
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
+#pragma unroll
+                        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) s[qt][kt][r] -= delta;
+                    }
+                    f32x2 rs2 = {0.f, 0.f};
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[qt][kt][r] = __builtin_amdgcn_exp2f(s[qt][kt][r]);
+                        rs2 += f32x2{s[qt][kt][0], s[qt][kt][1]};
+                        rs2 += f32x2{s[qt][kt][2], s[qt][kt][3]};
+                    }
+                    l_run[qt] += rs2.x + rs2.y;
+                    pack_p(qt);
+                }
+            } else {
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    float mx = s[qt][0][0];
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qt][kt][r]);
+                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    const float m_new = fmaxf(m_run[qt], mx);
+                    const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * a.scale_log2e);
+                    const float mb = m_new * a.scale_log2e;
+                    m_run[qt] = m_new;
+                    float rs = 0.f;
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float p = __builtin_amdgcn_exp2f(s[qt][kt][r] * a.scale_log2e - mb);
+                            s[qt][kt][r] = p;
+                            rs += p;
+                        }
+                    l_run[qt] = l_run[qt] * alpha + rs;
+                    if (!__all(alpha == 1.0f)) {       // exact skip: no row of this wave raised its running max
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
+                    }
+                    pack_p(qt);
                 }
             }
-        } else {
-    #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
-                float mx = s[qt][0][0];
-    #pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
-    #pragma unroll
-                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qt][kt][r]);
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                const float m_new = fmaxf(m_run[qt], mx);
-                const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * a.scale_log2e);
-                const float mb = m_new * a.scale_log2e;
-                m_run[qt] = m_new;
-                float rs = 0.f;
-    #pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
-    #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float p = __builtin_amdgcn_exp2f(s[qt][kt][r] * a.scale_log2e - mb);
-                        s[qt][kt][r] = p;
-                        rs += p;
+
+            // ---- O^T += V^T . P^T : A fragment = V^T[d = dt*16 + lq][same key permutation] ------------
+            // transposed read: lane (4q+p) of a 16-lane group addresses row (key0 + q), cols d0 + 4p..4p+3
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    union { bf16x4 h[2]; bf16x8 v; } vf;
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int row = (2 * kk + half) * 16 + g * 4 + tq;
+                        const int ch = (dt * 2 + (tp >> 1)) ^ (((row >> 1) & 3) << 1);
+                        const unsigned char *p = Vs + row * 128 + ch * 16 + (tp & 1) * 8;
+                        vf.h[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) bf16x4 *)p);
                     }
-                l_run[qt] = l_run[qt] * alpha + rs;
-                if (!__all(alpha == 1.0f)) {       // exact skip: no row of this wave raised its running max
-    #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt)
-    #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        o[qt][dt] = mfma16<DT>(vf.v, pf[qt][kk], o[qt][dt]);
                 }
-                // P fragment for k-step kk: element j<4 -> key (2kk)*16 + g*4 + j, j>=4 -> key (2kk+1)*16 + g*4 + j-4
-    #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    union { unsigned u[4]; bf16x8 v; } pk;
-                    pk.u[0] = pack16<DT>(s[qt][2 * kk][0], s[qt][2 * kk][1]);
-                    pk.u[1] = pack16<DT>(s[qt][2 * kk][2], s[qt][2 * kk][3]);
-                    pk.u[2] = pack16<DT>(s[qt][2 * kk + 1][0], s[qt][2 * kk + 1][1]);
-                    pk.u[3] = pack16<DT>(s[qt][2 * kk + 1][2], s[qt][2 * kk + 1][3]);
-                    pf[qt][kk] = pk.v;
+                if constexpr (MD == 2) {
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) l_acc[qt] = mfma16<DT>(ones, pf[qt][kk], l_acc[qt]);
                 }
+            }
+            m3gemm::lds_barrier();                  // all K/V fragment reads of this tile returned before it is restaged
+        }
+        if constexpr (MD == 2 && M3_ATTN_EXP != 1) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) l_run[qt] = l_acc[qt][0];       // complete row sum, no lane reduction left
+        } else {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                float l = l_run[qt];
+                l += __shfl_xor(l, 16, 64);
+                l_run[qt] = l + __shfl_xor(l, 32, 64);
             }
         }
+    };
 
-        // ---- O^T += V^T . P^T : A fragment = V^T[d = dt*16 + lq][same key permutation] ------------
-        // transposed read: lane (4q+p) of a 16-lane group addresses row (key0 + q), cols d0 + 4p..4p+3
-        const int tq = lq >> 2, tp = lq & 3;
+    if constexpr (MODE == 2) {
+        run(std::integral_constant<int, 2>{});
+        bool bad = false;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                union { bf16x4 h[2]; bf16x8 v; } vf;
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int row = (2 * kk + half) * 16 + g * 4 + tq;
-                    const int ch = (dt * 2 + (tp >> 1)) ^ (((row >> 1) & 3) << 1);
-                    const unsigned char *p = Vs + row * 128 + ch * 16 + (tp & 1) * 8;
-                    vf.h[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) bf16x4 *)p);
-                }
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt)
-                    o[qt][dt] = mfma16<DT>(vf.v, pf[qt][kk], o[qt][dt]);
-            }
-        m3gemm::lds_barrier();                  // all K/V fragment reads of this tile returned before it is restaged
+        for (int qt = 0; qt < QT; ++qt) bad |= !(l_run[qt] > 0.f && l_run[qt] < INFINITY);
+#if M3_ATTN_EXP == 3
+        bad = true;
+#endif
+        // workgroup-wide OR through a word of the (now idle) tile buffers; every wave passed the loop's last barrier
+        int *flag = reinterpret_cast<int *>(lds);
+        if (tid == 0) *flag = 0;
+        m3gemm::lds_barrier();
+        if (__any(bad) && lane == 0) atomicOr(flag, 1);
+        m3gemm::lds_barrier();
+        const int redo = *reinterpret_cast<volatile int *>(flag);
+        m3gemm::lds_barrier();                                  // everyone has read the flag before tile 0 is staged over it
+        if (redo) run(std::integral_constant<int, 1>{});        // exp2 overflowed somewhere: exact recomputation
+    } else {
+        run(std::integral_constant<int, MODE>{});
     }
 
     // ---- finalize: O[q][dt*16 + g*4 + r] = o / l ---------------------------------------------------
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        float l = l_run[qt];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        const float inv = 1.0f / l;
+        const float inv = 1.0f / l_run[qt];
         const int row = qblk * QR + wave * (16 * QT) + qt * 16 + lq;
         if (row >= a.Tq) continue;
         bf16_t *op = a.O + (size_t)b * a.o_batch_stride + (size_t)row * a.o_row_stride + head * HD;
@@ -344,12 +441,15 @@ static int attention_launch(const void *Q, const void *K, const void *V, void *O
     const int64_t wg128 = (int64_t)m3_cdiv(Tq, QROWS) * heads * nbatch;
     const int64_t wg64 = (int64_t)m3_cdiv(Tq, 64) * heads * nbatch;
     hipStream_t st = (hipStream_t)stream;
+    // M3_ATTN_SAFE=1: prescaled bf16 launches take the max-tracking loop (MODE 1) instead of the fast one (experiments)
+    static const bool safe_bf16 = [] { const char *e = getenv("M3_ATTN_SAFE"); return e && atoi(e) != 0; }();
 #define M3_ATTN(QTV, GRID)                                                                                  \
     do {                                                                                                    \
-        if (dtype == DT_F16) { if (pre) hipLaunchKernelGGL((k_attn<QTV, DT_F16, true>), dim3((unsigned)(GRID)), dim3(kThreads), 0, st, a); \
-                               else hipLaunchKernelGGL((k_attn<QTV, DT_F16, false>), dim3((unsigned)(GRID)), dim3(kThreads), 0, st, a); } \
-        else { if (pre) hipLaunchKernelGGL((k_attn<QTV, DT_BF16, true>), dim3((unsigned)(GRID)), dim3(kThreads), 0, st, a);              \
-               else hipLaunchKernelGGL((k_attn<QTV, DT_BF16, false>), dim3((unsigned)(GRID)), dim3(kThreads), 0, st, a); }               \
+        if (dtype == DT_F16) { if (pre) hipLaunchKernelGGL((k_attn<QTV, DT_F16, 1>), dim3((unsigned)(GRID)), dim3(kThreads), 0, st, a); \
+                               else hipLaunchKernelGGL((k_attn<QTV, DT_F16, 0>), dim3((unsigned)(GRID)), dim3(kThreads), 0, st, a); } \
+        else { if (pre) { if (safe_bf16) hipLaunchKernelGGL((k_attn<QTV, DT_BF16, 1>), dim3((unsigned)(GRID)), dim3(kThreads), 0, st, a); \
+                          else hipLaunchKernelGGL((k_attn<QTV, DT_BF16, 2>), dim3((unsigned)(GRID)), dim3(kThreads), 0, st, a); }          \
+               else hipLaunchKernelGGL((k_attn<QTV, DT_BF16, 0>), dim3((unsigned)(GRID)), dim3(kThreads), 0, st, a); }                    \
     } while (0)
     if (wg128 >= 512) M3_ATTN(2, wg128); else M3_ATTN(1, wg64);
 #undef M3_ATTN

@@ -41,11 +41,15 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     return __builtin_elementwise_fma(hx, z * p, hx);
 }
 
-// two fp32 -> packed bf16x2 (round to nearest even), lo in bits 0..15
+// two fp32 -> packed bf16x2 (round to nearest even), lo in bits 0..15: one v_cvt_pk_bf16_f32.  Written as a vector
+// conversion, NOT as inline asm: the result of a transcendental (v_exp_f32, v_rcp_f32, v_rsq_f32 ...) may not be
+// read by the next VALU instruction without a wait state, and the hazard recogniser cannot see into an asm
+// statement - an asm conversion placed right behind the softmax's v_exp_f32 read stale registers in some lanes,
+// depending on timing (round 2, found when the row-sum adds that used to separate the two were removed).
+typedef __bf16 m3_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 m3_f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, m3_bf16x2));
 }
 
 // ---- 16-bit storage type of a launch: DT = 0 bf16 (v_mfma_f32_16x16x32_bf16), DT = 1 IEEE fp16
@@ -55,11 +59,7 @@ enum { DT_BF16 = 0, DT_F16 = 1 };
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 template <int DT> __device__ __forceinline__ unsigned pack16(float lo, float hi) {
     if constexpr (DT == DT_BF16) return pack_bf16(lo, hi);
-    else {
-        unsigned r;                                            // round to nearest even
-        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-        return r;
-    }
+    else return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, m3_f16x2));   // round to nearest even
 }
 template <int DT> __device__ __forceinline__ float lo16(unsigned q) {   // low half of a packed pair -> fp32
     if constexpr (DT == DT_BF16) return __uint_as_float(q << 16);

@@ -13,6 +13,7 @@
 // the 7x7 system, retracts the pose and evaluates the stop test - the loop never
 // returns to the host.  HBM/L2 bound: 29 B per point per iteration.
 #include "common.h"
+#include <cstdlib>
 #include "sim3_dev.h"
 
 namespace {
@@ -36,7 +37,8 @@ constexpr int WS_STRIDE = WS_PART + kBlocks * kSums;   // doubles per problem
 // enough points to amortise the 36-value block reduction (at 256 rows x 8 problems it saw 4 points
 // and the reduction dominated: 62 us per iteration for 8 x 262144 points, HBM time 10 us).
 static inline int track_blocks(int P) {
-    int b = 512 / (P > 0 ? P : 1);
+    static const int total = [] { const char *e = getenv("M3_TRACK_BLOCKS"); return e ? atoi(e) : 512; }();
+    int b = total / (P > 0 ? P : 1);
     return b < 16 ? 16 : (b > kBlocks ? kBlocks : b);
 }
 

@@ -210,3 +210,33 @@ def test_grouped_heads_equal_separate_heads(tiny, dev):
     for v in range(2):
         for k in e_main[v]:
             assert torch.equal(o_main[v][k], e_main[v][k]) and torch.equal(o_side[v][k], e_side[v][k])
+
+
+def test_fp16_features_through_the_operator_api(tiny, dev):
+    """BASELINE configs[4] "fp16 features": a model built with features="fp16" emits half descriptors (the fp32 value
+    rounded once); the symmetric match operator on them equals the numpy oracle matcher run on the half-rounded
+    descriptors bit for bit, and everything else the network returns is unchanged."""
+    cfg, w, net = tiny
+    net16 = M.Mast3rFull(weights=w, cfg=cfg, device=dev, features="fp16")
+    with pytest.raises(ValueError, match="features"):
+        M.Mast3rFull(weights=w, cfg=cfg, device=dev, features="int8")
+    h, wd = 128, 256
+    imi, imj = synthetic.textured_image(h, wd, 10), synthetic.textured_image(h, wd, 11)
+    fi = create_frame(0, torch.from_numpy(imi).to(dev)); fj = create_frame(1, torch.from_numpy(imj).to(dev))
+    gi = create_frame(0, torch.from_numpy(imi).to(dev)); gj = create_frame(1, torch.from_numpy(imj).to(dev))
+    X4, C4, D4, Q4 = mast3r_utils.mast3r_symmetric_inference(net, fi, fj)
+    Xh, Ch, Dh, Qh = mast3r_utils.mast3r_symmetric_inference(net16, gi, gj)
+    assert Dh.dtype == torch.float16 and torch.equal(Dh, D4.half())
+    assert torch.equal(Xh, X4) and torch.equal(Ch, C4) and torch.equal(Qh, Q4)
+    shp = [torch.tensor([[h, wd]])]
+    config.set_config({"matching": {"use_simple": False}})
+    try:
+        idx_i2j, idx_j2i, valid_j, valid_i, *_ = mast3r_utils.mast3r_match_symmetric(net16, gi.feat[None], None, gj.feat[None],
+                                                                                      None, shp, shp)
+    finally:
+        config.reset_config()
+    c = lambda t: np.ascontiguousarray(t.float().cpu().numpy())
+    io, vo = om.match_iterative_proj(c(Xh[0])[None], c(Xh[1])[None], c(Dh[0])[None], c(Dh[1])[None], dilation_max=2)
+    assert np.array_equal(idx_i2j.cpu().numpy(), io) and np.array_equal(valid_j.cpu().numpy(), vo)
+    io, vo = om.match_iterative_proj(c(Xh[2])[None], c(Xh[3])[None], c(Dh[2])[None], c(Dh[3])[None], dilation_max=2)
+    assert np.array_equal(idx_j2i.cpu().numpy(), io) and np.array_equal(valid_i.cpu().numpy(), vo)

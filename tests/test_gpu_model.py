@@ -526,10 +526,13 @@ def test_dpt_tail_direct_convolution(dev, dt, upsample, bhw):
 @pytest.mark.parametrize("dt", DT16)
 @pytest.mark.parametrize("tq_tk_b_h", [(1024, 1024, 16, 16), (256, 256, 2, 3), (672, 672, 2, 4), (200, 150, 2, 3)])
 def test_attention_prescaled_deferred_max(dev, dt, tq_tk_b_h):
-    """m3_attention_prescaled_dt: q carries scale * log2(e), the running reference maximum enters the S^T MFMA as its
-    accumulator initialiser and is raised only when a tile outgrows it by 2^8.  Forced branches (guide rule 26): a key
-    far down the sequence that dominates one query (rescale at a late tile), a query whose first tile holds its
-    maximum (never rescaled), and growth BELOW the threshold (deferred); full-tensor fp64-style reference."""
+    """m3_attention_prescaled_dt: q carries scale * log2(e) and the reference maximum enters the S^T MFMA as its
+    accumulator initialiser.  fp16 runs the max-tracking loop (reference raised when a tile outgrows it by 2^8), bf16
+    the fast loop (reference = first tile's maximum, row sums by MFMA, 2^-64 range keeper, workgroup-wide exact
+    recomputation if exp2 overflowed).  Forced branches (guide rule 26): a late key that dominates one query by 2^69
+    (rescale / range keeper), a query whose first tile holds its maximum (never rescaled), growth below the deferral
+    threshold, and a late key that exceeds the reference by 2^346 (exp2 overflow -> the recomputation path);
+    full-tensor float64 reference."""
     tq, tk, b, h = tq_tk_b_h
     g = torch.Generator().manual_seed(tq + h)
     c = h * 64
@@ -539,6 +542,7 @@ def test_attention_prescaled_deferred_max(dev, dt, tq_tk_b_h):
     q[0, 5, :64] = 6.0 * k[0, tk - 3, :64]                      # query 5 / head 0: one late key dominates (score ~ 6 * 64 * 0.18 >> 8)
     q[0, 7, :64] = 6.0 * k[0, 2, :64]                           # query 7: the dominating key is in the FIRST tile
     q[0, 9, :64] = 0.35 * k[0, min(70, tk - 1), :64]            # query 9: mild growth in a later tile (below the deferral threshold)
+    q[1, 11, 64:128] = 30.0 * k[1, tk - 5, 64:128]              # batch 1 / query 11 / head 1: 2^346 above anything before it
     qs = (q * ops.QK_PRESCALE).to(dt)
     kd, vd = k.to(dt), v.to(dt)
     out = torch.full((b, tq, c), 3.0, dtype=dt, device=dev)
@@ -552,3 +556,5 @@ def test_attention_prescaled_deferred_max(dev, dt, tq_tk_b_h):
     assert torch.isfinite(out).all() and _rel(out, ref) < tol
     for row in (5, 7, 9):                                        # the forced rows individually (a whole-tensor norm would hide them)
         assert _rel(out[0, row], ref[0, row]) < 2 * tol, row
+    assert _rel(out[1, 11], ref[1, 11]) < 2 * tol
+    assert _rel(out[1, 8:16, 64:128], ref[1, 8:16, 64:128]) < 2 * tol     # its neighbours in the recomputed workgroup

@@ -307,6 +307,25 @@ k_track_export(const double *__restrict__ ws, double *__restrict__ out, int nblk
     if (threadIdx.x < kSums) out[threadIdx.x] = sums[threadIdx.x];
 }
 
+// One gathered point: Xf = Xf_canon[idx], Qk = sqrt(Qff[idx] * Qkf), the two validity masks (tracker.py:88-113, :177-214).
+struct Gathered { float x, y, z, q; int vo, vk; };
+__device__ __forceinline__ Gathered gather_point(const float *__restrict__ Xf_canon, const float *__restrict__ Cf_avg,
+                                                 const float *__restrict__ Qff, int64_t id, float qkf, float ck, int vm,
+                                                 int N, float C_conf, float Q_conf) {
+    if (id < 0) id += N;
+    id = id < 0 ? 0 : (id >= N ? N - 1 : id);
+    Gathered g;
+    g.x = Xf_canon[3 * id + 0]; g.y = Xf_canon[3 * id + 1]; g.z = Xf_canon[3 * id + 2];
+    g.q = sqrtf(Qff[id] * qkf);
+    g.vk = (vm != 0) && (g.q > Q_conf);
+    g.vo = g.vk && (Cf_avg[id] > C_conf) && (ck > C_conf);
+    return g;
+}
+
+// VEC: four consecutive points per lane - the per-point streams (idx, Qkf, Ck, valid_match in; Xf, Qk, the two masks out)
+// move as 16-byte (4-byte for the masks) accesses; only the three gathers per point stay scalar.  The first version
+// handled one point per lane: 12-byte-strided dword stores and ONE-byte mask stores, 0.13 of the HBM roof.
+template <bool VEC>
 __global__ void __launch_bounds__(kThreads)
 k_track_gather(const float *__restrict__ Xf_canon, const float *__restrict__ Cf_avg,
                const float *__restrict__ Ck_avg, const float *__restrict__ Qff, const float *__restrict__ Qkf,
@@ -318,31 +337,47 @@ k_track_gather(const float *__restrict__ Xf_canon, const float *__restrict__ Cf_
         Xf_canon += pb * N * 3; Cf_avg += pb * N; Ck_avg += pb * N; Qff += pb * N; Qkf += pb * N; idx += pb * N;
         valid_match += pb * N; Xf_g += pb * N * 3; Qk += pb * N; valid_opt += pb * N; valid_kf += pb * N; counts += 2 * pb;
     }
-    const int n = blockIdx.x * kThreads + threadIdx.x;
-    int vo = 0, vk = 0;
-    if (n < N) {
-        int64_t id = idx[n];
-        if (id < 0) id += N;
-        id = id < 0 ? 0 : (id >= N ? N - 1 : id);
-        Xf_g[3 * n + 0] = Xf_canon[3 * id + 0];
-        Xf_g[3 * n + 1] = Xf_canon[3 * id + 1];
-        Xf_g[3 * n + 2] = Xf_canon[3 * id + 2];
-        const float q = sqrtf(Qff[id] * Qkf[n]);
-        Qk[n] = q;
-        const bool vm = valid_match[n] != 0, vq = q > Q_conf;
-        vk = vm && vq;
-        vo = vk && (Cf_avg[id] > C_conf) && (Ck_avg[n] > C_conf);
-        valid_opt[n] = (uint8_t)vo;
-        valid_kf[n] = (uint8_t)vk;
+    int vo = 0, vk = 0;                                   // number of valid points of this lane
+    if constexpr (VEC) {
+        const int g4 = blockIdx.x * kThreads + threadIdx.x;
+        if (g4 < N / 4) {
+            const longlong2 i01 = reinterpret_cast<const longlong2 *>(idx)[2 * g4], i23 = reinterpret_cast<const longlong2 *>(idx)[2 * g4 + 1];
+            const float4 qk4 = reinterpret_cast<const float4 *>(Qkf)[g4], ck4 = reinterpret_cast<const float4 *>(Ck_avg)[g4];
+            const unsigned vm4 = reinterpret_cast<const unsigned *>(valid_match)[g4];
+            const Gathered a = gather_point(Xf_canon, Cf_avg, Qff, i01.x, qk4.x, ck4.x, vm4 & 0xffu, N, C_conf, Q_conf);
+            const Gathered b = gather_point(Xf_canon, Cf_avg, Qff, i01.y, qk4.y, ck4.y, vm4 & 0xff00u, N, C_conf, Q_conf);
+            const Gathered c = gather_point(Xf_canon, Cf_avg, Qff, i23.x, qk4.z, ck4.z, vm4 & 0xff0000u, N, C_conf, Q_conf);
+            const Gathered d = gather_point(Xf_canon, Cf_avg, Qff, i23.y, qk4.w, ck4.w, vm4 & 0xff000000u, N, C_conf, Q_conf);
+            float4 *xo = reinterpret_cast<float4 *>(Xf_g) + 3 * (size_t)g4;
+            xo[0] = make_float4(a.x, a.y, a.z, b.x);
+            xo[1] = make_float4(b.y, b.z, c.x, c.y);
+            xo[2] = make_float4(c.z, d.x, d.y, d.z);
+            reinterpret_cast<float4 *>(Qk)[g4] = make_float4(a.q, b.q, c.q, d.q);
+            reinterpret_cast<unsigned *>(valid_opt)[g4] = (unsigned)a.vo | ((unsigned)b.vo << 8) | ((unsigned)c.vo << 16) | ((unsigned)d.vo << 24);
+            reinterpret_cast<unsigned *>(valid_kf)[g4] = (unsigned)a.vk | ((unsigned)b.vk << 8) | ((unsigned)c.vk << 16) | ((unsigned)d.vk << 24);
+            vo = a.vo + b.vo + c.vo + d.vo;
+            vk = a.vk + b.vk + c.vk + d.vk;
+        }
+    } else {
+        const int n = blockIdx.x * kThreads + threadIdx.x;
+        if (n < N) {
+            const Gathered a = gather_point(Xf_canon, Cf_avg, Qff, idx[n], Qkf[n], Ck_avg[n], valid_match[n], N, C_conf, Q_conf);
+            Xf_g[3 * n + 0] = a.x; Xf_g[3 * n + 1] = a.y; Xf_g[3 * n + 2] = a.z;
+            Qk[n] = a.q;
+            valid_opt[n] = (uint8_t)a.vo;
+            valid_kf[n] = (uint8_t)a.vk;
+            vo = a.vo; vk = a.vk;
+        }
     }
     // one atomic pair per BLOCK (same-address atomics serialise at ~12 ns each)
     __shared__ int cnt[2];
     if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
     __syncthreads();
-    const unsigned long long bo = __ballot(vo), bk = __ballot(vk);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { vo += __shfl_down(vo, off, 64); vk += __shfl_down(vk, off, 64); }
     if ((threadIdx.x & 63) == 0) {
-        if (bo) atomicAdd(&cnt[0], __popcll(bo));
-        if (bk) atomicAdd(&cnt[1], __popcll(bk));
+        if (vo) atomicAdd(&cnt[0], vo);
+        if (vk) atomicAdd(&cnt[1], vk);
     }
     __syncthreads();
     if (threadIdx.x < 2 && cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], cnt[threadIdx.x]);
@@ -371,8 +406,14 @@ int m3_track_gather_batch(const float *Xf_canon, const float *Cf_avg, const floa
     M3_REQUIRE(Xf_g && Qk && valid_opt && valid_kf && counts && N > 0 && P > 0 && P <= 65535);
     hipStream_t st = (hipStream_t)stream;
     M3_CHECK_HIP(hipMemsetAsync(counts, 0, 2 * P * sizeof(int32_t), st), "m3_track_gather/memset");
-    hipLaunchKernelGGL(k_track_gather, dim3(m3_cdiv(N, kThreads), P), dim3(kThreads), 0, st, Xf_canon, Cf_avg,
-                       Ck_avg, Qff, Qkf, idx, valid_match, Xf_g, Qk, valid_opt, valid_kf, counts, N, C_conf, Q_conf);
+    const uintptr_t al = (uintptr_t)idx | (uintptr_t)Qkf | (uintptr_t)Ck_avg | (uintptr_t)Xf_g | (uintptr_t)Qk;
+    const uintptr_t al4 = (uintptr_t)valid_match | (uintptr_t)valid_opt | (uintptr_t)valid_kf;
+    if (N % 4 == 0 && (al & 15) == 0 && (al4 & 3) == 0)       // per-problem strides are then multiples of 16 / 4 bytes too
+        hipLaunchKernelGGL(k_track_gather<true>, dim3(m3_cdiv(N / 4, kThreads), P), dim3(kThreads), 0, st, Xf_canon, Cf_avg,
+                           Ck_avg, Qff, Qkf, idx, valid_match, Xf_g, Qk, valid_opt, valid_kf, counts, N, C_conf, Q_conf);
+    else
+        hipLaunchKernelGGL(k_track_gather<false>, dim3(m3_cdiv(N, kThreads), P), dim3(kThreads), 0, st, Xf_canon, Cf_avg,
+                           Ck_avg, Qff, Qkf, idx, valid_match, Xf_g, Qk, valid_opt, valid_kf, counts, N, C_conf, Q_conf);
     M3_CHECK_LAUNCH("m3_track_gather");
     return M3_OK;
 }

@@ -94,9 +94,9 @@ def test_all_invalid_and_degenerate_input_do_not_crash(dev):
     assert int(info.cpu()[0]) == 1 and bool(info.cpu()[3])
 
 
-def test_track_gather_and_sim3_act(dev):
+@pytest.mark.parametrize("n", [5000, 4999, 3])      # 4 points per lane / the one-point path (N % 4 != 0) / tiny
+def test_track_gather_and_sim3_act(dev, n):
     rng = np.random.default_rng(9)
-    n = 5000
     Xc = rng.normal(size=(n, 3)).astype(np.float32)
     Cf = rng.uniform(-0.5, 3, n).astype(np.float32); Ck = rng.uniform(-0.5, 3, n).astype(np.float32)
     Qff = rng.uniform(0.5, 4, n).astype(np.float32); Qkf = rng.uniform(0.5, 4, n).astype(np.float32)

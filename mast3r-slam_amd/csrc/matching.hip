@@ -321,7 +321,12 @@ k_refine(const TD *__restrict__ D11, const TD *__restrict__ D21, const int32_t *
 // LDS image and the inner loop are the fp32 ones.
 constexpr int kRefineLdsBytes = 64 * 1024;
 
-template <int D, typename TD>
+// R > 0: the radius is a compile-time constant and the 2R+1 candidates of a window row are scored TOGETHER: 2R+1
+// independent accumulation chains instead of one 2*D-deep dependent mul/add chain per candidate (with 2 waves per SIMD
+// that chain's latency was the kernel's time), no per-candidate bounds branches (out-of-image candidates read a clamped
+// address and are masked at selection), no index multiply per candidate.  Each score is still the same sequential
+// fp32 sum and the selection still walks the candidates in raster order with a strict '>': identical bits.
+template <int D, typename TD, int R>
 __global__ void __launch_bounds__(kThreads)
 k_refine_lds(const TD *__restrict__ D11, const TD *__restrict__ D21, const int32_t *__restrict__ p_in,
              int32_t *__restrict__ p_out, int H, int W, int N, int radius) {
@@ -368,6 +373,39 @@ k_refine_lds(const TD *__restrict__ D11, const TD *__restrict__ D21, const int32
         }
         __syncthreads();
         float best = -INFINITY;
+        if constexpr (R > 0) {
+            for (int dy = -R; dy <= R; ++dy) {
+                const int ny = cy + dy;
+                const bool row_ok = (ny >= 0) && (ny < H);
+                const int nyc = ny < y0 ? y0 : (ny > y1 ? y1 : ny);
+                const float4 *rowp = tile + (nyc - y0) * rw * PS4;
+                const float4 *cp[2 * R + 1];
+                float sc[2 * R + 1];
+#pragma unroll
+                for (int j = 0; j <= 2 * R; ++j) {
+                    const int nx = cx + j - R;
+                    const int nxc = nx < x0 ? x0 : (nx > x1 ? x1 : nx);
+                    cp[j] = rowp + (nxc - x0) * PS4;
+                    sc[j] = 0.0f;
+                }
+#pragma unroll
+                for (int k = 0; k < D / 4; ++k) {
+#pragma unroll
+                    for (int j = 0; j <= 2 * R; ++j) {
+                        const float4 v = cp[j][k];
+                        sc[j] = sc[j] + q[4 * k + 0] * v.x;
+                        sc[j] = sc[j] + q[4 * k + 1] * v.y;
+                        sc[j] = sc[j] + q[4 * k + 2] * v.z;
+                        sc[j] = sc[j] + q[4 * k + 3] * v.w;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j <= 2 * R; ++j) {
+                    const int nx = cx + j - R;
+                    if (row_ok && nx >= 0 && nx < W && sc[j] > best) { best = sc[j]; bx = nx; by = ny; }
+                }
+            }
+        } else {
         for (int dy = -radius; dy <= radius; ++dy) {
             const int ny = cy + dy;
             if (ny < 0 || ny >= H) continue;
@@ -386,6 +424,7 @@ k_refine_lds(const TD *__restrict__ D11, const TD *__restrict__ D21, const int32
                 }
                 if (score > best) { best = score; bx = nx; by = ny; }
             }
+        }
         }
     } else {
         refine_pass<D, TD>(img, q, H, W, radius, 1, cx, cy, bx, by);
@@ -542,7 +581,8 @@ int refine_launch(const TD *D11, const TD *D21, const int32_t *p_in, int32_t *p_
 #define M3_REFINE(DD) hipLaunchKernelGGL((k_refine<DD, TD>), grid, blk, 0, st, D11, D21, p_in, p_out, H, W, N, radius, dmax, chained, tiled)
     const bool single_pass = !chained || dmax == 1;
     if (aligned && D == 24 && tiled && single_pass && radius <= 4) {
-        hipLaunchKernelGGL((k_refine_lds<24, TD>), grid, blk, kRefineLdsBytes, st, D11, D21, p_in, p_out, H, W, N, radius);
+        if (radius == 3) hipLaunchKernelGGL((k_refine_lds<24, TD, 3>), grid, blk, kRefineLdsBytes, st, D11, D21, p_in, p_out, H, W, N, radius);
+        else hipLaunchKernelGGL((k_refine_lds<24, TD, 0>), grid, blk, kRefineLdsBytes, st, D11, D21, p_in, p_out, H, W, N, radius);
     } else if (aligned && D == 24) M3_REFINE(24);
     else if (aligned && D == 16) M3_REFINE(16);
     else if (aligned && D == 32) M3_REFINE(32);

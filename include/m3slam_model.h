@@ -190,6 +190,11 @@ int m3_unshuffle_bf16(const void *in, void *out, int B, int h, int w, int s, int
 /* bilinear x2, align_corners = True, NHWC bf16. */
 int m3_upsample2x_bf16(const void *in, void *out, int B, int H, int W, int C, void *stream);
 int m3_upsample2x_dt(const void *in, void *out, int B, int H, int W, int C, int dtype, void *stream);
+/* DPT fusion block (public DPT FeatureFusionBlock: upsample the coarser path, add the refined skip connection):
+ * out [B,OH,OW,C] = bilinear_x2(low [B,H,W,C], align_corners)[:, :OH, :OW] + y [B,OH,OW,C], OH <= 2H, OW <= 2W,
+ * summed in fp32 and rounded once.  out may alias y. */
+int m3_add_upsample2x_dt(const void *low, const void *y, void *out, int B, int H, int W, int OH, int OW, int C,
+                         int dtype, void *stream);
 /* DPT output [P,4] f32 -> pts3d [P,3] = xyz/|xyz| * expm1(|xyz|), conf [P] = 1 + exp(c). */
 int m3_pts_post(const float *in, float *pts, float *conf, int64_t P, void *stream);
 /* feature-head output [B*(H/16)*(W/16), 6400] bf16 -> pixel shuffle 16 -> desc [B,H,W,24] f32

@@ -138,9 +138,12 @@ k_attn(const AttnArgs a) {
         stage(0, 0);
         for (int t = 0; t < nt; ++t) {
             const int buf = t & 1;
-            if (t + 1 < nt) { stage(t + 1, buf ^ 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            m3gemm::lds_barrier();                  // every wave's K/V loads of tile t have landed
+            // ONE barrier per tile: it publishes tile t (every wave waited for its own share) and, because a wave
+            // reaches it only after its last fragment read of tile t-1, it also frees that tile's stage - which is
+            // where tile t+1 is staged right behind it, with the whole of tile t's arithmetic to land.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            m3gemm::lds_barrier();
+            if (t + 1 < nt) stage(t + 1, buf ^ 1);
             const unsigned char *Ks = lds + buf * 2 * kTileBytes, *Vs = Ks + kTileBytes;
 
             if constexpr (MD == 2) {
@@ -335,8 +338,8 @@ k_attn(const AttnArgs a) {
                     for (int qt = 0; qt < QT; ++qt) l_acc[qt] = mfma16<DT>(ones, pf[qt][kk], l_acc[qt]);
                 }
             }
-            m3gemm::lds_barrier();                  // all K/V fragment reads of this tile returned before it is restaged
         }
+        m3gemm::lds_barrier();                      // the stages are reused right after the loop (flag word / recomputation)
         if constexpr (MD == 2 && M3_ATTN_EXP != 1) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) l_run[qt] = l_acc[qt][0];       // complete row sum, no lane reduction left

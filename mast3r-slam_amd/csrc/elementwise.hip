@@ -205,6 +205,49 @@ k_upsample2x(const bf16_t *__restrict__ in, bf16_t *__restrict__ out, int B, int
     *reinterpret_cast<uint4 *>(out + (((size_t)b * OH + oy) * OW + ox) * C + c) = o.q;
 }
 
+// out[b,oy,ox,:] = bilinear_x2(low)[b,oy,ox,:] + y[b,oy,ox,:] for oy < OH <= 2H, ox < OW <= 2W (the DPT fusion block's
+// "upsample the coarser path, add the refined skip connection", with the crop the odd token grids need).  The
+// interpolation weights are those of the FULL 2H x 2W align_corners map; the sum is formed in fp32 and rounded once -
+// the upsampled map (537 MB per head at the last level) is neither written nor read back.
+template <int DT>
+__global__ void __launch_bounds__(kThreads)
+k_add_upsample2x(const bf16_t *__restrict__ low, const bf16_t *__restrict__ y, bf16_t *__restrict__ out, int B, int H,
+                 int W, int OH, int OW, int C) {
+    const int c8 = C / 8;
+    const int64_t total = (int64_t)B * OH * OW * c8;
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % c8) * 8;
+    int64_t p = i / c8;
+    const int ox = (int)(p % OW); p /= OW;
+    const int oy = (int)(p % OH);
+    const int b = (int)(p / OH);
+    const float sy = (H > 1) ? (float)(H - 1) / (float)(2 * H - 1) : 0.f;
+    const float sx = (W > 1) ? (float)(W - 1) / (float)(2 * W - 1) : 0.f;
+    const float fy = oy * sy, fx = ox * sx;
+    int y0 = (int)fy, x0 = (int)fx;
+    y0 = min(y0, H - 1); x0 = min(x0, W - 1);
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float wy = fy - (float)y0, wx = fx - (float)x0;
+    const bf16_t *base = low + (size_t)b * H * W * C + c;
+    union U { uint4 q; unsigned w[4]; } a, bq, cq, d, r, o;
+    const size_t oi = (((size_t)b * OH + oy) * OW + ox) * C + c;
+    r.q = *reinterpret_cast<const uint4 *>(y + oi);
+    a.q = *reinterpret_cast<const uint4 *>(base + ((size_t)y0 * W + x0) * C);
+    bq.q = *reinterpret_cast<const uint4 *>(base + ((size_t)y0 * W + x1) * C);
+    cq.q = *reinterpret_cast<const uint4 *>(base + ((size_t)y1 * W + x0) * C);
+    d.q = *reinterpret_cast<const uint4 *>(base + ((size_t)y1 * W + x1) * C);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float tl = lo16<DT>(a.w[k]) * (1.f - wx) + lo16<DT>(bq.w[k]) * wx;
+        const float bl = lo16<DT>(cq.w[k]) * (1.f - wx) + lo16<DT>(d.w[k]) * wx;
+        const float th = hi16<DT>(a.w[k]) * (1.f - wx) + hi16<DT>(bq.w[k]) * wx;
+        const float bh = hi16<DT>(cq.w[k]) * (1.f - wx) + hi16<DT>(d.w[k]) * wx;
+        o.w[k] = pack16<DT>((tl * (1.f - wy) + bl * wy) + lo16<DT>(r.w[k]), (th * (1.f - wy) + bh * wy) + hi16<DT>(r.w[k]));
+    }
+    *reinterpret_cast<uint4 *>(out + oi) = o.q;
+}
+
 // DPT head output [P,4] f32 (xyz, conf logit) -> pts3d [P,3] = xyz/|xyz| * expm1(|xyz|), conf [P] = 1 + exp(c)
 __global__ void __launch_bounds__(kThreads)
 k_pts_post(const float *__restrict__ in, float *__restrict__ pts, float *__restrict__ conf, int64_t P) {
@@ -383,6 +426,18 @@ int m3_upsample2x_dt(const void *in, void *out, int B, int H, int W, int C, int 
 }
 int m3_upsample2x_bf16(const void *in, void *out, int B, int H, int W, int C, void *stream) {
     return m3_upsample2x_dt(in, out, B, H, W, C, DT_BF16, stream);
+}
+
+int m3_add_upsample2x_dt(const void *low, const void *y, void *out, int B, int H, int W, int OH, int OW, int C, int dtype,
+                         void *stream) {
+    M3_REQUIRE(low && y && out && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0);
+    M3_REQUIRE(OH > 0 && OW > 0 && OH <= 2 * H && OW <= 2 * W);
+    M3_DT_OK(dtype);
+    const int64_t total = (int64_t)B * OH * OW * (C / 8);
+    M3_DT_LAUNCH(dtype, k_add_upsample2x, dim3(m3_cdiv(total, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                 (const bf16_t *)low, (const bf16_t *)y, (bf16_t *)out, B, H, W, OH, OW, C);
+    M3_CHECK_LAUNCH("m3_add_upsample2x");
+    return M3_OK;
 }
 
 int m3_pts_post(const float *in, float *pts, float *conf, int64_t P, void *stream) {

@@ -411,14 +411,17 @@ class Mast3rFull:
         return ops.conv3x3(c1, P[q + ".conv2.w"], P[q + ".conv2.b"], ops.EPI_BF16_ADD, resid=x)
 
     def _fusion(self, q, x0, x1=None):
+        """DPT FeatureFusionBlock WITHOUT its trailing x2 upsample: returns the out_conv output at the block's own
+        resolution.  With a skip connection x1, x0 is the previous block's (coarser) output: it is upsampled, cropped
+        to x1's size (odd token grids, oracle/model.py dpt_head: path[:, :, :h, :w]) and added to the refined x1 in one
+        launch (ops.add_upsample2x) - the upsampled map is never materialised."""
         P = self.P
-        out = x0 if x1 is None else ops.add(x0, self._rcu(x1, q + ".resConfUnit1"))
+        out = x0 if x1 is None else ops.add_upsample2x(x0, self._rcu(x1, q + ".resConfUnit1"))
         # out_conv is 1x1 and the align_corners bilinear weights sum to one, so conv(upsample(x)) ==
-        # upsample(conv(x)): run the GEMM on the low-resolution map (4x fewer rows), then upsample.
+        # upsample(conv(x)): run the GEMM on the low-resolution map (4x fewer rows); the consumer upsamples.
         out = self._rcu(out, q + ".resConfUnit2")
         b, h, w, ch = out.shape
-        out = ops.gemm(out.view(-1, ch), P[q + ".out_conv.w"], P[q + ".out_conv.b"], ops.EPI_BF16).view(b, h, w, -1)
-        return ops.upsample2x(out)
+        return ops.gemm(out.view(-1, ch), P[q + ".out_conv.w"], P[q + ".out_conv.b"], ops.EPI_BF16).view(b, h, w, -1)
 
     def head(self, hname: str, taps, npairs: int, grid):
         """taps: 4 [P*T,C] tensors in the head 16-bit type -> dict(pts3d [P,H,W,3], conf [P,H,W], desc [P,H,W,24], desc_conf [P,H,W])."""
@@ -447,13 +450,9 @@ class Mast3rFull:
         rn = [ops.conv3x3(l, P[p + f".scratch.layer_rn.{i}.w"], None, ops.EPI_BF16)
               for i, l in enumerate((l0, l1, l2, l3))]
         path = self._fusion(p + ".scratch.refinenet4", rn[3])
-        if path.shape[1:3] != rn[2].shape[1:3]:
-            # odd token grids (e.g. 512x336 -> 32x21): the stride-2 map has ceil(g/2) rows, its x2 upsampling one
-            # row more than the 1/16 map; the public DPT crops it (oracle/model.py dpt_head, path4[:, :, :h, :w])
-            path = path[:, :rn[2].shape[1], :rn[2].shape[2]].contiguous()
         path = self._fusion(p + ".scratch.refinenet3", path, rn[2])
         path = self._fusion(p + ".scratch.refinenet2", path, rn[1])
-        path = self._fusion(p + ".scratch.refinenet1", path, rn[0])
+        path = ops.upsample2x(self._fusion(p + ".scratch.refinenet1", path, rn[0]))
         h0 = ops.conv3x3(path, P[p + ".head.0.w"], P[p + ".head.0.b"], ops.EPI_BF16)
         ch = P[p + ".head.2.w"].shape[0]
         if ch == 128 and h0.shape[-1] == 128 and P[p + ".head.4.w"].shape == (4, 128):
@@ -482,13 +481,18 @@ class Mast3rFull:
         return ops.conv3x3_grouped2(c1, *W(".conv2.w"), *W(".conv2.b"), ops.EPI_BF16_ADD, resid=x)
 
     def _fusion2(self, q, x0, x1=None):
+        """`_fusion` for both heads at once: tensors [2 (head), B, h, w, C], weights per head."""
         P, h1, h2 = self.P, "downstream_head1", "downstream_head2"
-        out = x0 if x1 is None else ops.add(x0, self._rcu2(x1, q + ".resConfUnit1"))
+        if x1 is None:
+            out = x0
+        else:
+            y = self._rcu2(x1, q + ".resConfUnit1")
+            out = ops.add_upsample2x(x0.flatten(0, 1), y.flatten(0, 1)).view(y.shape)
         out = self._rcu2(out, q + ".resConfUnit2")
         g, b, h, w, ch = out.shape
         out = ops.gemm_grouped2(out.view(2, -1, ch), P[h1 + q + ".out_conv.w"], P[h2 + q + ".out_conv.w"],
                                 P[h1 + q + ".out_conv.b"], P[h2 + q + ".out_conv.b"], ops.EPI_BF16)
-        return ops.upsample2x(out.view(2 * b, h, w, -1)).view(2, b, 2 * h, 2 * w, -1)
+        return out.view(2, b, h, w, -1)
 
     def heads(self, taps1, taps2, npairs: int, grid):
         """Both heads (DPT + local features) with every operator as ONE 2-group launch (blockIdx.y = head: same
@@ -519,11 +523,11 @@ class Mast3rFull:
         rn = [ops.conv3x3_grouped2(l, *W(d + f".scratch.layer_rn.{i}.w"), None, None, ops.EPI_BF16)
               for i, l in enumerate((l0, l1, l2, l3))]
         path = self._fusion2(d + ".scratch.refinenet4", rn[3])
-        if path.shape[2:4] != rn[2].shape[2:4]:                                          # odd token grids, see `head`
-            path = path[:, :, :rn[2].shape[2], :rn[2].shape[3]].contiguous()
         path = self._fusion2(d + ".scratch.refinenet3", path, rn[2])
         path = self._fusion2(d + ".scratch.refinenet2", path, rn[1])
         path = self._fusion2(d + ".scratch.refinenet1", path, rn[0])
+        g2, b2, hh, ww, cc = path.shape
+        path = ops.upsample2x(path.view(g2 * b2, hh, ww, cc)).view(g2, b2, 2 * hh, 2 * ww, cc)
         h0 = ops.conv3x3_grouped2(path, *W(d + ".head.0.w"), *W(d + ".head.0.b"), ops.EPI_BF16)
         pts, conf = ops.dpt_tail_grouped2(h0, *W(d + ".head.2.w"), *W(d + ".head.2.b"), *W(d + ".head.4.w"), *W(d + ".head.4.b"),
                                           upsample=True)

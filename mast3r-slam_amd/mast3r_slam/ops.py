@@ -354,6 +354,20 @@ def upsample2x(x):
     return out
 
 
+def add_upsample2x(low, y):
+    """bilinear x2 (align_corners) of low [B,h,w,C], cropped to y's [B,OH,OW,C] (OH <= 2h, OW <= 2w), plus y - one launch,
+    one rounding; the DPT fusion block's 'upsampled coarser path + refined skip connection'."""
+    low = _ffi.check(low, H16, "low")
+    y = _ffi.check(y, low.dtype, "y")
+    b, h, w, c = low.shape
+    if y.dim() != 4 or y.shape[0] != b or y.shape[3] != c or y.shape[1] > 2 * h or y.shape[2] > 2 * w:
+        raise ValueError(f"y must be [{b},<={2 * h},<={2 * w},{c}], got {tuple(y.shape)}")
+    out = torch.empty_like(y)
+    _ffi.call("m3_add_upsample2x_dt", _ffi.ptr(low), _ffi.ptr(y), _ffi.ptr(out), b, h, w, y.shape[1], y.shape[2], c,
+              DT_CODE[low.dtype], _ffi.stream_ptr())
+    return out
+
+
 def pts_post(raw):
     """[...,4] f32 -> pts3d [...,3], conf [...]."""
     raw = _ffi.check(raw, torch.float32, "raw")

@@ -558,3 +558,25 @@ def test_attention_prescaled_deferred_max(dev, dt, tq_tk_b_h):
         assert _rel(out[0, row], ref[0, row]) < 2 * tol, row
     assert _rel(out[1, 11], ref[1, 11]) < 2 * tol
     assert _rel(out[1, 8:16, 64:128], ref[1, 8:16, 64:128]) < 2 * tol     # its neighbours in the recomputed workgroup
+
+
+@pytest.mark.parametrize("dt", DT16)
+@pytest.mark.parametrize("crop", [(0, 0), (1, 0), (1, 1)])
+def test_add_upsample2x_matches_interpolate_crop_add(dev, dt, crop):
+    """DPT fusion block glue: bilinear x2 (align_corners) of the coarser path, cropped to the skip connection's size
+    (odd token grids), plus the skip connection - fp32 sum, one rounding; against torch fp32."""
+    g = torch.Generator().manual_seed(7)
+    b, h, w, c = 3, 11, 16, 64
+    oh, ow = 2 * h - crop[0], 2 * w - crop[1]
+    low = torch.randn(b, h, w, c, generator=g).to(dt)
+    y = torch.randn(b, oh, ow, c, generator=g).to(dt)
+    out = ops.add_upsample2x(low.to(dev), y.to(dev))
+    up = F.interpolate(low.float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True)
+    ref = up[:, :, :oh, :ow].permute(0, 2, 3, 1) + y.float()
+    assert out.shape == y.shape and out.dtype == dt
+    assert _rel(out, ref) < TOL16[dt]
+    # equals the two separate launches up to the one rounding it saves
+    sep = ops.add(ops.upsample2x(low.to(dev))[:, :oh, :ow].contiguous(), y.to(dev))
+    assert _rel(out, sep) < 2 * TOL16[dt]
+    with pytest.raises(ValueError, match="y must be"):
+        ops.add_upsample2x(low.to(dev), torch.zeros(b, 2 * h + 1, ow, c, dtype=dt, device=dev))

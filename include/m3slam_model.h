@@ -172,6 +172,13 @@ int m3_layernorm_bf16_grouped2(const float *x, const float *gamma0, const float 
 int m3_layernorm_grouped2_dt(const float *x, const float *gamma0, const float *beta0, const float *gamma1,
                              const float *beta1, void *y, int M, int C, int in_row_shift, float eps,
                              int dtype, void *stream);
+/* Decoder block entry: two LayerNorms of the SAME rows in one pass.  x f32 [2,M,C] (two branches);
+ * y_own[g][r] = LN(x[g][r]; ga_g, ba_g) (norm1) and y_cross[1-g][r] = LN(x[g][r]; gb_(1-g), bb_(1-g)) (norm_y: the
+ * tokens of branch g as the other branch's cross-attention memory).  Bit-identical to m3_layernorm_grouped2_dt called
+ * twice (in_row_shift 0 and M). */
+int m3_layernorm_dual2_dt(const float *x, const float *ga0, const float *ba0, const float *ga1, const float *ba1,
+                          const float *gb0, const float *bb0, const float *gb1, const float *bb1, void *y_own,
+                          void *y_cross, int M, int C, float eps, int dtype, void *stream);
 
 /* uint8 image [B,H,W,3] -> bf16 patch matrix [B*(H/16)*(W/16), 768] (column c*256+py*16+px),
  * normalised (v/255-0.5)/0.5 (resize_img, mast3r_utils.py:186-188). */

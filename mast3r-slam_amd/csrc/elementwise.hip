@@ -67,6 +67,55 @@ k_layernorm(const float *__restrict__ x, const float *__restrict__ gamma, const 
     }
 }
 
+// Two LayerNorms of the same rows in one pass (decoder block entry: norm1 of a branch's own tokens and norm_y of
+// the same tokens as the OTHER branch's cross-attention memory): x f32 [2M,C] (two branches) is read once, the
+// statistics are shared, y_own[row] uses the row's branch parameters (ga*, ba*), y_cross[(row + M) mod 2M] the
+// destination branch's (gb*, bb*).  Bit-identical to the two separate launches.
+template <int VPL, int DT>
+__global__ void __launch_bounds__(kThreads)
+k_layernorm_dual(const float *__restrict__ x, const float *__restrict__ ga0, const float *__restrict__ ba0,
+                 const float *__restrict__ ga1, const float *__restrict__ ba1, const float *__restrict__ gb0,
+                 const float *__restrict__ bb0, const float *__restrict__ gb1, const float *__restrict__ bb1,
+                 bf16_t *__restrict__ y_own, bf16_t *__restrict__ y_cross, int M, int C, float eps) {
+    const int row = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (row >= 2 * M) return;
+    const int lane = threadIdx.x & 63;
+    const bool g1 = row >= M;
+    const float *ga = g1 ? ga1 : ga0, *ba = g1 ? ba1 : ba0;           // own branch
+    const float *gb = g1 ? gb0 : gb1, *bb = g1 ? bb0 : bb1;           // destination (other) branch
+    const int crow = g1 ? row - M : row + M;
+    const float4 *xr = reinterpret_cast<const float4 *>(x + (size_t)row * C);
+    float4 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { v[i] = xr[lane + 64 * i]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    uint2 *yo = reinterpret_cast<uint2 *>(y_own + (size_t)row * C), *yc = reinterpret_cast<uint2 *>(y_cross + (size_t)crow * C);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const float4 gm = reinterpret_cast<const float4 *>(ga)[lane + 64 * i], bt = reinterpret_cast<const float4 *>(ba)[lane + 64 * i];
+        const float4 gn = reinterpret_cast<const float4 *>(gb)[lane + 64 * i], bn = reinterpret_cast<const float4 *>(bb)[lane + 64 * i];
+        uint2 o, p;
+        o.x = pack16<DT>((v[i].x - mean) * rstd * gm.x + bt.x, (v[i].y - mean) * rstd * gm.y + bt.y);
+        o.y = pack16<DT>((v[i].z - mean) * rstd * gm.z + bt.z, (v[i].w - mean) * rstd * gm.w + bt.w);
+        p.x = pack16<DT>((v[i].x - mean) * rstd * gn.x + bn.x, (v[i].y - mean) * rstd * gn.y + bn.y);
+        p.y = pack16<DT>((v[i].z - mean) * rstd * gn.z + bn.z, (v[i].w - mean) * rstd * gn.w + bn.w);
+        yo[lane + 64 * i] = o;
+        yc[lane + 64 * i] = p;
+    }
+}
+
 // ---------------------------------------------------------------- patch extraction (im2col of the 16x16/16 conv)
 // img uint8 [B,H,W,3] -> A bf16 [B*(H/16)*(W/16), 768], column = c*256 + py*16 + px, value (v/255-0.5)/0.5
 template <int DT>
@@ -262,39 +311,61 @@ k_pts_post(const float *__restrict__ in, float *__restrict__ pts, float *__restr
 }
 
 // feature-MLP output [B*gh*gw, 25*256] bf16 (column c*256 + dy*16 + dx) -> pixel shuffle(16) ->
-// desc [B,H,W,24] L2-normalised, desc_conf [B,H,W] f32 = exp(channel 24).  One thread per pixel.
+// desc [B,H,W,24] L2-normalised, desc_conf [B,H,W] f32 = exp(channel 24).
 // F16OUT: the descriptors are stored as IEEE half ("fp16 features", BASELINE configs[4]) - the fp32 value rounded once.
+// The feature head emits, per 16x16 patch, 25 channel planes of 256 values (pixel shuffle layout c*256 + py*16 + px).
+// A thread owns EIGHT horizontally consecutive pixels of a patch row: one 16-byte load per channel (25 per thread)
+// and 8 x 96 contiguous output bytes - the one-pixel-per-thread version issued 25 two-byte loads per pixel (2.7 TB/s
+// of the kernel's 630 MB).
 template <int DT, bool F16OUT>
 __global__ void __launch_bounds__(kThreads)
 k_desc_post(const bf16_t *__restrict__ in, void *__restrict__ desc_out, float *__restrict__ dconf, int B, int H, int W) {
-    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    const int64_t P = (int64_t)B * H * W;
-    if (i >= P) return;
-    const int x = (int)(i % W), y = (int)((i / W) % H), b = (int)(i / ((int64_t)W * H));
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;          // (b, y, x/8)
+    const int w8 = W / 8;
+    const int64_t total = (int64_t)B * H * w8;
+    if (i >= total) return;
+    const int x = (int)(i % w8) * 8, y = (int)((i / w8) % H), b = (int)(i / ((int64_t)w8 * H));
     const int gw = W / 16, gh = H / 16;
     const bf16_t *row = in + (((size_t)b * gh + y / 16) * gw + x / 16) * 6400 + (y % 16) * 16 + (x % 16);
-    float v[25], n2 = 0.f;
+    union U { uint4 q; unsigned w[4]; } v[25];
 #pragma unroll
-    for (int c = 0; c < 25; ++c) v[c] = to_f32<DT>(row[c * 256]);
+    for (int c = 0; c < 25; ++c) v[c].q = *reinterpret_cast<const uint4 *>(row + c * 256);
+    float n2[8];
 #pragma unroll
-    for (int c = 0; c < 24; ++c) n2 += v[c] * v[c];
-    const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
-    if constexpr (F16OUT) {
-        uint4 *o = reinterpret_cast<uint4 *>(reinterpret_cast<unsigned short *>(desc_out) + i * 24);
+    for (int j = 0; j < 8; ++j) n2[j] = 0.f;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            uint32_t w[4];
+    for (int c = 0; c < 24; ++c)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                w[j] = pack16<DT_F16>(v[8 * c + 2 * j] * inv, v[8 * c + 2 * j + 1] * inv);
-            o[c] = make_uint4(w[0], w[1], w[2], w[3]);
+        for (int k = 0; k < 4; ++k) {
+            const float lo = lo16<DT>(v[c].w[k]), hi = hi16<DT>(v[c].w[k]);
+            n2[2 * k] += lo * lo;
+            n2[2 * k + 1] += hi * hi;
         }
-    } else {
-        float4 *o = reinterpret_cast<float4 *>(reinterpret_cast<float *>(desc_out) + i * 24);
+    const size_t pix = ((size_t)b * H + y) * W + x;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) o[c] = make_float4(v[4 * c] * inv, v[4 * c + 1] * inv, v[4 * c + 2] * inv, v[4 * c + 3] * inv);
+    for (int j = 0; j < 8; ++j) {
+        const float inv = 1.0f / fmaxf(sqrtf(n2[j]), 1e-12f);
+        float d[24];
+#pragma unroll
+        for (int c = 0; c < 24; ++c) d[c] = ((j & 1) ? hi16<DT>(v[c].w[j >> 1]) : lo16<DT>(v[c].w[j >> 1])) * inv;
+        if constexpr (F16OUT) {
+            uint4 *o = reinterpret_cast<uint4 *>(reinterpret_cast<unsigned short *>(desc_out) + (pix + j) * 24);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                o[c] = make_uint4(pack16<DT_F16>(d[8 * c], d[8 * c + 1]), pack16<DT_F16>(d[8 * c + 2], d[8 * c + 3]),
+                                  pack16<DT_F16>(d[8 * c + 4], d[8 * c + 5]), pack16<DT_F16>(d[8 * c + 6], d[8 * c + 7]));
+        } else {
+            float4 *o = reinterpret_cast<float4 *>(reinterpret_cast<float *>(desc_out) + (pix + j) * 24);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) o[c] = make_float4(d[4 * c], d[4 * c + 1], d[4 * c + 2], d[4 * c + 3]);
+        }
     }
-    dconf[i] = expf(v[24]);
+    float e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = expf((j & 1) ? hi16<DT>(v[24].w[j >> 1]) : lo16<DT>(v[24].w[j >> 1]));
+    float4 *dc = reinterpret_cast<float4 *>(dconf + pix);
+    dc[0] = make_float4(e[0], e[1], e[2], e[3]);
+    dc[1] = make_float4(e[4], e[5], e[6], e[7]);
 }
 
 }  // namespace
@@ -341,6 +412,21 @@ int m3_layernorm_grouped2_dt(const float *x, const float *gamma0, const float *b
 int m3_layernorm_bf16_grouped2(const float *x, const float *gamma0, const float *beta0, const float *gamma1,
                                const float *beta1, void *y, int M, int C, int in_row_shift, float eps, void *stream) {
     return m3_layernorm_grouped2_dt(x, gamma0, beta0, gamma1, beta1, y, M, C, in_row_shift, eps, DT_BF16, stream);
+}
+
+int m3_layernorm_dual2_dt(const float *x, const float *ga0, const float *ba0, const float *ga1, const float *ba1,
+                          const float *gb0, const float *bb0, const float *gb1, const float *bb1, void *y_own,
+                          void *y_cross, int M, int C, float eps, int dtype, void *stream) {
+    M3_REQUIRE(x && ga0 && ba0 && ga1 && ba1 && gb0 && bb0 && gb1 && bb1 && y_own && y_cross && y_own != y_cross);
+    M3_REQUIRE(M > 0 && C > 0 && C % 256 == 0 && C <= 2048);
+    M3_DT_OK(dtype);
+    dim3 grid(m3_cdiv(2 * M, kThreads / 64)), blk(kThreads);
+    hipStream_t st = (hipStream_t)stream;
+#define M3_LN(V, DTV) case V: hipLaunchKernelGGL((k_layernorm_dual<V, DTV>), grid, blk, 0, st, x, ga0, ba0, ga1, ba1, gb0, bb0, gb1, bb1, (bf16_t *)y_own, (bf16_t *)y_cross, M, C, eps); break
+    if (dtype == DT_F16) { M3_LN_CASES(DT_F16) } else { M3_LN_CASES(DT_BF16) }
+#undef M3_LN
+    M3_CHECK_LAUNCH("m3_layernorm_dual2");
+    return M3_OK;
 }
 
 int m3_patchify16_dt(const uint8_t *img, void *A, int B, int H, int W, int dtype, void *stream) {
@@ -450,7 +536,7 @@ int m3_pts_post(const float *in, float *pts, float *conf, int64_t P, void *strea
 static int desc_post_launch(const void *in, void *desc, float *dconf, int B, int H, int W, int dtype, bool f16out, void *stream) {
     M3_REQUIRE(in && desc && dconf && B > 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0);
     M3_DT_OK(dtype);
-    const int64_t P = (int64_t)B * H * W;
+    const int64_t P = (int64_t)B * H * (W / 8);                  // eight pixels per thread
     dim3 grid(m3_cdiv(P, kThreads)), blk(kThreads);
     hipStream_t st = (hipStream_t)stream;
 #define M3_DP(DTV, F) hipLaunchKernelGGL((k_desc_post<DTV, F>), grid, blk, 0, st, (const bf16_t *)in, desc, dconf, B, H, W)

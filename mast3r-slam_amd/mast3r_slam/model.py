@@ -367,12 +367,12 @@ class Mast3rFull:
         W = lambda i, s: (P[f"dec_blocks.{i}.{s}"], P[f"dec_blocks2.{i}.{s}"])
         for i in range(c["dec_depth"]):
             # cross-attention memory: norm_y of the OTHER view's previous-layer tokens, then k|v projection
-            yn = ops.layernorm_grouped2(x, *W(i, "norm_y.g")[:1], W(i, "norm_y.b")[0], W(i, "norm_y.g")[1],
-                                        W(i, "norm_y.b")[1], swap=True, dtype=dt)
+            # (one pass over x also yields norm1 of the same tokens for the self-attention below)
+            xn, yn = ops.layernorm_dual2(x, ((W(i, "norm1.g")[0], W(i, "norm1.b")[0]), (W(i, "norm1.g")[1], W(i, "norm1.b")[1])),
+                                         ((W(i, "norm_y.g")[0], W(i, "norm_y.b")[0]), (W(i, "norm_y.g")[1], W(i, "norm_y.b")[1])), dtype=dt)
             kv = ops.gemm_grouped2(yn, *W(i, "cross_attn.kv.w"), *W(i, "cross_attn.kv.b"), ops.EPI_BF16_ROPE,
                                    rope=(rtok, D))                                  # [2,M,2D], k rotated
             # self-attention
-            xn = ops.layernorm_grouped2(x, W(i, "norm1.g")[0], W(i, "norm1.b")[0], W(i, "norm1.g")[1], W(i, "norm1.b")[1], dtype=dt)
             qkv = ops.gemm_grouped2(xn, *W(i, "attn.qkv.w"), *W(i, "attn.qkv.b"), ops.EPI_BF16_ROPE,
                                     rope=(rtok, 2 * D, D, ops.QK_PRESCALE)).view(2 * m, 3 * D)
             a = torch.empty((2, m, D), dtype=dt, device=dev)

@@ -431,6 +431,22 @@ def gemm_grouped2(a, w0, w1, b0, b1, epi=EPI_BF16, out=None, resid=None, rope=No
     return out
 
 
+def layernorm_dual2(x, own, cross, eps=1e-6, dtype=torch.bfloat16):
+    """x f32 [2,M,C] -> (y_own, y_cross), both 16-bit [2,M,C], in one pass over x: y_own[g] = LN(x[g]) with own[g] =
+    (gamma, beta); y_cross[g] = LN(x[1-g]) with cross[g] - i.e. layernorm_grouped2(x, *own) and
+    layernorm_grouped2(x, *cross, swap=True) together."""
+    x = _ffi.check(x, torch.float32, "x")
+    _, m, c = x.shape
+    y_own = torch.empty((2, m, c), dtype=dtype, device=x.device)
+    y_cross = torch.empty((2, m, c), dtype=dtype, device=x.device)
+    (ga0, ba0), (ga1, ba1) = own
+    (gb0, bb0), (gb1, bb1) = cross
+    _ffi.call("m3_layernorm_dual2_dt", _ffi.ptr(x), _ffi.ptr(ga0), _ffi.ptr(ba0), _ffi.ptr(ga1), _ffi.ptr(ba1), _ffi.ptr(gb0),
+              _ffi.ptr(bb0), _ffi.ptr(gb1), _ffi.ptr(bb1), _ffi.ptr(y_own), _ffi.ptr(y_cross), m, c, float(eps), DT_CODE[dtype],
+              _ffi.stream_ptr())
+    return y_own, y_cross
+
+
 def layernorm_grouped2(x, g0, b0, g1, b1, swap=False, eps=1e-6, dtype=torch.bfloat16):
     """x f32 [2,M,C] -> 16-bit [2,M,C]; group v uses (g_v, b_v); swap=True normalises the OTHER group's rows."""
     x = _ffi.check(x, torch.float32, "x")

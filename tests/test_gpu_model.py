@@ -580,3 +580,17 @@ def test_add_upsample2x_matches_interpolate_crop_add(dev, dt, crop):
     assert _rel(out, sep) < 2 * TOL16[dt]
     with pytest.raises(ValueError, match="y must be"):
         ops.add_upsample2x(low.to(dev), torch.zeros(b, 2 * h + 1, ow, c, dtype=dt, device=dev))
+
+
+@pytest.mark.parametrize("dt", DT16)
+def test_layernorm_dual2_equals_two_grouped_launches(dev, dt):
+    """Decoder block entry: norm1 of a branch's tokens and norm_y of the same tokens as the other branch's memory in
+    one pass over the residual stream - bit-identical to the two separate 2-group launches."""
+    g = torch.Generator().manual_seed(3)
+    m, c = 517, 768
+    x = (torch.randn(2, m, c, generator=g) * 3 + 0.5).to(dev)
+    prm = [torch.randn(c, generator=g).to(dev) for _ in range(8)]
+    own, cross = ((prm[0], prm[1]), (prm[2], prm[3])), ((prm[4], prm[5]), (prm[6], prm[7]))
+    y_own, y_cross = ops.layernorm_dual2(x, own, cross, dtype=dt)
+    assert torch.equal(y_own, ops.layernorm_grouped2(x, prm[0], prm[1], prm[2], prm[3], dtype=dt))
+    assert torch.equal(y_cross, ops.layernorm_grouped2(x, prm[4], prm[5], prm[6], prm[7], swap=True, dtype=dt))

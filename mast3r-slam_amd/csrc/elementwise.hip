@@ -251,7 +251,10 @@ k_upsample2x(const bf16_t *__restrict__ in, bf16_t *__restrict__ out, int B, int
         const float bh = hi16<DT>(cq.w[k]) * (1.f - wx) + hi16<DT>(d.w[k]) * wx;
         o.w[k] = pack16<DT>(tl * (1.f - wy) + bl * wy, th * (1.f - wy) + bh * wy);
     }
-    *reinterpret_cast<uint4 *>(out + (((size_t)b * OH + oy) * OW + ox) * C + c) = o.q;
+    // streamed once by the next convolution's gather, 4x the bytes of the input: keep it out of the way of the taps in L2
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(u32x4{o.w[0], o.w[1], o.w[2], o.w[3]},
+                                reinterpret_cast<u32x4 *>(out + (((size_t)b * OH + oy) * OW + ox) * C + c));
 }
 
 // out[b,oy,ox,:] = bilinear_x2(low)[b,oy,ox,:] + y[b,oy,ox,:] for oy < OH <= 2H, ox < OW <= 2W (the DPT fusion block's

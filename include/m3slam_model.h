@@ -63,6 +63,17 @@ int m3_gemm_rope_dt(const void *A, const void *W, const float *bias, void *C, in
                     int ldc, const float *rope_tok, int tokens_per_image, int rope_cols, int q_cols,
                     float q_scale, int dtype, void *stream);
 
+/* Position mode of the fused RoPE epilogue: instead of the per-token cos/sin table (64 B read per 64 B written) the
+ * kernel takes the tokens' grid positions pos_yx int32 [tokens_per_image][2] (y, x) and computes cos/sin of
+ * pos * base^(-i/16), i = 0..15, itself (hardware sin/cos, absolute error ~1e-6; base = 100 for CroCo's RoPE100).
+ * Same results as m3_gemm_rope_dt with the table built from the same positions, to that accuracy. */
+int m3_gemm_rope_pos_dt(const void *A, const void *W, const float *bias, void *C, int M, int N, int K, int ldc,
+                        const int32_t *pos_yx, int tokens_per_image, float base, int rope_cols, int q_cols, float q_scale,
+                        int dtype, void *stream);
+int m3_gemm_grouped2_rope_pos_dt(const void *A, const void *W0, const void *W1, const float *bias0, const float *bias1,
+                                 void *C, int M, int N, int K, int ldc, int64_t a_gstride, int64_t c_gstride,
+                                 const int32_t *pos_yx, int tokens_per_image, float base, int rope_cols, int q_cols,
+                                 float q_scale, int dtype, void *stream);
 /* Two same-shape GEMMs in one launch (the two decoder branches have different weights): group g
  * (0/1) computes C + g*c_gstride = epi((A + g*a_gstride) . W[g]^T + bias[g]); strides in elements.
  * epilogue may be any M3_EPI_* including M3_EPI_BF16_ROPE (= 6; then the RoPE tables are required). */

@@ -17,6 +17,7 @@
 // pad 1 convolution over an NHWC bf16 image: K = 9*Cin, K-tile kt -> tap (kt*64)/Cin; taps that
 // fall outside the image read a 16-byte zero page instead.
 #include "gemm_common.h"
+#include <cmath>
 #include <stdlib.h>
 
 using namespace m3gemm;
@@ -381,6 +382,22 @@ int m3_gemm_rope_dt(const void *A, const void *W, const float *bias, void *C, in
     if (tile == 64) return launch<0, 64>(a, EPI_BF16_ROPE, (hipStream_t)stream);
     return launch<0>(a, EPI_BF16_ROPE, (hipStream_t)stream);
 }
+int m3_gemm_rope_pos_dt(const void *A, const void *W, const float *bias, void *C, int M, int N, int K, int ldc,
+                        const int32_t *pos_yx, int tokens_per_image, float base, int rope_cols, int q_cols, float q_scale,
+                        int dtype, void *stream) {
+    M3_REQUIRE(A && W && C && pos_yx && M > 0 && N > 0 && K > 0 && tokens_per_image > 0 && base > 1.0f && dt_ok(dtype));
+    M3_REQUIRE(q_cols >= 0 && q_cols <= rope_cols && q_cols % 64 == 0);
+    M3_REQUIRE(K % BK == 0 && N % 64 == 0 && ldc >= N && ldc % 4 == 0 && rope_cols % 64 == 0 && rope_cols <= N);
+    GemmArgs a{};
+    a.A = (const bf16_t *)A; a.W = (const bf16_t *)W; a.bias = bias; a.C = C;
+    a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.dt = dtype;
+    a.rope_pos = pos_yx; a.rope_log2_base = log2f(base); a.tokens_per_image = tokens_per_image; a.rope_cols = rope_cols;
+    a.q_cols = q_cols; a.q_scale = q_scale;
+    const int tile = pick_tile(M, N);
+    if (tile >= 192) return launch_dense_big(a, EPI_BF16_ROPE, tile, (hipStream_t)stream);
+    if (tile == 64) return launch<0, 64>(a, EPI_BF16_ROPE, (hipStream_t)stream);
+    return launch<0>(a, EPI_BF16_ROPE, (hipStream_t)stream);
+}
 int m3_gemm_bf16_rope(const void *A, const void *W, const float *bias, void *C, int M, int N, int K, int ldc,
                       const float *rope_tok, int tokens_per_image, int rope_cols, void *stream) {
     return m3_gemm_rope_dt(A, W, bias, C, M, N, K, ldc, rope_tok, tokens_per_image, rope_cols, 0, 1.0f, DT_BF16, stream);
@@ -409,6 +426,24 @@ int m3_gemm_grouped2_dt(const void *A, const void *W0, const void *W1, const flo
     if (tile >= 192) return launch_dense_big(a, epilogue, tile, (hipStream_t)stream);
     if (tile == 64) return launch<0, 64>(a, epilogue, (hipStream_t)stream);
     return launch<0>(a, epilogue, (hipStream_t)stream);
+}
+int m3_gemm_grouped2_rope_pos_dt(const void *A, const void *W0, const void *W1, const float *bias0, const float *bias1,
+                                 void *C, int M, int N, int K, int ldc, int64_t a_gstride, int64_t c_gstride,
+                                 const int32_t *pos_yx, int tokens_per_image, float base, int rope_cols, int q_cols,
+                                 float q_scale, int dtype, void *stream) {
+    M3_REQUIRE(A && W0 && W1 && C && pos_yx && M > 0 && N > 0 && K > 0 && tokens_per_image > 0 && base > 1.0f && dt_ok(dtype));
+    M3_REQUIRE(K % BK == 0 && N % 64 == 0 && ldc >= N && ldc % 4 == 0 && (bias0 == nullptr) == (bias1 == nullptr));
+    M3_REQUIRE(rope_cols % 64 == 0 && rope_cols <= N && q_cols >= 0 && q_cols <= rope_cols && q_cols % 64 == 0);
+    GemmArgs a{};
+    a.A = (const bf16_t *)A; a.W = (const bf16_t *)W0; a.W2 = (const bf16_t *)W1; a.bias = bias0; a.bias2 = bias1;
+    a.C = C; a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.dt = dtype;
+    a.a_gstride = a_gstride; a.c_gstride = c_gstride; a.groups = 2;
+    a.rope_pos = pos_yx; a.rope_log2_base = log2f(base); a.tokens_per_image = tokens_per_image; a.rope_cols = rope_cols;
+    a.q_cols = q_cols; a.q_scale = q_scale;
+    const int tile = pick_tile(M, N, 2);
+    if (tile >= 192) return launch_dense_big(a, EPI_BF16_ROPE, tile, (hipStream_t)stream);
+    if (tile == 64) return launch<0, 64>(a, EPI_BF16_ROPE, (hipStream_t)stream);
+    return launch<0>(a, EPI_BF16_ROPE, (hipStream_t)stream);
 }
 int m3_gemm_bf16_grouped2(const void *A, const void *W0, const void *W1, const float *bias0, const float *bias1,
                           void *C, const void *R, int M, int N, int K, int ldc, int64_t a_gstride,

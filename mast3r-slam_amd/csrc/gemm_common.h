@@ -104,7 +104,9 @@ struct GemmArgs {
     // conv geometry
     int H, Wd, Cin, OH, OW, stride;
     // fused RoPE-2D epilogue (EPI_BF16_ROPE): columns < rope_cols are 64-wide heads to rotate
-    const float *rope_tok;  // [tokens_per_image, 2 (y|x), 2 (cos|sin), 16]
+    const float *rope_tok;  // [tokens_per_image, 2 (y|x), 2 (cos|sin), 16]; or, position mode:
+    const int *rope_pos;    // [tokens_per_image, 2 (y|x)] grid positions - cos/sin are then computed in the epilogue
+    float rope_log2_base;   //   from frequencies base^(-i/16), i = 0..15 (v_sin_f32 / v_cos_f32, arguments in revolutions)
     int tokens_per_image, rope_cols;
     int q_cols;             // columns < q_cols (the q heads) are multiplied by q_scale after the rotation, before the
     float q_scale;          // 16-bit rounding: softmax scale * log2(e) folded into q (attention then needs no per-score FMA)
@@ -185,8 +187,21 @@ __device__ __forceinline__ void store_tile(const GemmArgs &g, f32x4 v, int m, in
 // per-row branches) made every row a dependent chain of two L2 round trips: 128 us instead of 93 us for
 // the 16384 x 3072 x 1024 projection.
 struct RopeCoef { float4 c, s; };               // cos / sin of frequencies fi .. fi+3
+// Position mode (g.rope_pos): the table read is 64 B of cos/sin per 64 B of output, fetched as 16 rows x 64 B pieces by
+// every wave that shares a row - by ablation ~10 us of a 105 us projection, while the rotation arithmetic itself is free.
+// One 4-byte position per (row, axis) and eight transcendentals per 32-column block replace it: angle in revolutions =
+// pos * base^(-i/16) / 2pi (at most ~10 for a 64 x 64 token grid; v_sin_f32's domain is +-256), absolute error ~1e-6.
+struct RopeFreq { float rev[4]; };              // this lane's four frequencies (columns fi..fi+3 of a 16-wide group) / 2pi
+__device__ __forceinline__ RopeFreq rope_freqs(const GemmArgs &g, int lane) {
+    RopeFreq f;
+    const int fi = (lane >> 4) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) f.rev[k] = exp2f(-(float)(fi + k) * (g.rope_log2_base * (1.0f / 16.0f))) * 0.15915494309189535f;
+    return f;
+}
 template <int NJ>
-__device__ __forceinline__ void rope_load(const GemmArgs &g, RopeCoef (&cf)[NJ / 2], int m, int n_base, int lane) {
+__device__ __forceinline__ void rope_load(const GemmArgs &g, RopeCoef (&cf)[NJ / 2], int m, int n_base, int lane,
+                                          const RopeFreq &fr) {
     const int mm = m < g.M ? m : g.M - 1;
     const int tok = mm % g.tokens_per_image;
     const int fi = (lane >> 4) * 4;
@@ -194,9 +209,17 @@ __device__ __forceinline__ void rope_load(const GemmArgs &g, RopeCoef (&cf)[NJ /
     for (int blk = 0; blk < NJ / 2; ++blk) {
         if (n_base + 32 * blk >= g.rope_cols) continue;                 // wave-uniform: v columns are not rotated
         const int axis = ((n_base + 32 * blk) >> 5) & 1;                 // 0: y, 1: x
-        const float *row = g.rope_tok + (size_t)(tok * 2 + axis) * 32 + fi;
-        cf[blk].c = *reinterpret_cast<const float4 *>(row);
-        cf[blk].s = *reinterpret_cast<const float4 *>(row + 16);
+        if (g.rope_pos) {                                                // kernel-uniform
+            const float pos = (float)g.rope_pos[tok * 2 + axis];
+            cf[blk].c = make_float4(__builtin_amdgcn_cosf(pos * fr.rev[0]), __builtin_amdgcn_cosf(pos * fr.rev[1]),
+                                    __builtin_amdgcn_cosf(pos * fr.rev[2]), __builtin_amdgcn_cosf(pos * fr.rev[3]));
+            cf[blk].s = make_float4(__builtin_amdgcn_sinf(pos * fr.rev[0]), __builtin_amdgcn_sinf(pos * fr.rev[1]),
+                                    __builtin_amdgcn_sinf(pos * fr.rev[2]), __builtin_amdgcn_sinf(pos * fr.rev[3]));
+        } else {
+            const float *row = g.rope_tok + (size_t)(tok * 2 + axis) * 32 + fi;
+            cf[blk].c = *reinterpret_cast<const float4 *>(row);
+            cf[blk].s = *reinterpret_cast<const float4 *>(row + 16);
+        }
     }
 }
 // (bias add +) rotation on packed pairs: 8 v_pk_* per 32-column block instead of 16 + 16 scalar ops
@@ -235,7 +258,7 @@ __device__ __forceinline__ void rope_strip(const GemmArgs &g, f32x4 *t, int m, i
         bj[j] = (g.bias && n_base + j * 16 + fi < g.N) ? *reinterpret_cast<const float4 *>(g.bias + n_base + j * 16 + fi)
                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
     RopeCoef cf[NJ / 2];
-    rope_load<NJ>(g, cf, m, n_base, lane);
+    rope_load<NJ>(g, cf, m, n_base, lane, rope_freqs(g, lane));
     rope_apply<NJ>(g, t, cf, bj, n_base);
 }
 
@@ -352,12 +375,14 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
         constexpr int RS = NJ * 32 + 16;                          // 16*NJ bf16 + 16 bytes of padding
         constexpr int TP = NI < 4 ? NI : 4;                       // accumulator row tiles per pass
         constexpr int PR = 16 * TP, CPR = NJ * 2;                 // rows per pass, 16-byte chunks (8 columns) per row
+        RopeFreq fr{};
+        if constexpr (EPI == EPI_BF16_ROPE) { if (g.rope_pos) fr = rope_freqs(g, lane); }
 #pragma unroll
         for (int pass = 0; pass < NI / TP; ++pass) {
             RopeCoef cf[EPI == EPI_BF16_ROPE ? TP : 1][NJ / 2];
             if constexpr (EPI == EPI_BF16_ROPE) {                 // all coefficient reads of the pass in flight at once
 #pragma unroll
-                for (int ii = 0; ii < TP; ++ii) rope_load<NJ>(g, cf[ii], m_base + (pass * TP + ii) * 16 + r, n_base, lane);
+                for (int ii = 0; ii < TP; ++ii) rope_load<NJ>(g, cf[ii], m_base + (pass * TP + ii) * 16 + r, n_base, lane, fr);
             }
 #pragma unroll
             for (int ii = 0; ii < TP; ++ii) {

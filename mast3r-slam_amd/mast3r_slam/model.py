@@ -275,15 +275,14 @@ class Mast3rFull:
 
     # ------------------------------------------------------------------ helpers
     def _rope(self, gh: int, gw: int):
+        """The fused RoPE epilogue's operand for a gh x gw token grid: int32 [T,2] positions (y, x); the kernels compute
+        cos/sin of pos * base^(-i/16) themselves (ops.gemm_rope).  rope_base must be ops.ROPE_BASE for the grouped launches."""
         key = (gh, gw)
         if key not in self._rope_cache:
-            n = max(gh, gw) + 1
-            inv = 1.0 / (self.cfg["rope_base"] ** (torch.arange(0, 32, 2, dtype=torch.float32) / 32.0))
-            ang = torch.arange(n, dtype=torch.float32)[:, None] * inv[None, :]
-            cs = torch.stack([ang.cos(), ang.sin()], dim=-1).to(self.device).contiguous()       # [n,16,2]
+            if float(self.cfg["rope_base"]) != ops.ROPE_BASE:
+                raise ValueError(f"rope_base {self.cfg['rope_base']} is not supported by the fused epilogue ({ops.ROPE_BASE})")
             gy, gx = torch.meshgrid(torch.arange(gh), torch.arange(gw), indexing="ij")
-            pos = torch.stack([gy.reshape(-1), gx.reshape(-1)], -1).to(torch.int32).to(self.device).contiguous()
-            self._rope_cache[key] = ops.rope_token_table(pos, cs)                 # [T,2,2,16] per token: axis, cos|sin, frequency
+            self._rope_cache[key] = torch.stack([gy.reshape(-1), gx.reshape(-1)], -1).to(torch.int32).to(self.device).contiguous()
         return self._rope_cache[key]
 
     def _as_images(self, img) -> torch.Tensor:

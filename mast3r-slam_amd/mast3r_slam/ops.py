@@ -107,11 +107,24 @@ def rope_token_table(pos_yx, cos_sin):
 QK_PRESCALE = 0.125 * 1.4426950408889634     # softmax scale (head dim 64) * log2(e), folded into q by the RoPE epilogue
 
 
-def gemm_rope(a, w, bias, rope_tok, rope_cols: int, q_cols: int = 0, q_scale: float = 1.0):
+ROPE_BASE = 100.0                            # CroCo "RoPE100"
+
+
+def _rope_table(t):
+    """The `rope` operand of the fused epilogue: int32 [T,2] grid positions (y, x) - cos/sin computed in the kernel -
+    or float32 [T,2,2,16] per-token cos/sin table (rope_token_table).  Returns (tensor, tokens_per_image, by_position)."""
+    if isinstance(t, torch.Tensor) and t.dtype == torch.int32:
+        t = _ffi.check(t, torch.int32, "rope positions", (None, 2))
+        return t, t.shape[0], True
+    t = _ffi.check(t, torch.float32, "rope_tok", (None, 2, 2, 16))
+    return t, t.shape[0], False
+
+
+def gemm_rope(a, w, bias, rope_tok, rope_cols: int, q_cols: int = 0, q_scale: float = 1.0, base: float = ROPE_BASE):
     """16-bit out[M,N] = a @ w.T + bias with RoPE-2D applied to the 64-wide heads in columns < rope_cols;
-    rope_tok f32 [tokens_per_image,2,2,16] (rope_token_table)."""
-    rope_tok = _ffi.check(rope_tok, torch.float32, "rope_tok", (None, 2, 2, 16))
-    tokens_per_image = rope_tok.shape[0]
+    rope_tok: int32 [tokens_per_image,2] token grid positions (frequencies base^(-i/16)) or the f32
+    [tokens_per_image,2,2,16] table of rope_token_table."""
+    rope_tok, tokens_per_image, by_pos = _rope_table(rope_tok)
     a = _ffi.check(a, H16, "a")
     w = _ffi.check(w, H16, "w")
     dt = _same16(a, w)
@@ -119,8 +132,12 @@ def gemm_rope(a, w, bias, rope_tok, rope_cols: int, q_cols: int = 0, q_scale: fl
     n = w.shape[0]
     out = torch.empty((m, n), dtype=a.dtype, device=a.device)
     e0 = _prof_begin()
-    _ffi.call("m3_gemm_rope_dt", _ffi.ptr(a), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(out), m, n, k, n,
-              _ffi.ptr(rope_tok), tokens_per_image, rope_cols, int(q_cols), float(q_scale), dt, _ffi.stream_ptr())
+    if by_pos:
+        _ffi.call("m3_gemm_rope_pos_dt", _ffi.ptr(a), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(out), m, n, k, n,
+                  _ffi.ptr(rope_tok), tokens_per_image, float(base), rope_cols, int(q_cols), float(q_scale), dt, _ffi.stream_ptr())
+    else:
+        _ffi.call("m3_gemm_rope_dt", _ffi.ptr(a), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(out), m, n, k, n,
+                  _ffi.ptr(rope_tok), tokens_per_image, rope_cols, int(q_cols), float(q_scale), dt, _ffi.stream_ptr())
     _prof_end(e0, _gemm_kind(m, n), 2.0 * m * n * k, 2.0 * (m * k + n * k + m * n))
     return out
 
@@ -401,7 +418,7 @@ def add(a, b):
 
 def gemm_grouped2(a, w0, w1, b0, b1, epi=EPI_BF16, out=None, resid=None, rope=None):
     """Two same-shape GEMMs in one launch.  a [2,M,K] bf16, weights [N,K] x2 -> out [2,M,N].
-    rope = (rope_tok [T,2,2,16] f32, rope_cols[, q_cols, q_scale]) with epi=EPI_BF16_ROPE."""
+    rope = (positions int32 [T,2] or table f32 [T,2,2,16], rope_cols[, q_cols, q_scale]) with epi=EPI_BF16_ROPE."""
     a = _ffi.check(a, H16, "a")
     if a.dim() != 3 or a.shape[0] != 2:
         raise ValueError(f"a must be [2,M,K], got {tuple(a.shape)}")
@@ -419,13 +436,18 @@ def gemm_grouped2(a, w0, w1, b0, b1, epi=EPI_BF16, out=None, resid=None, rope=No
     if resid is not None and (resid.dtype != odt or tuple(resid.shape) != tuple(out.shape) or not resid.is_contiguous()):
         raise ValueError("bad `resid`")
     rtok, rc, qc, qs = (tuple(rope) + (0, 1.0))[:4] if rope is not None else (None, 0, 0, 1.0)
-    tpi = 0
+    tpi, by_pos = 0, False
     if rtok is not None:
-        rtok = _ffi.check(rtok, torch.float32, "rope_tok", (None, 2, 2, 16))
-        tpi = rtok.shape[0]
+        rtok, tpi, by_pos = _rope_table(rtok)
     e0 = _prof_begin()
-    _ffi.call("m3_gemm_grouped2_dt", _ffi.ptr(a), _ffi.ptr(w0), _ffi.ptr(w1), _ffi.ptr(b0), _ffi.ptr(b1), _ffi.ptr(out),
-              _ffi.ptr(resid), m, n, k, ldc, m * k, m * ldc, epi, _ffi.ptr(rtok), tpi, rc, int(qc), float(qs), dt, _ffi.stream_ptr())
+    if by_pos:
+        if epi != EPI_BF16_ROPE or resid is not None:
+            raise ValueError("rope positions go with epi=EPI_BF16_ROPE and no residual")
+        _ffi.call("m3_gemm_grouped2_rope_pos_dt", _ffi.ptr(a), _ffi.ptr(w0), _ffi.ptr(w1), _ffi.ptr(b0), _ffi.ptr(b1), _ffi.ptr(out),
+                  m, n, k, ldc, m * k, m * ldc, _ffi.ptr(rtok), tpi, float(ROPE_BASE), rc, int(qc), float(qs), dt, _ffi.stream_ptr())
+    else:
+        _ffi.call("m3_gemm_grouped2_dt", _ffi.ptr(a), _ffi.ptr(w0), _ffi.ptr(w1), _ffi.ptr(b0), _ffi.ptr(b1), _ffi.ptr(out),
+                  _ffi.ptr(resid), m, n, k, ldc, m * k, m * ldc, epi, _ffi.ptr(rtok), tpi, rc, int(qc), float(qs), dt, _ffi.stream_ptr())
     _prof_end(e0, _gemm_kind(m, n, 2), 4.0 * m * n * k,
               2.0 * (2.0 * (m * k + n * k) + out.element_size() * m * n * (1 if resid is None else 2)))
     return out

@@ -409,6 +409,12 @@ def test_gemm_with_fused_rope_epilogue(dev, m_n_k):
     cs = torch.stack([cos, sin], -1).to(dev).contiguous()
     out = ops.gemm_rope(a.to(dev), w.to(dev), b.to(dev), ops.rope_token_table(pos.to(dev), cs), rope_cols)
     assert _rel(out, ref) < 3e-3
+    # position mode: cos/sin computed in the epilogue from the tokens' grid positions (hardware sin/cos, ~1e-6 absolute):
+    # the same result as the table to far below the 16-bit rounding of the output
+    out_p = ops.gemm_rope(a.to(dev), w.to(dev), b.to(dev), pos.to(torch.int32).to(dev).contiguous(), rope_cols)
+    assert _rel(out_p, ref) < 3e-3
+    assert float((out_p.float() - out.float()).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())     # at most one bf16 ulp apart
+    assert float((out_p != out).float().mean()) < 0.02
 
 
 def test_frame_tracker_end_to_end(tiny, dev):

@@ -155,6 +155,16 @@ def _pad_to(t: torch.Tensor, dim: int, size: int) -> torch.Tensor:
     return torch.cat([t, torch.zeros(shape, dtype=t.dtype)], dim=dim)
 
 
+def _pair2(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """[2, *a.shape] from two same-shape tensors: a strided view when b directly follows a in the same storage (the two
+    halves of a 2-group operator's output), a copy otherwise."""
+    if (a.shape == b.shape and a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous()
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            and b.data_ptr() == a.data_ptr() + a.numel() * a.element_size()):
+        return torch.as_strided(a, (2,) + tuple(a.shape), (a.numel(),) + tuple(a.stride()))
+    return torch.stack([a, b])
+
+
 def _ceil64(n: int) -> int:
     return (n + 63) // 64 * 64
 
@@ -361,7 +371,11 @@ class Mast3rFull:
                               P["decoder_embed.b"], ops.EPI_F32)                         # fp32 residual streams [2,M,D]
         # tap 0 = the cached encoder features; the heads read them in their own 16-bit type (bf16 -> fp16 is exact
         # for these LayerNorm outputs: fp16 has more mantissa bits and |x| << 65504)
-        taps = [[f1 if hdt == dt else ops.cast16(f1, hdt)], [f2 if hdt == dt else ops.cast16(f2, hdt)]]
+        if hdt == dt:
+            taps = [[f1], [f2]]
+        else:
+            c16 = ops.cast16(fcat.reshape(2 * m, -1), hdt)                              # one launch; halves stay adjacent for heads()
+            taps = [[c16[:m]], [c16[m:]]]
         hooks = set(c["hooks"])
         W = lambda i, s: (P[f"dec_blocks.{i}.{s}"], P[f"dec_blocks2.{i}.{s}"])
         for i in range(c["dec_depth"]):
@@ -507,7 +521,7 @@ class Mast3rFull:
         ld = c["layer_dims"]
         dev = taps1[0].device
         W = lambda s: (P[h1 + s], P[h2 + s])
-        T = [torch.stack([a, b]) for a, b in zip(taps1, taps2)]                       # [2, M, C]
+        T = [_pair2(a, b) for a, b in zip(taps1, taps2)]                               # [2, M, C], a view when the halves are adjacent
         gem = lambda x, s, epi=ops.EPI_BF16, out=None: ops.gemm_grouped2(x, *W(s + ".w"), *W(s + ".b"), epi, out=out)
         k0, k1 = _ceil64(ld[0]), _ceil64(ld[1])
         t0 = gem(T[0], d + ".act_postprocess.0.0", out=torch.zeros((2, m, k0), dtype=self.hdt, device=dev) if k0 != ld[0] else None)

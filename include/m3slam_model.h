@@ -159,8 +159,11 @@ int m3_attention_dt(const void *Q, const void *K, const void *V, void *O, int q_
 int m3_rope2d_bf16(void *X, const int32_t *pos_yx, const float *cos_sin, int row_stride, int tokens,
                    int heads, int tokens_per_image, void *stream);
 /* The same with q PRE-SCALED by softmax scale * log2(e) (m3_gemm_rope_dt's q_scale): a score is an exp2 argument as
- * it leaves the matrix core, the running reference maximum enters the MFMA as its accumulator initialiser, and the
- * rescale of the output runs only when a tile's maximum exceeds the reference by 2^8 (deferred maximum). */
+ * it leaves the matrix core and the reference maximum enters the MFMA as its accumulator initialiser.  fp16 operands:
+ * the tile maximum is tracked and the output rescaled only when it exceeds the reference by 2^8.  bf16 operands: the
+ * reference is the first key tile's maximum, row sums are accumulated by the matrix core, the range is kept by a 2^-64
+ * rescale when a row sum passes 2^60, and a workgroup whose exp2 overflowed (a score more than 127 above that
+ * reference) recomputes its query block with the tracking loop - same result to the rounding of P. */
 int m3_attention_prescaled_dt(const void *Q, const void *K, const void *V, void *O, int q_row_stride,
                               int kv_row_stride, int o_row_stride, int64_t q_batch_stride,
                               int64_t kv_batch_stride, int64_t o_batch_stride, int nbatch, int heads,

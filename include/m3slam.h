@@ -10,7 +10,10 @@
  *   - all pointers are DEVICE pointers (hipMalloc / torch ROCm storage) unless
  *     the parameter is documented as "host"; arrays are C-contiguous;
  *   - the caller owns and allocates every buffer, including workspaces; the
- *     library allocates nothing and keeps no global state;
+ *     library allocates nothing and keeps no mutable state between calls except
+ *     per-kernel, per-device "large-LDS opt-in done" bits (atomic; a process may
+ *     drive several devices from several threads) and the thread-local text of
+ *     the last HIP error;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work
  *     is stream-ordered and asynchronous, nothing synchronises the host;
  *   - return value: M3_OK (0) or a negative m3_status; no silent fallback exists;
@@ -263,7 +266,10 @@ int m3_gn_rays_step(float *Twc, const double *blocks, const int32_t *ii, const i
 
 /* linalg.cholesky_solve (linalg.py:17-50) for a system of any size: (H + shift I) x = b in float64 by blocked
  * Cholesky (block 64), stream-ordered.  H [dim,dim] row-major (lower triangle read; destroyed), b [dim]
- * (destroyed), x [dim], ws double[1 + dim]: ws[0] = 0 ok / 1 not positive definite. */
+ * (destroyed), x [dim], ws double[m3_chol_ws_doubles(dim)]: ws[0] = 0 ok / 1 not positive definite (the rest is
+ * scratch: the substitution vector and the 64 x 64 diagonal factors, which are kept OUT of H so that no
+ * workgroup of a panel launch ever reads a diagonal block another one has already overwritten). */
+int64_t m3_chol_ws_doubles(int dim);
 int m3_chol_solve(double *H, double *b, double *x, double *ws, int dim, double shift, void *stream);
 
 #ifdef __cplusplus

@@ -65,9 +65,11 @@ struct AttnArgs {
 //     the reference, so a lagging one costs no accuracy - numerator and denominator carry the same factor.  The row
 //     sums are one more MFMA per (query tile, k-step) against an all-ones A fragment - l accumulates in a matrix-core
 //     register across tiles, already summed over the lane groups, and sums exactly the rounded P that multiplies V.
-//     A per-lane test before the next tile (l > 2^60 -> scale o, l by 2^-64 and move m_ref) keeps the range; if a score
-//     ever exceeds the reference by more than 127 (exp2 overflow - not seen on any network input, but possible in
-//     principle) l ends non-finite and the WHOLE workgroup recomputes its block with the MODE 1 loop.
+//     A per-lane test before the next tile (l > 2^60 -> scale o, l by 2^-64 and move m_ref) keeps the range.  Overflow
+//     (a score far above the reference - not seen on any network input, but possible in principle) makes the WHOLE
+//     workgroup recompute its block with the MODE 1 loop.  The test is sticky and conservative: l > 2^100 at a range
+//     check or at the end (then o = sum p v may already be inf although l = sum p is finite - l alone would come back
+//     into range and hide it: round-2 advisor finding), a non-finite l, or a non-finite o at the end.
 #define M3_ATTN_EXP 0
 constexpr float kDefer = 8.0f;
 template <int QT, int DT, int MODE>
@@ -118,6 +120,7 @@ k_attn(const AttnArgs a) {
 
     f32x4 o[QT][4];
     float m_run[QT], l_run[QT];
+    bool ovf = false;                                             // MODE 2: sticky "a row sum left the safe range"
     const int nt = (a.Tk + KT - 1) / KT;
     const int tq = lq >> 2, tp = lq & 3;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -157,6 +160,7 @@ k_attn(const AttnArgs a) {
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) {
                         const bool hit = l_acc[qt][0] > 0x1p60f;
+                        ovf |= !(l_acc[qt][0] <= 0x1p100f);          // sticky: o may have overflowed where l has not
                         const float alpha = hit ? 0x1p-64f : 1.0f;
                         m_run[qt] += hit ? 64.0f : 0.0f;
 #pragma unroll
@@ -355,9 +359,15 @@ k_attn(const AttnArgs a) {
 
     if constexpr (MODE == 2) {
         run(std::integral_constant<int, 2>{});
-        bool bad = false;
+        bool bad = ovf;
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) bad |= !(l_run[qt] > 0.f && l_run[qt] < INFINITY);
+        for (int qt = 0; qt < QT; ++qt) {
+            bad |= !(l_run[qt] > 0.f && l_run[qt] <= 0x1p100f);
+            float osum = 0.f;                                     // inf / NaN anywhere in the row's outputs survives the sum
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) osum += (o[qt][dt][0] + o[qt][dt][1]) + (o[qt][dt][2] + o[qt][dt][3]);
+            bad |= !(fabsf(osum) < INFINITY);
+        }
 #if M3_ATTN_EXP == 3
         bad = true;
 #endif

@@ -23,6 +23,25 @@ void m3_set_hip_error(hipError_t e, const char *where);
 
 static inline int m3_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE opt-in: a process that drives several GPUs (one host
+// thread per device) has to make it on each of them, and two threads may arrive together.  One bit per device in an
+// atomic mask per kernel instantiation; setting the attribute twice is harmless, so the only requirement is that a
+// launch on device d never precedes the opt-in on device d.
+//   static M3AttrOnce once; int dev;
+//   if (m3_attr_need(once, &dev)) { hipFuncSetAttribute(...); m3_attr_done(once, dev); }
+#include <atomic>
+struct M3AttrOnce { std::atomic<unsigned long long> mask{0}; };
+static inline bool m3_attr_need(M3AttrOnce &o, int *dev) {
+    int d = 0;
+    *dev = -1;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) return true;         // unknown device: opt in every time
+    *dev = d;
+    return !((o.mask.load(std::memory_order_acquire) >> d) & 1ull);
+}
+static inline void m3_attr_done(M3AttrOnce &o, int dev) {
+    if (dev >= 0) o.mask.fetch_or(1ull << dev, std::memory_order_release);
+}
+
 // ---- wave / block reductions (wave = 64 lanes) --------------------------------
 __device__ __forceinline__ double m3_wave_sum(double v) {
 #pragma unroll

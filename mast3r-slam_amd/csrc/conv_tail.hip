@@ -349,11 +349,12 @@ static int dpt_tail_launch(const void *X, const void *Wc, const float *bias, con
     hipStream_t st = (hipStream_t)stream;
 #define M3_TAIL(DTV, UP)                                                                                         \
     do {                                                                                                         \
-        static bool attr_set = false;                                                                            \
-        if (!attr_set) {                                                                                         \
+        static M3AttrOnce once;                                                                                  \
+        int dev__;                                                                                               \
+        if (m3_attr_need(once, &dev__)) {                                                                        \
             M3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_tail<DTV, UP>),              \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes), "m3_dpt_tail/attr"); \
-            attr_set = true;                                                                                     \
+            m3_attr_done(once, dev__);                                                                           \
         }                                                                                                        \
         hipLaunchKernelGGL((k_conv_tail<DTV, UP>), grid, blk, kLdsBytes, st, a);                                 \
     } while (0)

@@ -211,12 +211,13 @@ int launch256(const GemmArgs &a, int epi, hipStream_t st) {
     dim3 grid(tiles, a.groups > 1 ? a.groups : 1), blk(kThreads);
 #define M3_L(E)                                                                                              \
     case E: {                                                                                                \
-        static bool attr_set = false;                                                                        \
-        if (!attr_set) {                                                                                     \
+        static M3AttrOnce once;                                                                              \
+        int dev__;                                                                                           \
+        if (m3_attr_need(once, &dev__)) {                                                                    \
             M3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm256<MODE, E, BN, DT>),        \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes),         \
                          "m3_gemm256/attr");                                                                 \
-            attr_set = true;                                                                                 \
+            m3_attr_done(once, dev__);                                                                       \
         }                                                                                                    \
         hipLaunchKernelGGL((k_gemm256<MODE, E, BN, DT>), grid, blk, kLdsBytes, st, a);                           \
     } break

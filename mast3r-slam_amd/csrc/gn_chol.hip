@@ -6,7 +6,11 @@
 // Right-looking blocked factorisation, block size 64, entirely stream-ordered (no host round trip; a failed pivot
 // sets a device flag that turns every later kernel of the solve into a no-op):
 //   step k:  k_chol_panel   every row block i >= k:  factor the diagonal block (64 x 64, in LDS - recomputed by each
-//                           workgroup instead of a separate launch + boundary), then L_ik = A_ik L_kk^-T
+//                           workgroup instead of a separate launch + boundary), then L_ik = A_ik L_kk^-T.  The factor
+//                           L_kk goes to a SEPARATE buffer (Ld [nblk][64][64]): A_kk in H is read by every workgroup of
+//                           the launch, at times the dispatcher chooses (a workgroup that starts late - CUs busy with
+//                           another stream's kernels - must still find A_kk, not L_kk: round-2 advisor finding), so
+//                           nothing overwrites it; the substitution kernels read L_kk from Ld.
 //            k_chol_update  every lower block pair i >= j > k:  A_ij -= L_ik L_jk^T
 //   then forward substitution (one launch per block column: y_k = L_kk^-1 b_k, b_i -= L_ik y_k for i > k) and
 //   backward substitution (x_k = L_kk^-T y_k, y_j -= L_kj^T x_k for j < k).
@@ -47,7 +51,8 @@ __device__ bool chol_diag_lds(double (*d)[NB + 1], int nb, int *bad) {
 
 // grid.x = row block i - k (0 = the diagonal block itself); adds `shift` to the diagonal of block k first
 __global__ void __launch_bounds__(kThreads)
-k_chol_panel(double *__restrict__ H, int dim, int k, double shift, double *__restrict__ fail, const double *__restrict__ off) {
+k_chol_panel(double *__restrict__ H, double *__restrict__ Ld, int dim, int k, double shift, double *__restrict__ fail,
+             const double *__restrict__ off) {
     if (solve_off(off) || fail[0] != 0.0) return;
     __shared__ double d[NB][NB + 1];
     __shared__ double a[NB][NB + 1];
@@ -64,10 +69,11 @@ k_chol_panel(double *__restrict__ H, int dim, int k, double shift, double *__res
         return;
     }
     const int ib = k + blockIdx.x;
-    if (blockIdx.x == 0) {                                   // write L_kk back
-        for (int idx = t; idx < nb * nb; idx += kThreads) {
-            const int r = idx / nb, c = idx % nb;
-            if (c <= r) H[(size_t)(k0 + r) * dim + k0 + c] = d[r][c];
+    if (blockIdx.x == 0) {                                   // L_kk -> Ld[k] (never over A_kk: the other workgroups read it)
+        double *L = Ld + (size_t)k * NB * NB;
+        for (int idx = t; idx < NB * NB; idx += kThreads) {
+            const int r = idx / NB, c = idx % NB;
+            L[idx] = (r < nb && c <= r) ? d[r][c] : 0.0;
         }
         return;
     }
@@ -125,13 +131,13 @@ k_chol_update(double *__restrict__ H, int dim, int k, const double *__restrict__
 // forward: grid.x = row block i - k; every workgroup solves y_k = L_kk^-1 b_k from an LDS copy of L_kk (64 sequential
 // steps), block 0 stores it, block i > 0 then does b_i -= L_ik y_k.
 __global__ void __launch_bounds__(kThreads)
-k_chol_fwd(const double *__restrict__ H, double *__restrict__ b, double *__restrict__ yout, int dim, int k,
-           const double *__restrict__ fail, const double *__restrict__ off) {
+k_chol_fwd(const double *__restrict__ H, const double *__restrict__ Ld, double *__restrict__ b, double *__restrict__ yout,
+           int dim, int k, const double *__restrict__ fail, const double *__restrict__ off) {
     if (solve_off(off) || fail[0] != 0.0) return;
     __shared__ double d[NB][NB + 1];
     __shared__ double y[NB];
     const int t = threadIdx.x, k0 = k * NB, nb = min(NB, dim - k0);
-    for (int idx = t; idx < nb * nb; idx += kThreads) d[idx / nb][idx % nb] = H[(size_t)(k0 + idx / nb) * dim + k0 + idx % nb];
+    for (int idx = t; idx < NB * NB; idx += kThreads) d[idx / NB][idx % NB] = Ld[(size_t)k * NB * NB + idx];
     if (t < nb) y[t] = b[k0 + t];                             // b_k is final (earlier launches); nobody writes it here:
     __syncthreads();                                          // the solved block goes to a SEPARATE vector, the other
     for (int c = 0; c < nb; ++c) {                            // workgroups of this launch are reading b_k right now
@@ -156,14 +162,14 @@ k_chol_fwd(const double *__restrict__ H, double *__restrict__ b, double *__restr
 
 // backward: grid.x = k - j (0 = the diagonal block): x_k = L_kk^-T y_k, then y_j -= L_kj^T x_k for the blocks j < k
 __global__ void __launch_bounds__(kThreads)
-k_chol_bwd(const double *__restrict__ H, double *__restrict__ yv, double *__restrict__ xout, int dim, int k,
-           const double *__restrict__ fail, const double *__restrict__ off) {
+k_chol_bwd(const double *__restrict__ H, const double *__restrict__ Ld, double *__restrict__ yv, double *__restrict__ xout,
+           int dim, int k, const double *__restrict__ fail, const double *__restrict__ off) {
     if (solve_off(off) || fail[0] != 0.0) return;
     __shared__ double d[NB][NB + 1];
     __shared__ double y[NB];
     __shared__ double red[kThreads / NB][NB];
     const int t = threadIdx.x, k0 = k * NB, nb = min(NB, dim - k0);
-    for (int idx = t; idx < nb * nb; idx += kThreads) d[idx / nb][idx % nb] = H[(size_t)(k0 + idx / nb) * dim + k0 + idx % nb];
+    for (int idx = t; idx < NB * NB; idx += kThreads) d[idx / NB][idx % NB] = Ld[(size_t)k * NB * NB + idx];
     if (t < nb) y[t] = yv[k0 + t];
     __syncthreads();
     for (int c = nb - 1; c >= 0; --c) {
@@ -188,24 +194,28 @@ k_chol_bwd(const double *__restrict__ H, double *__restrict__ yv, double *__rest
 
 }  // namespace
 
-// (H + shift I) x = b: H [dim, dim] row-major float64 (lower triangle read, overwritten by L), b [dim] (destroyed),
-// y [dim] scratch, x [dim] out.  fail[0] is set to 1 on a non-positive pivot (then x is garbage); `off` (may be null):
-// when off[0] != 0 the whole sequence is a no-op (the solver's device-side stop flag).
-int m3_chol_solve_launch(double *H, double *b, double *y, double *x, double *fail, const double *off, int dim,
+// (H + shift I) x = b: H [dim, dim] row-major float64 (lower triangle read; the off-diagonal blocks are overwritten by
+// L, the diagonal blocks keep A_kk of the running factorisation), b [dim] (destroyed), y [dim] scratch, Ld
+// [m3_chol_diag_doubles(dim)] scratch for the diagonal factors, x [dim] out.  fail[0] is set to 1 on a non-positive
+// pivot (then x is garbage); `off` (may be null): when off[0] != 0 the whole sequence is a no-op (the solver's
+// device-side stop flag).
+int64_t m3_chol_diag_doubles(int dim) { return (int64_t)((dim + NB - 1) / NB) * NB * NB; }
+
+int m3_chol_solve_launch(double *H, double *b, double *y, double *x, double *Ld, double *fail, const double *off, int dim,
                          double shift, hipStream_t st) {
     const int nblk = (dim + NB - 1) / NB;
     for (int k = 0; k < nblk; ++k) {
-        hipLaunchKernelGGL(k_chol_panel, dim3(nblk - k), dim3(kThreads), 0, st, H, dim, k, shift, fail, off);
+        hipLaunchKernelGGL(k_chol_panel, dim3(nblk - k), dim3(kThreads), 0, st, H, Ld, dim, k, shift, fail, off);
         if (k + 1 < nblk)
             hipLaunchKernelGGL(k_chol_update, dim3(nblk - k - 1, nblk - k - 1), dim3(kThreads), 0, st, H, dim, k,
                                (const double *)fail, off);
     }
     for (int k = 0; k < nblk; ++k)
-        hipLaunchKernelGGL(k_chol_fwd, dim3(nblk - k), dim3(kThreads), 0, st, (const double *)H, b, y, dim, k,
-                           (const double *)fail, off);
+        hipLaunchKernelGGL(k_chol_fwd, dim3(nblk - k), dim3(kThreads), 0, st, (const double *)H, (const double *)Ld, b, y,
+                           dim, k, (const double *)fail, off);
     for (int k = nblk - 1; k >= 0; --k)
-        hipLaunchKernelGGL(k_chol_bwd, dim3(k + 1), dim3(kThreads), 0, st, (const double *)H, y, x, dim, k,
-                           (const double *)fail, off);
+        hipLaunchKernelGGL(k_chol_bwd, dim3(k + 1), dim3(kThreads), 0, st, (const double *)H, (const double *)Ld, y, x, dim,
+                           k, (const double *)fail, off);
     M3_CHECK_LAUNCH("m3_chol_solve");
     return M3_OK;
 }
@@ -213,13 +223,15 @@ int m3_chol_solve_launch(double *H, double *b, double *y, double *x, double *fai
 extern "C" {
 
 // Level-1 entry (linalg.cholesky_solve, linalg.py:17-50, for systems of any size): solves (H + shift I) x = b.
-// H [dim,dim] float64 row-major (destroyed), b [dim] (destroyed), x [dim] out, ws: 1 + dim doubles
+// H [dim,dim] float64 row-major (destroyed), b [dim] (destroyed), x [dim] out, ws: m3_chol_ws_doubles(dim) doubles
 // (ws[0] = status on return: 0 ok, 1 not positive definite).
+int64_t m3_chol_ws_doubles(int dim) { return dim > 0 ? 1 + (int64_t)dim + m3_chol_diag_doubles(dim) : 0; }
+
 int m3_chol_solve(double *H, double *b, double *x, double *ws, int dim, double shift, void *stream) {
     M3_REQUIRE(H && b && x && ws && dim > 0 && x != b);
     hipStream_t st = (hipStream_t)stream;
     M3_CHECK_HIP(hipMemsetAsync(ws, 0, sizeof(double), st), "m3_chol_solve/memset");
-    return m3_chol_solve_launch(H, b, ws + 1, x, ws, nullptr, dim, shift, st);
+    return m3_chol_solve_launch(H, b, ws + 1, x, ws + 1 + dim, ws, nullptr, dim, shift, st);
 }
 
 }  // extern "C"

@@ -14,8 +14,9 @@
 #include "sim3_dev.h"
 
 // blocked float64 Cholesky solve (gn_chol.hip)
-int m3_chol_solve_launch(double *H, double *b, double *y, double *x, double *fail, const double *off, int dim, double shift,
-                         hipStream_t st);
+int m3_chol_solve_launch(double *H, double *b, double *y, double *x, double *Ld, double *fail, const double *off, int dim,
+                         double shift, hipStream_t st);
+int64_t m3_chol_diag_doubles(int dim);
 
 namespace {
 
@@ -387,8 +388,8 @@ CalibParams make_calib(const float *c) {
 
 
 // One Gauss-Newton step from an assembled system, any size, stream-ordered: dim <= kMaxDim -> the single-workgroup
-// kernel; larger -> blocked Cholesky (gn_chol.hip) + k_gn_tail.  Hbuf = H [dim*dim] | g | x | b | y [dim each] | fail [1]
-// = m3_gn_rays_hbuf_doubles(dim).
+// kernel; larger -> blocked Cholesky (gn_chol.hip) + k_gn_tail.  Hbuf = H [dim*dim] | g | x | b | y [dim each] | fail [8]
+// | Ld [m3_chol_diag_doubles(dim)] = m3_gn_rays_hbuf_doubles(dim).
 int launch_step(double *Hbuf, float *Twc, const int32_t *local, double *info, int K, int dim, float delta_thresh,
                 int apply, hipStream_t st) {
     double *H = Hbuf, *g = Hbuf + (size_t)dim * dim, *x = g + dim, *b = x + dim, *y = b + dim, *fail = y + dim;
@@ -398,7 +399,7 @@ int launch_step(double *Hbuf, float *Twc, const int32_t *local, double *info, in
         return M3_OK;
     }
     hipLaunchKernelGGL(k_gn_neg_rhs, dim3(m3_cdiv(dim, 256)), dim3(256), 0, st, (const double *)g, b, fail, dim);
-    const int rc = m3_chol_solve_launch(H, b, y, x, fail, info + 2, dim, 1e-6, st);
+    const int rc = m3_chol_solve_launch(H, b, y, x, fail + 8, fail, info + 2, dim, 1e-6, st);
     if (rc != M3_OK) return rc;
     hipLaunchKernelGGL(k_gn_tail, dim3(1), dim3(kSolveThreads), 0, st, x, Twc, local, info, (const double *)fail, K, dim,
                        delta_thresh, apply);
@@ -435,7 +436,9 @@ extern "C" {
 
 int m3_gn_rays_chunks(int P) { return gn_chunks(P); }
 int m3_gn_rays_max_dim(void) { return kMaxDim; }
-int64_t m3_gn_rays_hbuf_doubles(int dim) { return (int64_t)dim * dim + 4 * (int64_t)dim + 8; }
+int64_t m3_gn_rays_hbuf_doubles(int dim) {
+    return (int64_t)dim * dim + 4 * (int64_t)dim + 8 + (dim > kMaxDim ? m3_chol_diag_doubles(dim) : 0);
+}
 
 int m3_gn_rays_blocks(const float *Twc, const float *Xs, const float *Cs, const int32_t *ii, const int32_t *jj,
                       const int32_t *idx, const uint8_t *valid, const float *Q, double *blocks, double *ws,

@@ -80,12 +80,16 @@ def all_gather_results(tensors, group=None, async_op: bool = False):
     return handle if async_op else handle.wait()
 
 
-def all_gather_rows(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
-    """Ragged all-gather along dim 0 for a shard_range() partition of `total` rows: rank r passes its
-    len(shard_range(total, r, world)) rows, every rank gets all `total` rows in order.  One collective
-    (shards are padded to the largest shard; the padding is dropped on arrival)."""
+def all_gather_rows(local: torch.Tensor, total: int, group=None, sizes=None) -> torch.Tensor:
+    """Ragged all-gather along dim 0: rank r passes its sizes[r] rows, every rank gets all `total` rows in rank
+    order.  sizes=None: the shard_range() partition of `total`.  One collective (shards are padded to the largest
+    shard; the padding is dropped on arrival)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    sizes = [len(shard_range(total, r, world)) for r in range(world)]
+    if sizes is None:
+        sizes = [len(shard_range(total, r, world)) for r in range(world)]
+    sizes = [int(s) for s in sizes]
+    if len(sizes) != world or sum(sizes) != total:
+        raise ValueError(f"sizes {sizes} do not describe {total} rows over {world} ranks")
     if local.shape[0] != sizes[rank]:
         raise ValueError(f"rank {rank} owns {sizes[rank]} rows, got {local.shape[0]}")
     cap = max(sizes) if sizes else 0

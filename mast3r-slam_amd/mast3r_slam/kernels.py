@@ -178,23 +178,33 @@ def _prep_gn(Twc, Xs, Cs, ii, jj, idx, valid, Q):
 def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray: float = 0.003,
                       sigma_dist: float = 10.0, C_thresh: float = 0.0, Q_thresh: float = 1.5,
                       max_iter: int = 10, delta_thresh: float = 1e-4, pin: int = 1, use_metal: bool = True,
-                      *, return_info: bool = False, _point_mode: int = 0, _calib=None, group=None):
+                      *, return_info: bool = False, _point_mode: int = 0, _calib=None, group=None, graph=None):
     """kernels.py:262-322 / gauss_newton.py:23-280.  Returns updated Twc [K,8] float32
     (input is not modified).  sigma_dist is accepted and ignored, as in the reference.
-    group: a torch.distributed process group -> the edges are split over its ranks (each rank evaluates
-    the per-point blocks of its own edges, 36 doubles per edge are all-gathered, every rank assembles and
-    solves; rank 0's step is broadcast so all ranks hold bit-identical poses).  Every rank passes the
-    full graph."""
+
+    group: a torch.distributed process group -> the edges are split over its ranks: each rank evaluates the
+    per-point blocks of its own edges (10.8 MB of reads per edge), the 36-double blocks are all-gathered (288 B per
+    edge) and EVERY rank runs the same deterministic device step on the gathered blocks (fixed-order assembly,
+    Cholesky, stop test, retraction): bit-identical poses on all ranks, no broadcast, no host synchronisation
+    inside the loop.
+      * graph=None: every rank passes the FULL graph and takes its shard_range() slice of the edges;
+      * graph=(ii_all, jj_all, sizes): the edge arguments are this rank's OWN directed edges only (sizes[rank]
+        of them - the matches never leave the rank that computed them, BASELINE configs[4]) and ii_all / jj_all
+        list all sum(sizes) directed edges in rank order (rank 0's edges first)."""
     num_kf = Twc.shape[0]
-    num_edges = len(ii)
     as_np = isinstance(Twc, np.ndarray)
+    sharded = group is not None
+    if graph is not None and not sharded:
+        raise ValueError("graph=(ii_all, jj_all, sizes) needs a process group")
+    ii_g, jj_g = (graph[0], graph[1]) if graph is not None else (ii, jj)
+    num_edges = len(ii_g)
 
     def _unchanged():
         out = Twc.copy() if as_np else Twc.clone()
         return (out, dict(iters=0, last_dx=0.0, stopped=True, failed=False)) if return_info else out
     if num_edges == 0 or num_kf <= pin:
         return _unchanged()
-    uniq, local_h, num_free = _local_map(ii, jj, num_kf, pin)
+    uniq, local_h, num_free = _local_map(ii_g, jj_g, num_kf, pin)
     if len(uniq) <= pin or num_free <= 0:
         return _unchanged()
     t = _prep_gn(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q)
@@ -205,21 +215,12 @@ def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray:
     L = _ffi.lib()
     chunks = L.m3_gn_rays_chunks(p)
     dim = 7 * num_free
-    blocks = torch.empty((e, 36), dtype=torch.float64, device=dev)
-    ws = torch.empty(e * chunks * 36, dtype=torch.float64, device=dev)
     info = torch.zeros(4, dtype=torch.float64, device=dev)
     st = _ffi.stream_ptr()
-    sharded = group is not None
-    if sharded:
-        import torch.distributed as tdist
-        from . import dist as m3dist
-        mine = m3dist.shard_range(e, tdist.get_rank(group), tdist.get_world_size(group))
-        sl = slice(mine.start, mine.stop)
-        loc = {n: t[n][sl].contiguous() for n in ("ii", "jj", "idx", "valid", "Q")}
-        e_loc = len(mine)
-        blocks_loc = torch.empty((e_loc, 36), dtype=torch.float64, device=dev)
     hbuf = torch.empty(int(L.m3_gn_rays_hbuf_doubles(dim)), dtype=torch.float64, device=dev)
     if not sharded:
+        blocks = torch.empty((e, 36), dtype=torch.float64, device=dev)
+        ws = torch.empty(e * chunks * 36, dtype=torch.float64, device=dev)
         # the whole loop (blocks -> assemble -> Cholesky of ANY size -> stop test -> retract) in one stream-ordered call
         _ffi.call("m3_gn_rays_solve", _ffi.ptr(twc), _ffi.ptr(t["Xs"]), _ffi.ptr(t["Cs"]), _ffi.ptr(t["ii"]),
                   _ffi.ptr(t["jj"]), _ffi.ptr(t["idx"]), _ffi.ptr(t["valid"]), _ffi.ptr(t["Q"]), _ffi.ptr(local),
@@ -227,10 +228,26 @@ def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray:
                   float(sigma_ray), float(C_thresh), float(Q_thresh), int(max_iter), float(delta_thresh),
                   int(_point_mode), _calib_ptr(_calib), st)
     else:
-        # edge-sharded: every rank evaluates its own edges, the 36-double blocks are all-gathered, and EVERY rank runs
-        # the same deterministic device step (fixed-order assembly, Cholesky, stop test, retraction) on the gathered
-        # blocks: bit-identical poses on all ranks with no broadcast and no host synchronisation in the loop.  The
-        # stop / failure flags live on the device (info); a stopped solve turns the remaining launches into no-ops.
+        import torch.distributed as tdist
+        from . import dist as m3dist
+        rank, world = tdist.get_rank(group), tdist.get_world_size(group)
+        if graph is None:
+            mine = m3dist.shard_range(e, rank, world)
+            sl = slice(mine.start, mine.stop)
+            loc = {n: t[n][sl].contiguous() for n in ("ii", "jj", "idx", "valid", "Q")}
+            sizes = [len(m3dist.shard_range(e, r, world)) for r in range(world)]
+            ii_all, jj_all = t["ii"], t["jj"]
+        else:
+            loc = {n: t[n] for n in ("ii", "jj", "idx", "valid", "Q")}
+            sizes = [int(x) for x in graph[2]]
+            if len(sizes) != world or sizes[rank] != e or sum(sizes) != num_edges:
+                raise ValueError(f"graph sizes {sizes} do not match {e} local / {num_edges} global edges on rank {rank}")
+            ii_all, _ = _to_dev(ii_g, torch.int32)
+            jj_all, _ = _to_dev(jj_g, torch.int32)
+        e_loc, e_all = sizes[rank], sum(sizes)
+        blocks_loc = torch.empty((e_loc, 36), dtype=torch.float64, device=dev)
+        ws = torch.empty(max(e_loc, 1) * chunks * 36, dtype=torch.float64, device=dev)
+        # The stop / failure flags live on the device (info); a stopped solve turns the remaining launches into no-ops.
         _ffi.call("m3_gn_rays_info_init", _ffi.ptr(info), st)
         for _ in range(max_iter):
             if e_loc:
@@ -238,9 +255,9 @@ def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray:
                           _ffi.ptr(loc["jj"]), _ffi.ptr(loc["idx"]), _ffi.ptr(loc["valid"]), _ffi.ptr(loc["Q"]),
                           _ffi.ptr(blocks_loc), _ffi.ptr(ws), k, p, e_loc, float(sigma_ray), float(C_thresh),
                           float(Q_thresh), int(_point_mode), _calib_ptr(_calib), st)
-            blocks = m3dist.all_gather_rows(blocks_loc, e, group).contiguous()
-            _ffi.call("m3_gn_rays_step", _ffi.ptr(twc), _ffi.ptr(blocks), _ffi.ptr(t["ii"]), _ffi.ptr(t["jj"]),
-                      _ffi.ptr(local), _ffi.ptr(hbuf), _ffi.ptr(info), k, e, num_free, float(delta_thresh), st)
+            blocks = m3dist.all_gather_rows(blocks_loc, e_all, group, sizes).contiguous()
+            _ffi.call("m3_gn_rays_step", _ffi.ptr(twc), _ffi.ptr(blocks), _ffi.ptr(ii_all), _ffi.ptr(jj_all),
+                      _ffi.ptr(local), _ffi.ptr(hbuf), _ffi.ptr(info), k, e_all, num_free, float(delta_thresh), st)
     result_info = None
     if return_info:
         i = info.cpu().numpy()
@@ -252,23 +269,37 @@ def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray:
 def cholesky_solve(H, g, reg: float = 1e-6):
     """backends/mpsgraph/linalg.py:17-50 on the device: x = solve(H + reg I, g) for a symmetric positive-definite H
     [N,N] (or batched [B,N,N]) of ANY size by the blocked float64 Cholesky of gn_chol.hip.  numpy in -> numpy out,
-    tensors in -> tensor out (float64).  Raises RuntimeError when H + reg I is not positive definite (the reference
-    falls back to lstsq there; no silent downgrade here)."""
+    tensors in -> tensor out; the arithmetic is float64, the result has H's dtype (as the reference: float32 in ->
+    float32 out).
+
+    Difference from the reference, on purpose: the reference calls LAPACK's LU (any non-singular H) and falls back
+    to lstsq on a singular one; its contract, and every caller on the hot path, is a Gauss-Newton normal matrix
+    (SPD after + reg I).  H + reg I that is NOT positive definite raises RuntimeError here instead of returning an
+    LU / least-squares answer - no silent downgrade.  A batched call checks the status flags of all items with ONE
+    host synchronisation after the last launch."""
+    if isinstance(H, np.ndarray):
+        out_dtype = torch.from_numpy(np.empty(0, dtype=H.dtype)).dtype if H.dtype in (np.float32, np.float64) else torch.float64
+    else:
+        out_dtype = H.dtype if isinstance(H, torch.Tensor) and H.dtype.is_floating_point else torch.float64
     Hd, np_in = _to_dev(H, torch.float64)
     gd, _ = _to_dev(g, torch.float64)
-    if Hd.dim() == 3:
-        xs = [cholesky_solve(Hd[i], gd[i].reshape(-1), reg) for i in range(Hd.shape[0])]
-        return _out(torch.stack(xs), np_in)
-    n = Hd.shape[0]
-    if Hd.dim() != 2 or Hd.shape[1] != n or gd.numel() != n:
-        raise ValueError(f"H must be [N,N] and g [N], got {tuple(Hd.shape)} / {tuple(gd.shape)}")
-    Hw, bw = Hd.clone().contiguous(), gd.reshape(-1).clone().contiguous()
-    x = torch.empty(n, dtype=torch.float64, device=Hw.device)
-    ws = torch.empty(n + 1, dtype=torch.float64, device=Hw.device)
-    _ffi.call("m3_chol_solve", _ffi.ptr(Hw), _ffi.ptr(bw), _ffi.ptr(x), _ffi.ptr(ws), n, float(reg), _ffi.stream_ptr())
-    if float(ws[0]) != 0.0:
-        raise RuntimeError("cholesky_solve: H + reg*I is not positive definite")
-    return _out(x, np_in)
+    batched = Hd.dim() == 3
+    Hb = Hd if batched else Hd[None]
+    nb, n = Hb.shape[0], Hb.shape[1]
+    if Hb.dim() != 3 or Hb.shape[2] != n or gd.numel() != nb * n:
+        raise ValueError(f"H must be [N,N] / [B,N,N] and g [N] / [B,N], got {tuple(Hd.shape)} / {tuple(gd.shape)}")
+    Hw, bw = Hb.clone().contiguous(), gd.reshape(nb, n).clone().contiguous()
+    x = torch.empty((nb, n), dtype=torch.float64, device=Hw.device)
+    wsn = int(_ffi.lib().m3_chol_ws_doubles(n))
+    ws = torch.empty((nb, wsn), dtype=torch.float64, device=Hw.device)
+    for i in range(nb):
+        _ffi.call("m3_chol_solve", _ffi.ptr(Hw[i]), _ffi.ptr(bw[i]), _ffi.ptr(x[i]), _ffi.ptr(ws[i]), n, float(reg),
+                  _ffi.stream_ptr())
+    bad = torch.nonzero(ws[:, 0]).reshape(-1).tolist()                  # the one host synchronisation
+    if bad:
+        raise RuntimeError(f"cholesky_solve: H + reg*I is not positive definite (batch items {bad})")
+    x = x.to(out_dtype)
+    return _out(x if batched else x[0], np_in)
 
 
 def gauss_newton_points(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_point: float = 0.01,
@@ -284,7 +315,7 @@ def gauss_newton_points(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_po
 def gauss_newton_calib(Twc, Xs, Cs, K, ii, jj, idx_ii2jj, valid_match, Q, img_size, pixel_border: int = 0,
                        z_eps: float = 0.0, sigma_pixel: float = 1.0, sigma_depth: float = 0.1, C_thresh: float = 0.0,
                        Q_thresh: float = 1.5, max_iter: int = 10, delta_thresh: float = 1e-4, pin: int = 1,
-                       use_metal: bool = True, *, return_info: bool = False):
+                       use_metal: bool = True, *, return_info: bool = False, group=None, graph=None):
     """kernels.py:325-393 / gauss_newton_calib.py:17-274: calibrated projection residual
     ((du, dv)/sigma_pixel, dlog z/sigma_depth).  K is [3,3] or (fx, fy, cx, cy); img_size = (width, height)."""
     Kh = K.cpu().numpy() if isinstance(K, torch.Tensor) else np.asarray(K)
@@ -293,4 +324,4 @@ def gauss_newton_calib(Twc, Xs, Cs, K, ii, jj, idx_ii2jj, valid_match, Q, img_si
     calib = (fx, fy, cx, cy, w, h, pixel_border, z_eps, sigma_pixel, sigma_depth)
     return gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray=1.0, C_thresh=C_thresh,
                              Q_thresh=Q_thresh, max_iter=max_iter, delta_thresh=delta_thresh, pin=pin,
-                             return_info=return_info, _point_mode=2, _calib=calib)
+                             return_info=return_info, _point_mode=2, _calib=calib, group=group, graph=graph)

@@ -201,13 +201,20 @@ class Mast3rFull:
 
     @classmethod
     def from_pretrained(cls, resolution: int = 512, precision: str = "bf16", weights_path: Optional[str] = None,
-                        **kw) -> "Mast3rFull":
-        """mast3r_utils.py:72-76.  No checkpoint can be fetched here (no network); `weights_path` may name a
-        torch state dict with the public MASt3R key names, else seeded random weights are used."""
-        weights = None
+                        random_init: bool = False, **kw) -> "Mast3rFull":
+        """mast3r_utils.py:72-76.  The reference fetches the checkpoint by name; nothing can be fetched here, so
+        `weights_path` must name a torch / safetensors state dict with the public MASt3R key names.  Without it the
+        call RAISES - a "pretrained" model with random weights would be a silent downgrade - unless the caller asks
+        for seeded random weights explicitly with random_init=True (benchmarks and tests do)."""
+        if precision not in cls._PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(cls._PRECISIONS)}, got {precision!r}")
         if weights_path is not None:
-            weights = load_state_dict(weights_path)
-        return cls(weights=weights, resolution=resolution, precision=precision, **kw)
+            return cls(weights=load_state_dict(weights_path), resolution=resolution, precision=precision, **kw)
+        if not random_init:
+            raise FileNotFoundError(
+                "Mast3rFull.from_pretrained: no weights_path given and checkpoints cannot be downloaded here; pass "
+                "weights_path=<state dict with the public MASt3R key names> or random_init=True for seeded random weights")
+        return cls(weights=None, resolution=resolution, precision=precision, **kw)
 
     # ------------------------------------------------------------------ weight preparation
     def _prepare(self, w: dict) -> None:

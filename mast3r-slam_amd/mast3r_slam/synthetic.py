@@ -8,6 +8,10 @@ Recipes follow SURVEY.md §8d:
   * gn_graph            create_gn_test_data-style random pose graph
                         (shape/dtype recipe of benchmark_all_kernels.py:16-42,
                         own generator and RNG stream)
+  * keyframe_graph_scene  config 5: K keyframes on a circular trajectory viewing the same
+                        smooth surface - canonical pointmaps, world points, descriptors,
+                        poses and the true pixel correspondences of any edge (torch, on the
+                        device: 256 keyframes x 262144 points are generated where they are used)
 """
 from __future__ import annotations
 
@@ -158,3 +162,64 @@ def gn_graph(num_kf=10, num_pts=500, num_edges=15, seed=42, chain=False, pose_no
     valid = rng.uniform(size=(num_edges, num_pts)) > 0.3
     Q = (rng.uniform(size=(num_edges, num_pts)) * 3 + 1).astype(np.float32)
     return Twc, Xs, Cs, ii, jj, idx, valid, Q
+
+
+def chain_edges(num_kf: int, back: int = 3):
+    """slam.py:302-303: every keyframe is linked to its previous <= `back` keyframes.  Returns (ii, jj) lists with
+    ii < jj (256 keyframes -> 762 undirected edges)."""
+    ii, jj = [], []
+    for j in range(1, num_kf):
+        for i in range(max(0, j - back), j):
+            ii.append(i)
+            jj.append(j)
+    return ii, jj
+
+
+def keyframe_graph_scene(num_kf: int, h: int, w: int, device, seed: int = 0, d: int = 24, radius_px: float = 40.0,
+                         desc_dtype=None):
+    """`num_kf` keyframes on a circular trajectory looking at one smooth surface.
+
+    Keyframe k's pixel (u, v) sees the surface point S(u + a_k, v + b_k) with (a_k, b_k) = radius_px (cos, sin)(2 pi k / K)
+    and has the world pose T_k = (t_k, q_k, s_k) (small translation on the circle, a rotation about y that varies along
+    it, a scale near one).  Hence for an edge (i, j) the TRUE match of keyframe j's pixel (u, v) in keyframe i is
+    (u + a_j - a_i, v + b_j - b_i), and T_i X_i[match] = T_j X_j up to interpolation.
+
+    Returns a dict of torch tensors on `device`:
+      Pw [K,N,3] f32 world points, Xs [K,N,3] f32 canonical pointmaps (T_k^-1 Pw_k), D [K,H,W,d] descriptors of the
+      world points (desc_dtype, default float16), poses [K,8] f32 (t, q_xyzw, s), shift [K,2] f64 (a_k, b_k),
+      C [K,N] f32 confidences U(1,3), Qself / Qother [K,N] f32 descriptor confidences U(1,4)."""
+    import torch
+    dd = desc_dtype or torch.float16
+    f64 = torch.float64
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    k = torch.arange(num_kf, dtype=f64, device=device)
+    th = 2 * np.pi * k / num_kf
+    shift = torch.stack([radius_px * torch.cos(th), radius_px * torch.sin(th)], -1)              # [K,2]
+    t = torch.stack([0.05 * torch.cos(th), 0.05 * torch.sin(th), 0.01 * torch.sin(2 * th)], -1)  # [K,3]
+    ang = np.deg2rad(2.0) * torch.sin(th)
+    q = torch.stack([torch.zeros_like(ang), torch.sin(ang / 2), torch.zeros_like(ang), torch.cos(ang / 2)], -1)
+    sc = 1.0 + 0.02 * torch.cos(th)
+    n = h * w
+    vv, uu = torch.meshgrid(torch.arange(h, dtype=f64, device=device), torch.arange(w, dtype=f64, device=device), indexing="ij")
+    Pw = torch.empty((num_kf, n, 3), dtype=torch.float32, device=device)
+    Xs = torch.empty((num_kf, n, 3), dtype=torch.float32, device=device)
+    D = torch.empty((num_kf, h, w, d), dtype=dd, device=device)
+    kk = d // 6
+    freqs = (2.0 ** torch.arange(kk, dtype=f64, device=device)) * 3.0
+    for i in range(num_kf):
+        u = uu + shift[i, 0]
+        v = vv + shift[i, 1]
+        z = 2.0 + 0.3 * torch.sin(2 * np.pi * u / w) * torch.cos(2 * np.pi * v / h)
+        P = torch.stack([(u - 0.5 * w) / w * z, (v - 0.5 * h) / w * z, z], -1).reshape(n, 3)     # _surface
+        Pw[i] = P.float()
+        # X = R^T (P - t) / s with R = rotation about y by ang
+        c, s_ = torch.cos(ang[i]), torch.sin(ang[i])
+        pv = P - t[i]
+        X = torch.stack([c * pv[:, 0] - s_ * pv[:, 2], pv[:, 1], s_ * pv[:, 0] + c * pv[:, 2]], -1) / sc[i]
+        Xs[i] = X.float()
+        a = P[:, None, :] * freqs[:, None]                                                      # _descriptor
+        e = torch.cat([torch.sin(a), torch.cos(a)], -1).reshape(n, -1)[:, :d]
+        D[i] = (e / e.norm(dim=-1, keepdim=True)).reshape(h, w, d).to(dd)
+    poses = torch.cat([t, q, sc[:, None]], -1).float()
+    rnd = lambda lo, hi: (torch.rand((num_kf, n), generator=g) * (hi - lo) + lo).to(device)
+    return dict(Pw=Pw, Xs=Xs, D=D, poses=poses, shift=shift, C=rnd(1.0, 3.0), Qself=rnd(1.0, 4.0), Qother=rnd(1.0, 4.0))

@@ -33,7 +33,8 @@ def test_every_declared_symbol_is_exported(built_lib):
 
 def test_metadata_entry_points(built_lib):
     L = _ffi.lib()
-    assert L.m3_abi_version() >= 1000
+    assert L.m3_abi_version() == 2000          # exact: a signature change must bump it (include/m3slam.h)
+    assert L.m3_chol_ws_doubles(1785) == 1 + 1785 + 28 * 64 * 64 and L.m3_chol_ws_doubles(7) == 1 + 7 + 4096
     assert L.m3_status_string(0) == b"ok"
     assert b"invalid" in L.m3_status_string(-1)
     assert L.m3_track_ws_doubles() > 36
@@ -117,6 +118,7 @@ def test_factor_graph_edge_bookkeeping_cpu():
     fg = FactorGraph(SimpleNamespace(device="cpu"), frames=[])
     n = 6
     fg.ii, fg.jj = torch.tensor([2, 5], dtype=torch.int32), torch.tensor([5, 9], dtype=torch.int32)
+    fg.owner = torch.zeros(2, dtype=torch.int32)                  # no group: every edge is stored here
     fg.idx_ii2jj = torch.arange(2 * n).reshape(2, n)
     fg.idx_jj2ii = 100 + torch.arange(2 * n).reshape(2, n)
     fg.valid_match_j = torch.ones(2, n, 1, dtype=torch.bool)
@@ -127,7 +129,7 @@ def test_factor_graph_edge_bookkeeping_cpu():
     ii, jj, idx, valid, Q = fg._prep_two_way_edges()
     assert ii.tolist() == [2, 5, 5, 9] and jj.tolist() == [5, 9, 2, 5]
     assert idx[2, 0] == 100 and valid[:2].all() and not valid[2:].any() and Q[3, 0, 0] == 3.0
-    li, lj, lidx, lvalid, lQ = fg._local_edges(uniq)
+    li, lj, lidx, lvalid, lQ, _ = fg._local_edges(uniq)
     assert li.tolist() == [0, 1, 1, 2] and lj.tolist() == [1, 2, 0, 1]
     assert lidx.dtype == torch.int32 and lvalid.shape == (4, n) and lQ.shape == (4, n)
 
@@ -189,7 +191,10 @@ def test_precision_argument_is_validated_before_the_device_is_needed():
     from mast3r_slam import mast3r_utils
     with pytest.raises(ValueError, match="precision"):
         mast3r_utils.load_mast3r("mast3r_full", precision="int8")
+    # no checkpoint path: the reference would download one; here that is an error, never silent random weights
+    with pytest.raises(FileNotFoundError, match="random_init=True"):
+        mast3r_utils.load_mast3r("mast3r_full", precision="bf16")
     if not torch.cuda.is_available():
         for prec in ("bf16", "fp16", "fp32"):
             with pytest.raises(RuntimeError, match="ROCm device"):
-                mast3r_utils.load_mast3r("mast3r_full", precision=prec)
+                mast3r_utils.load_mast3r("mast3r_full", precision=prec, random_init=True)

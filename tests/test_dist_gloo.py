@@ -115,3 +115,84 @@ def test_two_rank_sharded_edge_blocks():
         p.join(60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res) and res[0][2] % 2 == 1      # an odd edge count: the shards are ragged
+
+
+def _fake_match(model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j):
+    """Stand-in for mast3r_match_symmetric on CPU: deterministic per-edge results derived from the features, so that
+    any rank computes the same thing for the same edge."""
+    b, n = feat_i.shape[0], 12
+    key = (feat_i[:, 0, 0] * 10 + feat_j[:, 0, 0]).long()                      # feat = keyframe id
+    base = torch.arange(n)[None].repeat(b, 1)
+    idx_i2j = (base + key[:, None]) % n
+    idx_j2i = (base + 2 * key[:, None]) % n
+    vj = ((base + key[:, None]) % 5 != 0)[..., None]
+    vi = ((base + key[:, None]) % 7 != 0)[..., None]
+    # edge (0,3) gets low descriptor confidence -> dropped by the match-fraction test (not consecutive)
+    q = torch.where((feat_i[:, 0, 0] == 0) & (feat_j[:, 0, 0] == 3), 1.0, 3.0)[:, None, None].expand(b, n, 1)
+    return idx_i2j, idx_j2i, vj, vi, q, q, q, q
+
+
+def _graph_frames():
+    from types import SimpleNamespace
+    shape = torch.tensor([[16, 16]], dtype=torch.int32)
+    return [SimpleNamespace(feat=torch.full((1, 1024), float(k)), pos=torch.zeros((1, 2), dtype=torch.long),
+                            img_true_shape=shape, X_canon=torch.zeros(12, 3)) for k in range(6)]
+
+
+def _edge_lists():
+    ii = [0, 0, 1, 0, 1, 2, 2, 3, 3, 4]
+    jj = [1, 2, 2, 3, 3, 3, 4, 4, 5, 5]
+    return ii, jj
+
+
+def _worker_factor_graph(rank, world, port, q):
+    from types import SimpleNamespace
+    from mast3r_slam.global_opt import FactorGraph
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ii, jj = _edge_lists()
+        fg = FactorGraph(SimpleNamespace(device="cpu"), _graph_frames(), group=dist.group.WORLD, batch=2)
+        ok = fg.add_factors(ii[:6], jj[:6], 0.1, _fake_match)
+        ok &= fg.add_factors(ii[6:], jj[6:], 0.1, _fake_match)                 # a second call: ownership interleaves
+        uniq = fg.get_unique_kf_idx()
+        li, lj, lidx, lvalid, lQ, graph = fg._local_edges(uniq)
+        q.put((rank, ok, fg.ii.tolist(), fg.jj.tolist(), fg.owner.tolist(), li.tolist(), lj.tolist(),
+               lidx.tolist(), graph[0].tolist(), graph[1].tolist(), graph[2]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_edge_sharded_factor_graph():
+    """FactorGraph(group=...) on CPU: each rank matches only its shard of every add_factors call, the keep decision is
+    global, and the rank-ordered directed edge list every rank derives is the concatenation of the ranks' own lists."""
+    from types import SimpleNamespace
+    from mast3r_slam.global_opt import FactorGraph
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_factor_graph, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ii, jj = _edge_lists()
+    ref = FactorGraph(SimpleNamespace(device="cpu"), _graph_frames())           # the same graph on one rank
+    assert ref.add_factors(ii[:6], jj[:6], 0.1, _fake_match) and ref.add_factors(ii[6:], jj[6:], 0.1, _fake_match)
+    assert (0, 3) not in zip(ref.ii.tolist(), ref.jj.tolist()) and ref.ii.numel() == 9       # the weak edge was dropped
+    ri, rj, ridx, _, _, rgraph = ref._local_edges(ref.get_unique_kf_idx())
+    assert rgraph is None
+    for r in res:
+        assert r[1] and r[2] == ref.ii.tolist() and r[3] == ref.jj.tolist()     # every rank knows the whole graph
+        assert r[8] == res[0][5] + res[1][5] and r[9] == res[0][6] + res[1][6]  # rank-ordered global directed list
+        assert r[10] == [len(res[0][5]), len(res[1][5])]
+    assert res[0][4] == res[1][4] and set(res[0][4]) == {0, 1}
+    # the union of the ranks' stored matches equals the single-rank graph's, edge by edge
+    want = {(a, b): row for a, b, row in zip(ri.tolist(), rj.tolist(), ridx.tolist())}
+    got = {}
+    for r in res:
+        got.update({(a, b): row for a, b, row in zip(r[5], r[6], r[7])})
+    assert got == want

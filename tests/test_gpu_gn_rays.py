@@ -214,6 +214,41 @@ def test_blocked_cholesky_solve_any_size(dev, n):
         assert np.allclose(xb[1], 0.5 * xb[0], rtol=1e-9, atol=1e-12)
 
 
+def test_blocked_cholesky_under_a_saturated_gpu(dev):
+    """Round-2 advisor finding: k_chol_panel's workgroups all read the diagonal block A_kk while workgroup 0 used to write
+    L_kk over it - harmless on an idle GPU (every workgroup loads within microseconds), wrong when a panel workgroup is
+    dispatched late because another stream keeps the CUs busy (the intended deployment: tracking / inference beside the
+    backend).  The factor now goes to a separate buffer; this runs the 1785-unknown solve several times while a second
+    stream saturates the chip, and every solve must equal the float64 reference."""
+    n = 1785
+    rng = np.random.default_rng(5)
+    A = rng.normal(size=(n, n))
+    H = A @ A.T / n + np.eye(n) * 0.5
+    g = rng.normal(size=n)
+    ref = np.linalg.solve(H + 1e-6 * np.eye(n), g)
+    Hd, gd = torch.from_numpy(H).to(dev), torch.from_numpy(g).to(dev)
+    side = torch.cuda.Stream()
+    x = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+    junk = torch.empty(64 * 1024 * 1024, device=dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):                                   # ~0.3 s of work that occupies every CU: matrix + streaming kernels
+        for _ in range(60):
+            y = x @ x
+            junk.add_(1.0)
+    outs = [kernels.cholesky_solve(Hd, gd, 1e-6) for _ in range(6)]   # on the current stream, beside the load
+    busy = not side.query()
+    torch.cuda.synchronize()
+    assert busy, "the side stream finished before the solves were issued: the test did not overlap anything"
+    for o in outs:
+        assert np.abs(o.cpu().numpy() - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    del y
+    # float32 in -> float32 out (linalg.py:17-50 returns H.dtype), arithmetic still float64
+    x32 = kernels.cholesky_solve(H[:65, :65].astype(np.float32), g[:65].astype(np.float32), 1e-6)
+    assert x32.dtype == np.float32
+    r32 = np.linalg.solve(H[:65, :65].astype(np.float32).astype(np.float64) + 1e-6 * np.eye(65), g[:65].astype(np.float32).astype(np.float64))
+    assert np.abs(x32 - r32).max() <= 1e-6 * max(1.0, np.abs(r32).max())
+
+
 def test_large_graph_solve_stays_on_the_device(dev):
     """70 keyframes -> 483 unknowns > the single-workgroup limit (448): the whole Gauss-Newton loop (blocks, assembly,
     blocked Cholesky, stop test, retraction) runs as one stream-ordered call and matches the float64 oracle; a

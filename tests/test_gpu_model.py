@@ -566,6 +566,42 @@ def test_attention_prescaled_deferred_max(dev, dt, tq_tk_b_h):
     assert _rel(out[1, 8:16, 64:128], ref[1, 8:16, 64:128]) < 2 * tol     # its neighbours in the recomputed workgroup
 
 
+def test_attention_fast_path_output_overflow_with_finite_row_sum(dev):
+    """bf16 fast loop (MODE 2), round-2 advisor finding: a MID-sequence key ~124 (log2 units) above the first tile's maximum
+    with |v| = 32 makes o = sum p v overflow (2^124 * 32 > fp32 max) while l = sum p stays finite; the next tile's range
+    keeper would bring l back into range and leave o at inf.  The overflow flag is sticky (l > 2^100 at a range check or
+    at the end, or a non-finite o), so the workgroup recomputes the block exactly.  Full float64 reference."""
+    tq = tk = 256
+    b, h, c = 1, 2, 128
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(b, tq, c, generator=g)
+    k = torch.randn(b, tk, c, generator=g)
+    v = torch.randn(b, tk, c, generator=g)
+    key, row = 70, 21                                              # key 70 sits in the second of four key tiles
+    v[0, key, :64] = 32.0 * torch.sign(v[0, key, :64])
+    kd = k.to(torch.bfloat16)
+    excess = 0.0
+    for alpha in torch.linspace(8.0, 24.0, 161).tolist():            # pick the multiple of the key that lands the excess in [120, 126]
+        q[0, row, :64] = alpha * k[0, key, :64]
+        qs = (q * ops.QK_PRESCALE).to(torch.bfloat16)
+        sc = qs[0, row, :64].double() @ kd[0, :, :64].double().T
+        excess = float(sc[key] - sc[:64].max())
+        if 120.0 <= excess <= 126.0:
+            break
+    assert 120.0 <= excess <= 126.0, excess                          # exp2 stays finite (< 127), p * 32 does not
+    vd = v.to(torch.bfloat16)
+    out = torch.full((b, tq, c), 3.0, dtype=torch.bfloat16, device=dev)
+    ops.attention(qs.to(dev), kd.to(dev), vd.to(dev), out, nbatch=b, heads=h, tq=tq, tk=tk, q_row_stride=c, kv_row_stride=c,
+                  o_row_stride=c, q_batch_stride=tq * c, kv_batch_stride=tk * c, o_batch_stride=tq * c, prescaled=True)
+    qf = qs.double().view(b, tq, h, 64).transpose(1, 2)
+    kf = kd.double().view(b, tk, h, 64).transpose(1, 2)
+    vf = vd.double().view(b, tk, h, 64).transpose(1, 2)
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * math.log(2.0), -1) @ vf).transpose(1, 2).reshape(b, tq, c)
+    assert torch.isfinite(out).all()
+    assert _rel(out[0, row, :64], ref[0, row, :64]) < 8e-3 and _rel(out, ref) < 4e-3
+    assert _rel(out[0, 16:32, :64], ref[0, 16:32, :64]) < 8e-3      # the rest of the recomputed workgroup
+
+
 @pytest.mark.parametrize("dt", DT16)
 @pytest.mark.parametrize("crop", [(0, 0), (1, 0), (1, 1)])
 def test_add_upsample2x_matches_interpolate_crop_add(dev, dt, crop):

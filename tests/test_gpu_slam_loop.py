@@ -76,7 +76,7 @@ def test_factor_graph_solve_matches_oracle(net, dev):
         fg = FactorGraph(net, kfs)
         assert fg.add_factors([0, 1, 0], [1, 2, 2], 0.0, mast3r_match_symmetric)
         uniq = fg.get_unique_kf_idx()
-        ii, jj, idx, valid, Q = fg._local_edges(uniq)
+        ii, jj, idx, valid, Q, _ = fg._local_edges(uniq)
         assert ii.tolist() == [0, 1, 0, 1, 2, 2] and jj.tolist() == [1, 2, 2, 0, 1, 0]
         n = H * W
         assert idx.shape == (6, n) and valid.shape == (6, n) and Q.shape == (6, n) and idx.dtype == torch.int32
@@ -106,7 +106,7 @@ def test_factor_graph_solve_matches_oracle(net, dev):
         assert fg.add_factors([0, 1, 0], [1, 2, 2], 0.0, true_matches)
         uniq = fg.get_unique_kf_idx()
         Xd, T, Cd = fg._get_poses_points(uniq)
-        ii, jj, idx, valid, Q = fg._local_edges(uniq)
+        ii, jj, idx, valid, Q, _ = fg._local_edges(uniq)
         ref = OG.gauss_newton_rays(T.cpu().numpy().astype(np.float64), Xd.cpu().numpy(), Cd[..., 0].cpu().numpy(),
                                    ii.cpu().numpy(), jj.cpu().numpy(), idx.cpu().numpy(), valid.cpu().numpy(),
                                    Q.cpu().numpy(), Q_thresh=0.0, max_iter=2, delta_thresh=1e-3, pin=1)

@@ -147,7 +147,9 @@ int64_t m3_track_ws_doubles(void);
  * <= max_iters Gauss-Newton loop runs on the device with no host round trip.
  * Xf [N,3] (already gathered), Xk [N,3], Qk [N], valid uint8 [N], T_WCf/T_WCk [8].
  * Out: T_WCf_out [8], T_CkCf_out [8], info double[4] = (iterations run, last cost,
- * last |tau|, converged flag).  ws: double[m3_track_ws_doubles()].
+ * last |tau|, status: 0 = iteration budget used up, 1 = converged, 2 = solve failed - singular
+ * normal matrix or divergent step, the pose is the last good one; the reference raises there and
+ * FrameTracker.track returns try_reloc, tracker.py:121-141).  ws: double[m3_track_ws_doubles()].
  * fixed_iters != 0 disables the convergence test (exactly max_iters iterations). */
 int m3_track_gn_ray_dist(const float *Xf, const float *Xk, const float *Qk, const uint8_t *valid,
                          const float *T_WCf, const float *T_WCk,

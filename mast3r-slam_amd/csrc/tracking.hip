@@ -249,31 +249,84 @@ __device__ __forceinline__ void reduce_partials(const double *__restrict__ part,
     __syncthreads();
 }
 
+// Per-iteration tail of the tracking solve, one workgroup per problem (round 3: 11.4 -> ~3 us):
+//   1. the nblk x 36 partial rows are reduced by 252 threads (thread = (row group of 7, column); rows in a fixed order),
+//      then 36 threads add the 7 group sums - one wave of independent, coalesced loads instead of nine dependent
+//      load -> shuffle-tree rounds;
+//   2. the 7 x 7 system [H + 1e-6 I | g] is solved by Gauss-Jordan elimination IN ONE WAVE, lane 8 i + j holding element
+//      (i, j) (column 7 = right-hand side): 7 steps of three broadcasts and one FMA instead of ~150 dependent float64
+//      operations on one lane.  No pivoting: the matrix is a Gram matrix plus 1e-6 I (symmetric positive definite); a
+//      pivot that is not positive and finite reports the failure the old pivoted elimination reported for a zero column;
+//   3. the retraction T <- T exp(tau) needs sin(th), cos(th), sin(th/2), cos(th/2) and exp(sigma) in float64: lanes 0-3
+//      evaluate sin at (th, th + pi/2, th/2, th/2 + pi/2) in ONE library call, lane 4 the exponential - five serial
+//      library calls before.
+__device__ __forceinline__ double bcast(double v, int src) { return __shfl(v, src, 64); }
+
 __global__ void __launch_bounds__(kThreads)
 k_track_solve(double *__restrict__ ws, float rel_error, float delta_norm, int fixed_iters, int nblk) {
     ws += (size_t)blockIdx.x * WS_STRIDE;
     if (ws[WS_DONE] != 0.0) return;
+    __shared__ double red[7][kSums];
     __shared__ double sums[kSums];
-    reduce_partials(ws + WS_PART, sums, nblk);
-    if (threadIdx.x != 0) return;
-    double H[7][7], g[7];
-    int k = 0;
-    for (int i = 0; i < 7; ++i)
-        for (int j = i; j < 7; ++j) { H[i][j] = sums[k]; H[j][i] = sums[k]; ++k; }
-    for (int i = 0; i < 7; ++i) { g[i] = sums[28 + i]; H[i][i] += 1e-6; }
+    const int t = threadIdx.x;
+    if (t < 7 * kSums) {
+        const int rg = t / kSums, col = t - rg * kSums;
+        const double *part = ws + WS_PART + col;
+        double s0 = 0.0, s1 = 0.0;
+        int r = rg;
+        for (; r + 7 < nblk; r += 14) { s0 += part[(size_t)r * kSums]; s1 += part[(size_t)(r + 7) * kSums]; }
+        if (r < nblk) s0 += part[(size_t)r * kSums];
+        red[rg][col] = s0 + s1;
+    }
+    __syncthreads();
+    if (t < kSums) sums[t] = ((red[0][t] + red[1][t]) + (red[2][t] + red[3][t])) + ((red[4][t] + red[5][t]) + red[6][t]);
+    __syncthreads();
+    if (t >= 64) return;                                   // one wave from here on; every lane of it stays active
+    const int i = (t >> 3) < 7 ? (t >> 3) : 6, j = t & 7;
+    // upper-triangular packing of the 28 sums: (a, b), a <= b -> a * 7 - a (a - 1) / 2 + (b - a)
+    const int a_ = i < j ? i : j, b_ = i < j ? j : i;
+    double e = (j < 7) ? sums[a_ * 7 - (a_ * (a_ - 1)) / 2 + (b_ - a_)] + (i == j ? 1e-6 : 0.0) : sums[28 + i];
     const double cost = sums[35];
-    if (!solve_small<7>(H, g, 7)) {            // singular system: stop, keep the pose (reference would raise)
-        ws[WS_DONE] = 2.0;
-        return;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const double piv = bcast(e, 8 * k + k), rk = bcast(e, 8 * k + j), ik = bcast(e, 8 * i + k);
+        ok = ok && (piv > 0.0) && isfinite(piv);
+        const double nrk = rk / piv;
+        e = (i == k) ? nrk : e - ik * nrk;
     }
+    double tau[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) tau[k] = bcast(e, 8 * k + 7);
     double tn = 0.0;
-    for (int i = 0; i < 7; ++i) tn += g[i] * g[i];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) tn += tau[k] * tau[k];
     tn = sqrt(tn);
-    if (!isfinite(tn) || fabs(g[6]) > 30.0) {  // a step whose scale factor e^sigma leaves float range (degenerate
-        ws[WS_DONE] = 2.0;                      // geometry): stop and keep the pose, like the singular case
+    // a step whose scale factor e^sigma leaves the float range (degenerate geometry) is refused like a singular system:
+    // stop and keep the pose (the reference raises inside _opt_pose_*, tracker.py:121-141)
+    if (!ok || !isfinite(tn) || fabs(tau[6]) > 30.0) {
+        if (t == 0) ws[WS_DONE] = 2.0;
         return;
     }
-    Pose<double> T = mul(load_pose<double>(ws + WS_T), exp_mlx(g));
+    // exp(tau), liegroups/sim3.py:107-154 (exp_mlx of sim3_dev.h with the transcendentals shared across lanes)
+    const V3<double> v{tau[0], tau[1], tau[2]}, w{tau[3], tau[4], tau[5]};
+    const double th2 = dot(w, w), th = sqrt(th2 + 1e-10);
+    const bool small = th2 < 1e-8;
+    const double arg = (t & 2 ? 0.5 * th : th) + (t & 1 ? 1.5707963267948966 : 0.0);
+    const double tr = (t == 4) ? exp(tau[6]) : sin(arg);
+    const double sin_th = bcast(tr, 0), cos_th = bcast(tr, 1), sin_h = bcast(tr, 2), cos_h = bcast(tr, 3), es = bcast(tr, 4);
+    if (t != 0) return;
+    const double A = small ? 1.0 - th2 / 6.0 : sin_th / th;
+    const double B = small ? 0.5 - th2 / 24.0 : (1.0 - cos_th) / th2;
+    const double C = small ? 1.0 / 6.0 - th2 / 120.0 : (1.0 - A) / th2;
+    const V3<double> wv = cross(w, v);
+    Pose<double> E;
+    E.t = v + B * wv + C * cross(w, wv);
+    const double sinc_half = small ? 0.5 - th2 / 48.0 : sin_h / th;
+    const double cos_half = small ? 1.0 - th2 / 8.0 : cos_h;
+    E.q = {sinc_half * w.x, sinc_half * w.y, sinc_half * w.z, cos_half};
+    E.s = es;
+    const Pose<double> T = mul(load_pose<double>(ws + WS_T), E);
     store_pose(ws + WS_T, T);
     const double old = ws[WS_OLD];
     const double rel_dec = fabs((old - cost) / (old + 1e-10));       // NaN on the first step, as in the reference
@@ -296,7 +349,11 @@ __global__ void k_track_final(const double *__restrict__ ws, const float *__rest
     Pose<double> T = load_pose<double>(ws + WS_T);
     store_pose(T_rel_out, T);
     store_pose(T_WCf_out, mul(load_pose<double>(T_WCk), T));
-    info[0] = ws[WS_ITERS]; info[1] = ws[WS_COST]; info[2] = ws[WS_TAUN]; info[3] = ws[WS_CONV];
+    // status: 0 = iteration budget used up, 1 = converged (optimizer.py:11-46), 2 = the solve FAILED (singular normal
+    // matrix or a divergent step: the pose is the last good one) - what the reference reports by raising inside
+    // _opt_pose_* (tracker.py:121-141), the caller then relocalises
+    info[0] = ws[WS_ITERS]; info[1] = ws[WS_COST]; info[2] = ws[WS_TAUN];
+    info[3] = ws[WS_DONE] == 2.0 ? 2.0 : ws[WS_CONV];
 }
 
 __global__ void __launch_bounds__(kThreads)
@@ -315,7 +372,10 @@ __device__ __forceinline__ Gathered gather_point(const float *__restrict__ Xf_ca
     if (id < 0) id += N;
     id = id < 0 ? 0 : (id >= N ? N - 1 : id);
     Gathered g;
-    g.x = Xf_canon[3 * id + 0]; g.y = Xf_canon[3 * id + 1]; g.z = Xf_canon[3 * id + 2];
+    // one 12-byte load per gathered row (global_load_dwordx3 needs dword alignment only) instead of three dword loads
+    struct __attribute__((packed, aligned(4))) Row3 { float x, y, z; };
+    const Row3 row = reinterpret_cast<const Row3 *>(Xf_canon)[id];
+    g.x = row.x; g.y = row.y; g.z = row.z;
     g.q = sqrtf(Qff[id] * qkf);
     g.vk = (vm != 0) && (g.q > Q_conf);
     g.vo = g.vk && (Cf_avg[id] > C_conf) && (ck > C_conf);

@@ -63,7 +63,8 @@ def _ws(dev, P=1):
 
 def opt_pose_ray_dist_sim3(Xf, Xk, T_WCf, T_WCk, Qk, valid, cfg=None, fixed_iters: bool = False):
     """tracker.py:258-324.  Xf [N,3] (gathered at idx_f2k), Xk [N,3], Qk [N(,1)], valid [N(,1)].
-    Returns (T_WCf [8], T_CkCf [8], info float64[4] = iterations, cost, |tau|, converged).
+    Returns (T_WCf [8], T_CkCf [8], info float64[4] = iterations, cost, |tau|, status: 0 budget used up /
+    1 converged / 2 solve failed - singular or divergent, pose = the last good one).
     Batched: Xf [P,N,3] with poses [P,8] solves P independent problems in one launch sequence
     (outputs [P,8], [P,8], [P,4])."""
     c = dict(get_config()["tracking"])
@@ -207,6 +208,8 @@ class FrameTracker:
         self.keyframes = keyframes
         self.cfg = get_config()["tracking"]
         self.idx_f2k = None
+        self.last_info = None
+        self.last_stats = None
 
     def reset_idx_f2k(self) -> None:
         self.idx_f2k = None
@@ -233,22 +236,30 @@ class FrameTracker:
         Xf, Qk, valid_opt, valid_kf, counts = track_gather(
             Xf_canon, frame.get_average_conf(), keyframe.get_average_conf(), Qff, Qkf, idx, vm,
             self.cfg["C_conf"], self.cfg["Q_conf"])
-        uniq = count_unique(idx, vm, n)          # tracker.py:153-155, needs only idx / valid_match: launch it now
-        cnt = torch.cat([counts.reshape(-1)[:2], uniq]).cpu()   # the ONE host sync of the frame (match_frac gate, :116)
-        if float(cnt[0]) / n < self.cfg["min_match_frac"]:
+        uniq = count_unique(idx, vm, n)          # tracker.py:153-155, needs only idx / valid_match
+        # The solve is launched BEFORE the match-fraction gate is known: it only reads the gathered arrays and writes
+        # its own outputs, so a frame the gate rejects (rare) costs 0.4 ms of discarded work - and the gate (:116), the
+        # solve's failure flag (:139-141) and the keyframe statistics (:149-158) reach the host in ONE synchronisation.
+        if use_calib:
+            T_WCf, T_CkCf, info = opt_pose_calib_sim3(Xf, Xk_canon, frame.T_WC, keyframe.T_WC, Qk, valid_opt, keyframe.K,
+                                                      img_size, self.cfg)
+        else:
+            T_WCf, T_CkCf, info = opt_pose_ray_dist_sim3(Xf, Xk_canon, frame.T_WC, keyframe.T_WC, Qk, valid_opt, self.cfg)
+        host = torch.cat([counts.reshape(-1)[:2].double(), uniq.double(), info.reshape(-1)[3:4]]).cpu()
+        self.last_info = info                                      # (iterations, cost, |tau|, status) of the last solve, on the device
+        if float(host[0]) / n < self.cfg["min_match_frac"]:
             print(f"Skipped frame {frame.frame_id}")
             return False, [], True
-        if use_calib:
-            T_WCf, T_CkCf, _ = opt_pose_calib_sim3(Xf, Xk_canon, frame.T_WC, keyframe.T_WC, Qk, valid_opt, keyframe.K,
-                                                   img_size, self.cfg)
-        else:
-            T_WCf, T_CkCf, _ = opt_pose_ray_dist_sim3(Xf, Xk_canon, frame.T_WC, keyframe.T_WC, Qk, valid_opt, self.cfg)
+        if float(host[3]) == 2.0:                                  # the reference's `except` branch (tracker.py:139-141)
+            print(f"Optimization failed for frame {frame.frame_id}: singular or divergent Gauss-Newton step")
+            return False, [], True
         frame.T_WC = T_WCf.reshape(1, 8)
         # Xkk = T_CkCf.act(Xkf); keyframe.update_pointmap(Xkk, Ckf)  (tracker.py:146-147) in one kernel
         keyframe.update_pointmap(Xkf.reshape(n, 3), Ckf.reshape(n, 1), T=T_CkCf)
         self.keyframes[len(self.keyframes) - 1] = keyframe
-        match_frac_k = float(cnt[1]) / n
-        unique_frac_f = float(cnt[2]) / n
+        match_frac_k = float(host[1]) / n
+        unique_frac_f = float(host[2]) / n
+        self.last_stats = (match_frac_k, unique_frac_f)
         new_kf = min(match_frac_k, unique_frac_f) < self.cfg["match_frac_thresh"]
         if new_kf:
             self.reset_idx_f2k()

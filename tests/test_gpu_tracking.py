@@ -156,3 +156,131 @@ def test_calibrated_tracking_matches_oracle(dev):
     Tb, Trb, ib = tracker.opt_pose_calib_sim3(st(Xf), st(pr["Xk"]), st(pr["T_WCf"]), st(pr["T_WCk"]), st(pr["Qk"]),
                                               st(pr["valid"]), K, (h, w))
     assert torch.equal(Trb[0], Trel) and torch.equal(Trb[1], Trel)
+
+
+# ------------------------------------------------------------------ FrameTracker.track end to end (tracker.py:51-175)
+def _track_scene(h, w, seed, dev):
+    """A solvable frame / keyframe pair: synthetic.geometric_pair gives both views' points in the FRAME's coordinates and
+    the true pixel correspondences; the keyframe's own canonical map is those points under a known Sim(3) (+ noise).
+    Returns the host arrays and a match operator with mast3r_match_asymmetric's signature that injects them
+    (tracker.track takes the operator as a callable, tracker.py:72-74)."""
+    n = h * w
+    sc = synthetic.geometric_pair(h, w, seed=seed, batch=1, noise=2e-4)
+    rng = np.random.default_rng(seed + 100)
+    uv = np.rint(sc["uv_true"][0]).astype(np.int64)
+    inb = (uv[:, 0] >= 0) & (uv[:, 0] < w) & (uv[:, 1] >= 0) & (uv[:, 1] < h)
+    idx = np.clip(uv[:, 0], 0, w - 1) + w * np.clip(uv[:, 1], 0, h - 1)
+    bad = rng.uniform(size=n) < 0.03                                   # 3 % wrong matches, flagged invalid
+    idx[bad] = rng.integers(0, n, size=int(bad.sum()))
+    vm = inb & ~bad & (rng.uniform(size=n) < 0.95)
+    ang = np.deg2rad(1.5)
+    q = np.array([0.0, np.sin(ang / 2), 0.0, np.cos(ang / 2)])
+    T_true = np.concatenate([[0.03, -0.01, 0.02], q, [1.015]])
+    Xkf = sc["X21"][0].reshape(n, 3).astype(np.float64)                # keyframe pixels' points in the frame's coordinates
+    Xk_canon = (S.sim3_act_mlx(T_true, Xkf) + rng.normal(0, 2e-4, (n, 3))).astype(np.float32)
+    u = lambda lo, hi: rng.uniform(lo, hi, size=(n, 1)).astype(np.float32)
+    host = dict(idx=idx, vm=vm, Xff=sc["X11"][0].reshape(n, 3), Xkf=Xkf.astype(np.float32), Cff=u(0.5, 3.0), Ckf=u(0.5, 3.0),
+                Qff=u(1.0, 4.0), Qkf=u(1.0, 4.0), Xk_canon=Xk_canon, Ck=u(0.5, 3.0), T_true=T_true)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    def match_fn(model, frame, keyframe, idx_i2j_init=None):
+        return (d(idx)[None], d(vm)[None, :, None], d(host["Xff"])[None], d(host["Cff"])[None], d(host["Qff"])[None],
+                d(host["Xkf"])[None], d(host["Ckf"])[None], d(host["Qkf"])[None])
+    return host, match_fn
+
+
+def _oracle_track(z, T_WCf, T_WCk, cfg):
+    """The same frame through the oracle pieces chained in the reference's order (tracker.py:88-158)."""
+    from oracle import frame as of
+    fr = of.FrameState(cfg["filtering_mode"])
+    fr.update_pointmap(z["Xff"], z["Cff"])                                              # :94
+    kf = of.FrameState(cfg["filtering_mode"])
+    kf.update_pointmap(z["Xk_canon"], z["Ck"])
+    idx, vm = z["idx"], z["vm"][:, None]
+    Qk = ot.match_quality(z["Qff"][:, 0], z["Qkf"][:, 0], idx)[:, None]                 # :88-91
+    Xf, Cf, Ck = fr.X_canon[idx], fr.get_average_conf()[idx], kf.get_average_conf()      # :177-214
+    valid_opt, valid_kf = ot.validity(vm, Cf, Ck, Qk, cfg["C_conf"], cfg["Q_conf"])      # :108-113
+    match_frac = float(valid_opt.astype(np.float32).sum()) / valid_opt.size
+    T_f, T_rel, info = ot.opt_pose_ray_dist_sim3(Xf, kf.X_canon, T_WCf, T_WCk, Qk, valid_opt, cfg)
+    kf.update_pointmap(ot.act_sim3(T_rel, z["Xkf"].astype(np.float64)), z["Ckf"])       # :146-147
+    mk, uf = of.keyframe_stats(idx, vm, valid_kf)                                        # :149-155
+    return dict(T_WCf=T_f, T_rel=T_rel, iters=info["iters"], kf=kf, fr=fr, match_frac=match_frac, match_frac_k=mk,
+                unique_frac_f=uf, new_kf=min(mk, uf) < cfg["match_frac_thresh"])
+
+
+@pytest.mark.parametrize("thresh", [0.333, 0.95])
+def test_frame_tracker_track_matches_the_oracle_chain(dev, thresh):
+    """FrameTracker.track (tracker.py:51-175) on solvable geometry with the true correspondences injected through the
+    match operator: frame pointmap update, gathers and masks, the Gauss-Newton solve, the fused keyframe update
+    (Sim3.act + weighted fusion in one kernel), the keyframe statistics and the new-keyframe decision, against the
+    oracle pieces chained in the reference's order.  Two thresholds so that both outcomes of the decision occur."""
+    from types import SimpleNamespace
+    from mast3r_slam import config
+    from mast3r_slam.frame import Keyframes, create_frame
+    h, w = 96, 128
+    n = h * w
+    z, match_fn = _track_scene(h, w, 4, dev)
+    T_WCk = np.array([0.2, -0.1, 0.05, 0.0, 0.0, np.sin(0.05), np.cos(0.05), 1.1], dtype=np.float32)
+    config.set_config({"tracking": {"match_frac_thresh": thresh}})
+    try:
+        cfg = config.get_config()["tracking"]
+        img = torch.zeros((3, h, w), dtype=torch.uint8, device=dev)
+        kf = create_frame(0, img, T_WC=_t(T_WCk[None], dev))
+        kf.update_pointmap(_t(z["Xk_canon"], dev), _t(z["Ck"], dev))
+        frame = create_frame(1, img, T_WC=_t(T_WCk[None], dev))                          # slam.py: a new frame starts at the last pose
+        kfs = Keyframes()
+        kfs.append(kf)
+        tr = tracker.FrameTracker(SimpleNamespace(device=dev), kfs)
+        new_kf, match_info, try_reloc = tr.track(frame, mast3r_match_fn=match_fn)
+        o = _oracle_track(z, T_WCk.astype(np.float64), T_WCk.astype(np.float64), cfg)
+    finally:
+        config.reset_config()
+    assert try_reloc is False and len(match_info) == 6
+    assert o["match_frac"] > 0.5                                                         # the gate was passed on real matches
+    info = tr.last_info.cpu().numpy().reshape(-1)
+    assert int(info[0]) == o["iters"] and info[3] == 1.0                                 # same stopping iteration, converged
+    assert np.abs(frame.T_WC.cpu().numpy().reshape(8) - o["T_WCf"]).max() < 5e-5         # pose (t, q, s are O(1))
+    rel_true = np.abs(o["T_rel"] - z["T_true"]).max()
+    assert rel_true < 2e-3                                                               # ... and both found the scene's Sim(3)
+    kfo = o["kf"]
+    got = kfs.last_keyframe()
+    assert got.N == kfo.N == 2 and frame.N == 1
+    assert np.abs(got.X_canon.cpu().numpy() - kfo.X_canon).max() < 2e-5 * np.abs(kfo.X_canon).max()   # fused keyframe map
+    assert np.allclose(got.C.cpu().numpy(), kfo.C, rtol=1e-6)
+    assert np.array_equal(frame.X_canon.cpu().numpy(), o["fr"].X_canon.astype(np.float32))
+    assert tr.last_stats == (o["match_frac_k"], o["unique_frac_f"])                      # integer counts / N: exact
+    assert new_kf is o["new_kf"] and new_kf is (thresh > 0.5)
+    assert (tr.idx_f2k is None) == new_kf                                                # :160-161
+
+
+def test_frame_tracker_solve_failure_relocalises(dev):
+    """tracker.py:121-141: a failing optimisation makes track() return (False, [], True) and leaves the frame pose and the
+    keyframe map untouched.  Degenerate input: every matched point is the same point (rank-deficient normal matrix up
+    to the 1e-6 regulariser -> the step's scale component leaves the float range), which the device solve flags as
+    status 2."""
+    from types import SimpleNamespace
+    from mast3r_slam import config
+    from mast3r_slam.frame import Keyframes, create_frame
+    h, w = 32, 48
+    n = h * w
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    one = np.tile(np.array([[0.3, -0.2, 2.0]], dtype=np.float32), (n, 1))
+    far = np.tile(np.array([[30.0, 10.0, 2.0e4]], dtype=np.float32), (n, 1))             # a wildly inconsistent keyframe map
+    conf = np.full((n, 1), 2.0, dtype=np.float32)
+
+    def match_fn(model, frame, keyframe, idx_i2j_init=None):
+        return (d(np.zeros(n, np.int64))[None], d(np.ones(n, bool))[None, :, None], d(one)[None], d(conf)[None], d(conf)[None],
+                d(one)[None], d(conf)[None], d(conf)[None])
+    img = torch.zeros((3, h, w), dtype=torch.uint8, device=dev)
+    kf = create_frame(0, img)
+    kf.update_pointmap(d(far), d(conf))
+    frame = create_frame(1, img)
+    kfs = Keyframes()
+    kfs.append(kf)
+    tr = tracker.FrameTracker(SimpleNamespace(device=dev), kfs)
+    pose0, map0, n0 = frame.T_WC.clone(), kf.X_canon.clone(), kf.N
+    out = tr.track(frame, mast3r_match_fn=match_fn)
+    status = float(tr.last_info.reshape(-1)[3])
+    assert status == 2.0, status
+    assert out == (False, [], True)
+    assert torch.equal(frame.T_WC, pose0) and torch.equal(kfs.last_keyframe().X_canon, map0) and kfs.last_keyframe().N == n0

@@ -3,6 +3,7 @@
 the C ABI - and torch.mm (hipBLASLt) on the same operands as a yardstick measured in the same process (devices of
 the pool differ by up to 12 %: compare ratios, not absolutes across runs).  Interleaved rounds, median."""
 import os, sys, statistics
+P = int(sys.argv[sys.argv.index("--pairs") + 1]) if "--pairs" in sys.argv else 8     # pairs per step: M = 2048 P (encoder), 1024 P (decoder / heads)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "mast3r-slam_amd")]
 import torch
@@ -23,20 +24,21 @@ def mk(m, n, k, dt, groups):
     b = [torch.randn(n, generator=g).to(dev) for _ in range(groups)]
     return a, w, b
 
+ME, MD = 2048 * P, 1024 * P
 CASES = [  # name, m, n, k, epi, dtype, groups, launches per step
-    ("enc qkv+rope", 16384, 3072, 1024, "rope", torch.bfloat16, 1, 24),
-    ("enc qkv plain", 16384, 3072, 1024, "bf16", torch.bfloat16, 1, 0),
-    ("enc proj f32acc", 16384, 1024, 1024, "acc", torch.bfloat16, 1, 24),
-    ("enc fc1 gelu", 16384, 4096, 1024, "gelu", torch.bfloat16, 1, 24),
-    ("enc fc2 f32acc", 16384, 1024, 4096, "acc", torch.bfloat16, 1, 24),
-    ("dec kv+rope x2", 8192, 1536, 768, "rope", torch.bfloat16, 2, 12),
-    ("dec qkv+rope x2", 8192, 2304, 768, "rope", torch.bfloat16, 2, 12),
-    ("dec q+rope x2", 8192, 768, 768, "rope", torch.bfloat16, 2, 12),
-    ("dec proj f32acc x2", 8192, 768, 768, "acc", torch.bfloat16, 2, 24),
-    ("dec fc1 gelu x2", 8192, 3072, 768, "gelu", torch.bfloat16, 2, 12),
-    ("dec fc2 f32acc x2", 8192, 768, 3072, "acc", torch.bfloat16, 2, 12),
-    ("feat fc1 gelu f16", 8192, 7168, 1792, "gelu", torch.float16, 1, 2),
-    ("feat fc2 f16", 8192, 6400, 7168, "bf16", torch.float16, 1, 2),
+    ("enc qkv+rope", ME, 3072, 1024, "rope", torch.bfloat16, 1, 24),
+    ("enc qkv plain", ME, 3072, 1024, "bf16", torch.bfloat16, 1, 0),
+    ("enc proj f32acc", ME, 1024, 1024, "acc", torch.bfloat16, 1, 24),
+    ("enc fc1 gelu", ME, 4096, 1024, "gelu", torch.bfloat16, 1, 24),
+    ("enc fc2 f32acc", ME, 1024, 4096, "acc", torch.bfloat16, 1, 24),
+    ("dec kv+rope x2", MD, 1536, 768, "rope", torch.bfloat16, 2, 12),
+    ("dec qkv+rope x2", MD, 2304, 768, "rope", torch.bfloat16, 2, 12),
+    ("dec q+rope x2", MD, 768, 768, "rope", torch.bfloat16, 2, 12),
+    ("dec proj f32acc x2", MD, 768, 768, "acc", torch.bfloat16, 2, 24),
+    ("dec fc1 gelu x2", MD, 3072, 768, "gelu", torch.bfloat16, 2, 12),
+    ("dec fc2 f32acc x2", MD, 768, 3072, "acc", torch.bfloat16, 2, 12),
+    ("feat fc1 gelu f16 x2", MD, 7168, 1792, "gelu", torch.float16, 2, 1),
+    ("feat fc2 f16 x2", MD, 6400, 7168, "bf16", torch.float16, 2, 1),
 ]
 EPI = {"bf16": ops.EPI_BF16, "gelu": ops.EPI_BF16_GELU, "acc": ops.EPI_F32_ACCUM, "rope": ops.EPI_BF16_ROPE}
 runs = []
@@ -56,28 +58,44 @@ for name, m, n, k, epi, dt, groups, per_step in CASES:
         else:
             fn = lambda a=a, w=w, b=b, e=EPI[epi], x=x: ops.gemm(a, w[0], b[0], e, out=x, resid=x)
         ref = lambda a=a, w=w: torch.mm(a, w[0].T)
-    runs.append((name, 2.0 * groups * m * n * k, fn, ref, per_step))
+    runs.append((name, 2.0 * groups * m * n * k, fn, ref, per_step, int(_ffi.lib().m3_gemm_pick_tile(m, n, groups))))
+
+GRAPH = "--graph" in sys.argv        # time hipGraph replays of 16 launches (small launches are host-bound when issued eagerly)
+_graphs = {}
 
 def t(fn, n=8):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if GRAPH:
+        g_ = _graphs.get(id(fn))
+        if g_ is None:
+            fn(); torch.cuda.synchronize()
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_):
+                for _ in range(16):
+                    fn()
+            _graphs[id(fn)] = g_
+        g_.replay()
+        e0.record(); g_.replay(); e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 16 * 1e3
     e0.record()
     for _ in range(n):
         fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 
-for name, fl, fn, ref, _ in runs:
+for name, fl, fn, ref, _, _ in runs:
     fn(); ref()
 torch.cuda.synchronize()
 res = {name: ([], []) for name, *_ in runs}
 for rnd in range(5):
-    for name, fl, fn, ref, _ in runs:
+    for name, fl, fn, ref, _, _ in runs:
         res[name][0].append(t(fn)); res[name][1].append(t(ref))
-print("| launch | us (ours) | TFLOP/s | torch.mm us (no epilogue) | TFLOP/s | ours/mm time | per step ms |")
-print("|---|---|---|---|---|---|---|")
+print(f"P = {P} pairs per step; M3_GEMM_TILE={os.environ.get('M3_GEMM_TILE', '-')}\n")
+print("| launch | tile | us (ours) | TFLOP/s | torch.mm us (no epilogue) | TFLOP/s | ours/mm time | per step ms |")
+print("|---|---|---|---|---|---|---|---|")
 tot = 0.0
-for name, fl, fn, ref, per_step in runs:
+for name, fl, fn, ref, per_step, tile in runs:
     a, b = statistics.median(res[name][0]), statistics.median(res[name][1])
     tot += a * per_step / 1e3
-    print(f"| {name} | {a:.1f} | {fl / a / 1e6:.0f} | {b:.1f} | {fl / b / 1e6:.0f} | {a / b:.2f} | {a * per_step / 1e3:.2f} |")
+    print(f"| {name} | {tile} | {a:.1f} | {fl / a / 1e6:.0f} | {b:.1f} | {fl / b / 1e6:.0f} | {a / b:.2f} | {a * per_step / 1e3:.2f} |")
 print(f"\nsum over one step's launches: {tot:.2f} ms")

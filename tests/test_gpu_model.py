@@ -440,13 +440,22 @@ def test_frame_tracker_end_to_end(tiny, dev):
         try:
             tr.cfg = config.get_config()["tracking"]
             tr.reset_idx_f2k()
+            n_before, pose_before = keyframes.last_keyframe().N, fr.T_WC.clone()
             new_kf, match_info, try_reloc = tr.track(fr, mast3r_match_fn=mast3r_utils.mast3r_match_asymmetric)
         finally:
             config.reset_config()
-        assert try_reloc is False and isinstance(new_kf, bool) and len(match_info) == 6
+        status = float(tr.last_info.reshape(-1)[3])
         assert fr.T_WC.shape == (1, 8) and torch.isfinite(fr.T_WC).all()
         assert tr.idx_f2k is None or tr.idx_f2k.shape == (1, h * wd)
-        assert keyframes.last_keyframe().N >= 2                         # keyframe pointmap was fused again
+        if try_reloc:
+            # random-weight pointmaps are not a consistent scene: the Gauss-Newton step can diverge, which the device solve
+            # reports (status 2) and track() turns into the reference's `except` branch (tracker.py:139-141): relocalise,
+            # frame pose and keyframe map untouched
+            assert status == 2.0 and (new_kf, match_info) == (False, [])
+            assert torch.equal(fr.T_WC, pose_before) and keyframes.last_keyframe().N == n_before
+        else:
+            assert status in (0.0, 1.0) and isinstance(new_kf, bool) and len(match_info) == 6
+            assert keyframes.last_keyframe().N == n_before + 1              # keyframe pointmap was fused again
     # the min_match_frac gate (tracker.py:116-119): impossible thresholds -> relocalise
     config.set_config({"tracking": {"Q_conf": 1e9}})
     try:

@@ -438,18 +438,35 @@ class PairsWorkload:
                                                              "achieved": 29.3 * MB * P / us16 / 1e3, "unit": "GB/s",
                                                              "frac": 29.3 * MB * P / us16 / 1e3 / HBM_PEAK_GBS}}
 
-        # matcher variant named by north_star: fast reciprocal NN (MASt3R sec. 3.3) on the same scene, 64 x 64 seeds
-        # (subsample 8), fp16 descriptors, device-side loop (3 rounds), per pair; not part of the timed step
-        d1, d2 = sc["D21"][0].half(), sc["D11"][0].half()
+        # matcher variant named by north_star: fast reciprocal NN (MASt3R sec. 3.3) on the same scenes, all P pairs in one
+        # set of launches (m3_frnn_pack once per map, m3_frnn_round per round), 64 x 64 seeds per pair (subsample 8),
+        # fp16 descriptors, 3 rounds; not part of the timed step.  MFMA roofline per search launch: 2 S N D flops
+        # (D = 24; the kernel multiplies K padded to 32) over the device time of the k_nn_mfma launch.
+        d1, d2 = sc["D21"].half(), sc["D11"].half()
         for _ in range(2):
             matching.fast_reciprocal_nn_device(d1, d2, subsample=8, max_iter=3)
         e0, e1 = ev(), ev()
         e0.record()
         for _ in range(3):
-            p1, p2 = matching.fast_reciprocal_nn_device(d1, d2, subsample=8, max_iter=3)
+            pp, p1, p2 = matching.fast_reciprocal_nn_device(d1, d2, subsample=8, max_iter=3)
         e1.record(); torch.cuda.synchronize()
-        result["fast_nn_matcher"] = {"ms_per_pair": round(e0.elapsed_time(e1) / 3, 3), "reciprocal_pairs": int(p1.numel()),
-                                     "seeds": 4096, "note": "m3_nn_search_mfma, fp16 descriptors, 3 rounds x 2 searches of 4096 x 262144 x 24"}
+        ms_all = e0.elapsed_time(e1) / 3
+        # one search launch alone (queries = the seed rows of the packed map), HIP events around the C-ABI round
+        _ffi.PROFILE, _ffi.PROFILE_NAMES = {}, ("m3_frnn_round",)
+        matching.fast_reciprocal_nn_device(d1, d2, subsample=8, max_iter=3)
+        torch.cuda.synchronize()
+        evs, _ffi.PROFILE = _ffi.PROFILE.get("m3_frnn_round", []), None
+        us_round = sum(a_.elapsed_time(b_) for a_, b_ in evs) / max(len(evs), 1) * 1e3
+        seeds = (self.h // 8) * (self.w // 8)
+        fl_search = 2.0 * P * seeds * (self.h * self.w) * 24
+        result["fast_nn_matcher"] = {"ms_per_pair": round(ms_all / P, 3), "ms_all_pairs": round(ms_all, 3), "pairs": P,
+                                     "reciprocal_pairs": int(p1.numel()), "seeds_per_pair": seeds,
+                                     "round_us": us_round,
+                                     "roofline": {"bound": "mfma", "kernel": "k_nn_mfma<1> (two searches + bookkeeping per m3_frnn_round)",
+                                                  "achieved": 2 * fl_search / us_round / 1e6, "peak": MFMA_BF16_PEAK_TFLOPS,
+                                                  "unit": "TFLOP/s", "frac": 2 * fl_search / us_round / 1e6 / MFMA_BF16_PEAK_TFLOPS,
+                                                  "flops_note": "2 S N D with D = 24 (K is padded to 32 on the matrix core: x 4/3 issued)"},
+                                     "note": f"m3_frnn_pack + 3 x m3_frnn_round on {P} pairs at once, fp16 descriptors, {seeds} seeds x {self.h * self.w} pixels per search"}
 
         if P != 1:
             # BASELINE configs[1]: one pair per step (latency regime), same pipeline, graph-replayed

@@ -110,6 +110,20 @@ int64_t m3_nn_pack_bytes(int B, int S, int N, int in_f16);
 int m3_nn_search_mfma(const void *Q, const void *DB, int32_t *idx_out, float *score_out, uint64_t *keys_ws,
                       void *pack_ws, int B, int S, int N, int D, int in_f16, void *stream);
 
+/* Fast reciprocal nearest-neighbour matching, P pairs at once, loop on the device (MASt3R sec. 3.3; BASELINE.json names
+ * it, the reference tree has no code for it: semantics in mast3r_slam/matching.py, oracle/matching.py).  Each
+ * descriptor map [P,N,D] (fp32, or IEEE fp16 with in_f16 = 1; D in {16, 24, 32}) is packed ONCE
+ * (m3_frnn_pack -> m3_frnn_pack_bytes(P, N, in_f16) bytes, 16-byte aligned) and serves as the database of one search
+ * direction and as the query source of the other.  m3_frnn_round runs view 1 -> view 2 -> view 1 for every seed:
+ * cur int32 [P,S] = the view-1 pixel a seed sits on (in / out), active uint8 [P,S] (in / out), got1 / got2 int32
+ * [P,S] = this round's reciprocal pairs (-1 where none), xy2_ws int32 [P,S], keys_ws uint64 [P,S] scratch that
+ * must be zero on entry and is left zero. */
+int64_t m3_frnn_pack_bytes(int P, int N, int in_f16);
+int m3_frnn_pack(const void *Dmap, void *packed, int P, int N, int D, int in_f16, void *stream);
+int m3_frnn_round(const void *packed1, const void *packed2, int32_t *cur, uint8_t *active, int32_t *got1,
+                  int32_t *got2, int32_t *xy2_ws, uint64_t *keys_ws, int P, int S, int N1, int N2, int in_f16,
+                  void *stream);
+
 /* ------------------------------------------------------------------ tracking */
 
 /* FrameTracker.track glue (tracker.py:88-113, _get_points_poses :177-214): for each

@@ -23,6 +23,10 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fhip-fp32-cor
 PER_FILE = {
     "matching.hip": ["-ffp-contract=off"],
     "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+    # MFMA results are consumed by VALU (arg-max) right away: keep them out of the AGPR file (4 v_accvgpr_read per MFMA)
+    # -fno-honor-nans: scores are sums of finite products, so the arg-max needs no NaN canonicalisation (a v_max x, x
+    # in front of every v_max3 that takes an MFMA result); infinities (the -inf initial maximum) stay honoured
+    "fast_nn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-honor-nans"],
     # hipcc 7.2's SLP vectoriser mis-compiled the first k_track_accum (two of its 36 sums wrong at -O3, right with
     # -fno-slp-vectorize or -O1: tools/incident_r01/run.py); packed fp32 math buys these
     # float64-fold-bound kernels nothing, so it stays off for both Gauss-Newton sources

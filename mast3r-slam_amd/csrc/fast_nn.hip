@@ -95,7 +95,7 @@ k_nn_unpack(const unsigned long long *__restrict__ keys, int32_t *__restrict__ i
 //   fp16 descriptors (BASELINE configs[4] "fp16 features")  -> 1 MFMA per 16 x 16 scores, exact products, fp32 sums
 //   fp32 descriptors -> hi = fp16(x), lo = fp16(x - hi); score = hi.hi + hi.lo + lo.hi (3 MFMAs), dropped lo.lo term
 //                       <= 2^-24 for unit vectors: the result is as close to the float64 oracle as the fp32 FMA chain
-// Workgroup = 4 waves x 128 queries (8 query tiles in registers per wave); 64 database rows per step are staged once
+// Workgroup = 4 waves x 128 queries (8 query tiles in registers per wave); 128 database rows per step are staged once
 // in LDS (LDS-DMA, double-buffered, swizzled so the ds_read_b128 fragment reads are conflict-free) and shared by the
 // four waves.  Arg-max: two v_max3 per tile find whether ANY lane improved; only then (O(log N) times per query) the
 // exact sequential update runs - rows ascend, strict '>': the lowest index wins ties as in the fp32 kernel.
@@ -126,17 +126,90 @@ k_nn_pack(const void *__restrict__ X, unsigned short *__restrict__ hi, unsigned 
 constexpr int kQT = 8;                      // query tiles (16 queries each) per wave
 constexpr int kQPW = kQT * 16;              // queries per wave
 constexpr int kQPB = kQPW * (kThreads / 64);   // queries per workgroup: 512
-constexpr int kRows = 64;                   // database rows per LDS step
+constexpr int kRows = 128;                  // database rows per LDS step (two workgroup barriers per step; 64 rows: 1564 us per round, 128: 1509)
 
+// Round 3.  The round-2 loop issued ONE MFMA at a time: its result went to an AGPR quad that the next instructions
+// read back (v_accvgpr_read x 4), so the following MFMA waited out the matrix core's full latency, and the ragged-tail
+// compares ran on every tile: 358 TFLOP/s (K padded to 32) = 0.14 of the peak.  Now (a) the file is built with
+// -amdgpu-mfma-vgpr-form (results land in VGPRs), (b) the 2 x 4 MFMAs of two row tiles x four query tiles are issued
+// back to back into eight accumulators and only then reduced (max over a lane's 8 scores of a query: 3 x v_max3 + v_max,
+// one compare + wave vote per PAIR of tiles), (c) the ragged tail is a separate instantiation of the step (RAGGED) taken
+// for the last step of a split only, (d) queries are gathered BY INDEX from a packed map (qidx), so a descriptor map is
+// packed once per matcher call and serves as database of one search direction and query source of the other.
+template <int PASSES, bool RAGGED>
+__device__ __forceinline__ void nn_step(const unsigned char *__restrict__ hi_s, const unsigned char *__restrict__ lo_s,
+                                        const f16x8 (&qh)[kQT], const f16x8 (&ql)[PASSES == 3 ? kQT : 1],
+                                        float (&best)[kQT], int (&bestn)[kQT], int nbase, int n1, int col, int g) {
+#pragma unroll
+    for (int rp = 0; rp < kRows / 32; ++rp) {                                 // pairs of 16-row tiles
+        f16x8 ah[2], al[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = (2 * rp + h) * 16 + col;                          // A operand: lane -> row (lane & 15), k chunk g
+            const int off = row * 64 + ((g ^ ((0 - (row >> 2)) & 3)) << 4);
+            ah[h] = *reinterpret_cast<const f16x8 *>(hi_s + off);
+            al[h] = ah[h];
+            if (PASSES == 3) al[h] = *reinterpret_cast<const f16x8 *>(lo_s + off);
+        }
+        const int nrow = nbase + rp * 32 + g * 4;                             // first of this lane's 2 x 4 output rows
+#pragma unroll
+        for (int t0 = 0; t0 < kQT; t0 += 4) {
+            f32x4 acc[4][2];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[h], qh[t0 + tt], c, 0, 0, 0);
+                    if (PASSES == 3) {
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[h], ql[t0 + tt], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[h], qh[t0 + tt], c, 0, 0, 0);
+                    }
+                    acc[tt][h] = c;
+                }
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int t = t0 + tt;
+                f32x4 &a0 = acc[tt][0], &a1 = acc[tt][1];
+                if (RAGGED) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (nrow + j >= n1) a0[j] = -INFINITY;
+                        if (nrow + 16 + j >= n1) a1[j] = -INFINITY;
+                    }
+                }
+                float mx = __builtin_fmaxf(__builtin_fmaxf(a0[0], a0[1]), a0[2]);
+                mx = __builtin_fmaxf(__builtin_fmaxf(mx, a0[3]), a1[0]);
+                mx = __builtin_fmaxf(__builtin_fmaxf(mx, a1[1]), a1[2]);
+                mx = __builtin_fmaxf(mx, a1[3]);
+                // the running maximum is updated on the straight-line path (one v_max); only the INDEX lives in the rare
+                // branch - with both updated there, every loop-carried best[] register became a phi and was copied
+                // around the branch on every tile (PMC: 8.4 VALU instructions per MFMA, most of them v_mov)
+                const bool imp = mx > best[t];
+                best[t] = __builtin_fmaxf(best[t], mx);
+                if (__any(imp)) {                                             // rare after the first few steps
+                    int bn = bestn[t];
+#pragma unroll
+                    for (int j = 3; j >= 0; --j) bn = (imp && a1[j] == best[t]) ? nrow + 16 + j : bn;   // descending: the lowest row
+#pragma unroll
+                    for (int j = 3; j >= 0; --j) bn = (imp && a0[j] == best[t]) ? nrow + j : bn;        // that holds the maximum wins
+                    bestn[t] = bn;
+                }
+            }
+        }
+    }
+}
+
+// Qhi / Qlo: packed rows [P][NQ][32]; qidx int32 [P][S] selects the query rows (null: query s = row s, NQ = S).
 template <int PASSES>
-__global__ void __launch_bounds__(kThreads)
-k_nn_mfma(const unsigned short *__restrict__ Qhi, const unsigned short *__restrict__ Qlo,
+__global__ void __launch_bounds__(kThreads, PASSES == 1 ? 4 : 2)       // fp16 descriptors: 4 waves per SIMD (<= 128 registers)
+k_nn_mfma(const unsigned short *__restrict__ Qhi, const unsigned short *__restrict__ Qlo, const int32_t *__restrict__ qidx,
           const unsigned short *__restrict__ Dhi, const unsigned short *__restrict__ Dlo,
-          unsigned long long *__restrict__ keys, int S, int N, int per_split) {
+          unsigned long long *__restrict__ keys, int S, int NQ, int N, int per_split) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][kRows * 64];   // [stage][hi|lo][64 rows x 64 B]
     const int b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, g = lane >> 4;
-    const size_t qb = (size_t)b * S, db = (size_t)b * N;
+    const size_t qb = (size_t)b * NQ, db = (size_t)b * N, kb = (size_t)b * S;
     // query fragments (MFMA B operand): lane -> query col, k = 8 g .. 8 g + 7
     f16x8 qh[kQT], ql[PASSES == 3 ? kQT : 1];
     const int q0 = blockIdx.x * kQPB + wave * kQPW;
@@ -144,8 +217,10 @@ k_nn_mfma(const unsigned short *__restrict__ Qhi, const unsigned short *__restri
     for (int t = 0; t < kQT; ++t) {
         int q = q0 + t * 16 + col;
         q = q < S ? q : S - 1;
-        qh[t] = *reinterpret_cast<const f16x8 *>(Qhi + (qb + q) * 32 + g * 8);
-        if (PASSES == 3) ql[t] = *reinterpret_cast<const f16x8 *>(Qlo + (qb + q) * 32 + g * 8);
+        int qr = qidx ? qidx[kb + q] : q;
+        qr = qr < 0 ? 0 : (qr >= NQ ? NQ - 1 : qr);
+        qh[t] = *reinterpret_cast<const f16x8 *>(Qhi + (qb + qr) * 32 + g * 8);
+        if (PASSES == 3) ql[t] = *reinterpret_cast<const f16x8 *>(Qlo + (qb + qr) * 32 + g * 8);
     }
     const int n0 = blockIdx.y * per_split, n1 = min(n0 + per_split, N);
     float best[kQT];
@@ -155,13 +230,16 @@ k_nn_mfma(const unsigned short *__restrict__ Qhi, const unsigned short *__restri
     // staging: thread -> (row = tid / 4, chunk' = tid % 4); source chunk = chunk' ^ ((-(row >> 2)) & 3)
     const int srow = tid >> 2, sc = (tid & 3) ^ ((0 - (srow >> 2)) & 3);
     auto stage = [&](int blk, int buf) {
-        int n = n0 + blk * kRows + srow;
-        n = n < N ? n : N - 1;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) unsigned *)(Dhi + (db + n) * 32 + sc * 8),
-                                         (__attribute__((address_space(3))) unsigned *)(&lds[buf][0][wave * 1024]), 16, 0, 0);
-        if (PASSES == 3)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) unsigned *)(Dlo + (db + n) * 32 + sc * 8),
-                                             (__attribute__((address_space(3))) unsigned *)(&lds[buf][1][wave * 1024]), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < kRows / 64; ++i) {
+            int n = n0 + blk * kRows + i * 64 + srow;
+            n = n < N ? n : N - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) unsigned *)(Dhi + (db + n) * 32 + sc * 8),
+                                             (__attribute__((address_space(3))) unsigned *)(&lds[buf][0][i * 4096 + wave * 1024]), 16, 0, 0);
+            if (PASSES == 3)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) unsigned *)(Dlo + (db + n) * 32 + sc * 8),
+                                                 (__attribute__((address_space(3))) unsigned *)(&lds[buf][1][i * 4096 + wave * 1024]), 16, 0, 0);
+        }
     };
     const int nblk = (n1 - n0 + kRows - 1) / kRows;
     if (nblk > 0) stage(0, 0);
@@ -169,40 +247,15 @@ k_nn_mfma(const unsigned short *__restrict__ Qhi, const unsigned short *__restri
         const int buf = blk & 1;
         if (blk + 1 < nblk) {
             stage(blk + 1, buf ^ 1);
-            if (PASSES == 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            static_assert(kRows == 128, "the counted waits below assume two 64-row issues per plane and stage");
+            if (PASSES == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        const bool ragged = n0 + (blk + 1) * kRows > n1;                      // only the last step of a split
-#pragma unroll
-        for (int rt = 0; rt < kRows / 16; ++rt) {
-            const int row = rt * 16 + col;                                    // A operand: lane -> row (lane & 15), k chunk g
-            const int off = row * 64 + ((g ^ ((0 - (row >> 2)) & 3)) << 4);
-            const f16x8 ah = *reinterpret_cast<const f16x8 *>(&lds[buf][0][off]);
-            f16x8 al = ah;
-            if (PASSES == 3) al = *reinterpret_cast<const f16x8 *>(&lds[buf][1][off]);
-            const int nrow = n0 + blk * kRows + rt * 16 + g * 4;              // first of this lane's 4 output rows
-#pragma unroll
-            for (int t = 0; t < kQT; ++t) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, qh[t], acc, 0, 0, 0);
-                if (PASSES == 3) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ql[t], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, qh[t], acc, 0, 0, 0);
-                }
-                if (ragged) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (nrow + j >= n1) acc[j] = -INFINITY;
-                }
-                const float mx = fmaxf(__builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]), acc[3]);
-                if (__any(mx > best[t])) {                                    // rare after the first few steps
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (acc[j] > best[t]) { best[t] = acc[j]; bestn[t] = nrow + j; }
-                }
-            }
-        }
+        const int nbase = n0 + blk * kRows;
+        if (nbase + kRows > n1) nn_step<PASSES, true>(lds[buf][0], lds[buf][1], qh, ql, best, bestn, nbase, n1, col, g);   // last step of a split only
+        else nn_step<PASSES, false>(lds[buf][0], lds[buf][1], qh, ql, best, bestn, nbase, n1, col, g);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                         // reads of `buf` done before it is restaged
@@ -222,9 +275,35 @@ k_nn_mfma(const unsigned short *__restrict__ Qhi, const unsigned short *__restri
         if (g == 0 && q < S) {
             const unsigned long long key = ((unsigned long long)ordered_bits(best[t]) << 32) |
                                            (unsigned long long)(0xffffffffu - (unsigned)bestn[t]);
-            atomicMax(keys + qb + q, key);
+            atomicMax(keys + kb + q, key);
         }
     }
+}
+
+// ---- one round of fast reciprocal NN on the device (matching.fast_reciprocal_nn_device), batched over P pairs -----------
+// mid: keys of the forward search -> xy2 (the view-2 pixel each seed landed on), keys cleared for the backward search
+__global__ void __launch_bounds__(kThreads)
+k_frnn_mid(unsigned long long *__restrict__ keys, int32_t *__restrict__ xy2, long long total) {
+    const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= total) return;
+    xy2[i] = (int32_t)(0xffffffffu - (unsigned)(keys[i] & 0xffffffffull));
+    keys[i] = 0ull;
+}
+// end: keys of the backward search -> back; a seed that returned to where it started is a reciprocal pair (recorded in
+// row `round` of got1 / got2, -1 elsewhere) and leaves the active set, the others continue from where they landed
+__global__ void __launch_bounds__(kThreads)
+k_frnn_end(unsigned long long *__restrict__ keys, const int32_t *__restrict__ xy2, int32_t *__restrict__ cur,
+           uint8_t *__restrict__ active, int32_t *__restrict__ got1, int32_t *__restrict__ got2, long long total) {
+    const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= total) return;
+    const int32_t back = (int32_t)(0xffffffffu - (unsigned)(keys[i] & 0xffffffffull));
+    keys[i] = 0ull;
+    const int32_t c = cur[i];
+    const bool act = active[i] != 0, conv = act && back == c;
+    got1[i] = conv ? c : -1;
+    got2[i] = conv ? xy2[i] : -1;
+    active[i] = (uint8_t)(act && !conv);
+    if (act && !conv) cur[i] = back;
 }
 
 }  // namespace
@@ -294,13 +373,73 @@ int m3_nn_search_mfma(const void *Q, const void *DB, int32_t *idx_out, float *sc
     splits = m3_cdiv(N, per_split);
     const dim3 grid(qblocks, splits, B);
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(keys_ws);
-    if (in_f16) hipLaunchKernelGGL(k_nn_mfma<1>, grid, blk, 0, st, qhi, qlo, dhi, dlo, keys, S, N, per_split);
-    else hipLaunchKernelGGL(k_nn_mfma<3>, grid, blk, 0, st, qhi, qlo, dhi, dlo, keys, S, N, per_split);
+    if (in_f16) hipLaunchKernelGGL(k_nn_mfma<1>, grid, blk, 0, st, qhi, qlo, (const int32_t *)nullptr, dhi, dlo, keys, S, S, N, per_split);
+    else hipLaunchKernelGGL(k_nn_mfma<3>, grid, blk, 0, st, qhi, qlo, (const int32_t *)nullptr, dhi, dlo, keys, S, S, N, per_split);
     M3_CHECK_LAUNCH("m3_nn_search_mfma");
     const long long total = (long long)B * S;
     hipLaunchKernelGGL(k_nn_unpack, dim3((unsigned)m3_cdiv(total, (long long)kThreads)), dim3(kThreads), 0, st,
                        (const unsigned long long *)keys, idx_out, score_out, total);
     M3_CHECK_LAUNCH("m3_nn_search_mfma/unpack");
+    return M3_OK;
+}
+
+
+// ---- batched fast reciprocal NN: pack each descriptor map ONCE, then rounds of (forward search, backward search) ------
+// A packed map is [P][N][32] fp16 (K zero-padded), followed by the lo plane for fp32 descriptors.
+int64_t m3_frnn_pack_bytes(int P, int N, int in_f16) {
+    if (P <= 0 || N <= 0) return 0;
+    return (int64_t)P * N * 64 * (in_f16 ? 1 : 2);
+}
+int m3_frnn_pack(const void *Dmap, void *packed, int P, int N, int D, int in_f16, void *stream) {
+    M3_REQUIRE(Dmap && packed && P > 0 && N > 0 && (D == 16 || D == 24 || D == 32));
+    M3_REQUIRE((reinterpret_cast<size_t>(packed) & 15) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned short *hi = (unsigned short *)packed, *lo = in_f16 ? nullptr : hi + (size_t)P * N * 32;
+    const long long rows = (long long)P * N;
+    const dim3 blk(kThreads), grid((unsigned)m3_cdiv(rows * 4, (long long)kThreads));
+#define M3_PACK1(DD)                                                                                         \
+    do { if (in_f16) hipLaunchKernelGGL((k_nn_pack<true, DD>), grid, blk, 0, st, Dmap, hi, lo, rows);          \
+         else hipLaunchKernelGGL((k_nn_pack<false, DD>), grid, blk, 0, st, Dmap, hi, lo, rows); } while (0)
+    if (D == 24) M3_PACK1(24); else if (D == 16) M3_PACK1(16); else M3_PACK1(32);
+#undef M3_PACK1
+    M3_CHECK_LAUNCH("m3_frnn_pack");
+    return M3_OK;
+}
+
+static int frnn_search(const void *qpacked, int NQ, const int32_t *qidx, const void *dpacked, int N, unsigned long long *keys,
+                       int P, int S, int in_f16, hipStream_t st) {
+    const unsigned short *qhi = (const unsigned short *)qpacked, *qlo = in_f16 ? nullptr : qhi + (size_t)P * NQ * 32;
+    const unsigned short *dhi = (const unsigned short *)dpacked, *dlo = in_f16 ? nullptr : dhi + (size_t)P * N * 32;
+    const int qblocks = m3_cdiv(S, kQPB);
+    int splits = m3_cdiv(1024, qblocks * P);                  // ~4 workgroups per CU over the whole call
+    if (splits < 1) splits = 1;
+    if (splits > m3_cdiv(N, kRows)) splits = m3_cdiv(N, kRows);
+    int per_split = m3_cdiv(N, splits);
+    per_split = m3_cdiv(per_split, kRows) * kRows;
+    splits = m3_cdiv(N, per_split);
+    const dim3 grid(qblocks, splits, P), blk(kThreads);
+    if (in_f16) hipLaunchKernelGGL(k_nn_mfma<1>, grid, blk, 0, st, qhi, qlo, qidx, dhi, dlo, keys, S, NQ, N, per_split);
+    else hipLaunchKernelGGL(k_nn_mfma<3>, grid, blk, 0, st, qhi, qlo, qidx, dhi, dlo, keys, S, NQ, N, per_split);
+    return M3_OK;
+}
+
+// One round for P pairs at once (no reference counterpart: SURVEY 8a row K8).  packed1 / packed2: the two views'
+// packed maps (m3_frnn_pack; N1 / N2 rows per pair).  cur int32 [P,S]: the view-1 pixel every seed currently sits on
+// (in / out), active uint8 [P,S] (in / out), got1 / got2 int32 [P,S]: this round's reciprocal pairs (-1 = none),
+// xy2_ws int32 [P,S] and keys_ws uint64 [P,S] scratch; keys_ws must be ZERO on entry (it is left zero).
+int m3_frnn_round(const void *packed1, const void *packed2, int32_t *cur, uint8_t *active, int32_t *got1, int32_t *got2,
+                  int32_t *xy2_ws, uint64_t *keys_ws, int P, int S, int N1, int N2, int in_f16, void *stream) {
+    M3_REQUIRE(packed1 && packed2 && cur && active && got1 && got2 && xy2_ws && keys_ws);
+    M3_REQUIRE(P > 0 && P <= 65535 && S > 0 && N1 > 0 && N2 > 0);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(keys_ws);
+    const long long total = (long long)P * S;
+    const dim3 eb(kThreads), eg((unsigned)m3_cdiv(total, (long long)kThreads));
+    frnn_search(packed1, N1, cur, packed2, N2, keys, P, S, in_f16, st);               // view 1 -> view 2
+    hipLaunchKernelGGL(k_frnn_mid, eg, eb, 0, st, keys, xy2_ws, total);
+    frnn_search(packed2, N2, xy2_ws, packed1, N1, keys, P, S, in_f16, st);            // and back
+    hipLaunchKernelGGL(k_frnn_end, eg, eb, 0, st, keys, (const int32_t *)xy2_ws, cur, active, got1, got2, total);
+    M3_CHECK_LAUNCH("m3_frnn_round");
     return M3_OK;
 }
 

@@ -143,36 +143,52 @@ def nn_search(Q: torch.Tensor, DB: torch.Tensor, return_score: bool = False, met
 
 
 def fast_reciprocal_nn_device(D1: torch.Tensor, D2: torch.Tensor, subsample: int = 8, max_iter: int = 10):
-    """fast_reciprocal_nn with the whole loop on the device: no host synchronisation per round.  Every round runs
-    on the full seed set (converged seeds are masked, a seed that moved continues from where it landed) and the
-    converged pairs are collected into fixed-size buffers; ONE synchronisation at the end (the final `unique`).
-    Same result set as the shrinking-active-set version for the same max_iter.  D1, D2 [H,W,D] fp32 or fp16."""
-    if D1.dim() != 3 or D2.dim() != 3 or D1.shape[2] != D2.shape[2]:
-        raise ValueError("D1, D2 must be [H,W,D] with the same D")
-    h1, w1, d = D1.shape
-    f1, f2 = D1.reshape(1, -1, d).contiguous(), D2.reshape(1, -1, d).contiguous()
-    dev = D1.device
+    """fast_reciprocal_nn with the whole loop on the device, for ONE pair (D1, D2 [H,W,D]) or a BATCH of P pairs
+    ([P,H,W,D] each) in the same launches: every descriptor map is packed to K-padded fp16 once (m3_frnn_pack) and serves
+    as the database of one search direction and the query source of the other; a round is ONE C-ABI call (m3_frnn_round:
+    forward search, backward search, convergence bookkeeping - four launches for all pairs, no torch glue, no host
+    synchronisation).  Every round runs on the full seed set (converged seeds are masked, a seed that moved continues
+    from where it landed); ONE synchronisation at the end (the final `unique`).  Same result set as the
+    shrinking-active-set version (fast_reciprocal_nn) for the same max_iter.  fp32 or fp16 descriptors.
+    Returns (idx1, idx2) int64 [M] for one pair; (pair, idx1, idx2) int64 [M] (sorted by pair, idx1) for a batch."""
+    batched = D1.dim() == 4
+    if D1.dim() not in (3, 4) or D2.dim() != D1.dim() or D1.shape[-1] != D2.shape[-1] or (batched and D1.shape[0] != D2.shape[0]):
+        raise ValueError("D1, D2 must be [H,W,D] or [P,H,W,D] with the same D (and P)")
+    if D1.dtype != D2.dtype:
+        raise TypeError(f"D1 and D2 must have the same dtype, got {D1.dtype} / {D2.dtype}")
+    A = _ffi.check(D1 if batched else D1[None], (torch.float32, torch.float16), "D1")
+    B = _ffi.check(D2 if batched else D2[None], A.dtype, "D2")
+    P, h1, w1, d = A.shape
+    n1, n2 = h1 * w1, B.shape[1] * B.shape[2]
+    dev = A.device
     ys = torch.arange(subsample // 2, h1, subsample, device=dev)
     xs = torch.arange(subsample // 2, w1, subsample, device=dev)
-    cur = (ys[:, None] * w1 + xs[None, :]).reshape(-1)
-    s = cur.numel()
-    if s == 0:
-        e = torch.empty(0, dtype=torch.int64, device=dev)
-        return e, e
-    active = torch.ones(s, dtype=torch.bool, device=dev)
-    got1 = torch.full((max_iter, s), -1, dtype=torch.int64, device=dev)
-    got2 = torch.full((max_iter, s), -1, dtype=torch.int64, device=dev)
+    seeds = (ys[:, None] * w1 + xs[None, :]).reshape(-1).to(torch.int32)
+    s = seeds.numel()
+    e = torch.empty(0, dtype=torch.int64, device=dev)
+    if s == 0 or max_iter <= 0:
+        return (e, e, e) if batched else (e, e)
+    L = _ffi.lib()
+    f16 = 1 if A.dtype == torch.float16 else 0
+    st = _ffi.stream_ptr()
+    pk1 = torch.empty(int(L.m3_frnn_pack_bytes(P, n1, f16)), dtype=torch.uint8, device=dev)
+    pk2 = torch.empty(int(L.m3_frnn_pack_bytes(P, n2, f16)), dtype=torch.uint8, device=dev)
+    _ffi.call("m3_frnn_pack", _ffi.ptr(A), _ffi.ptr(pk1), P, n1, d, f16, st)
+    _ffi.call("m3_frnn_pack", _ffi.ptr(B), _ffi.ptr(pk2), P, n2, d, f16, st)
+    cur = seeds[None].repeat(P, 1).contiguous()
+    active = torch.ones((P, s), dtype=torch.uint8, device=dev)
+    got1 = torch.empty((max_iter, P, s), dtype=torch.int32, device=dev)
+    got2 = torch.empty((max_iter, P, s), dtype=torch.int32, device=dev)
+    xy2 = torch.empty((P, s), dtype=torch.int32, device=dev)
+    keys = torch.zeros((P, s), dtype=torch.int64, device=dev)
     for r in range(max_iter):
-        xy2 = nn_search(f1[:, cur], f2)[0].long()
-        back = nn_search(f2[:, xy2], f1)[0].long()
-        conv = (back == cur) & active
-        got1[r] = torch.where(conv, cur, got1[r])
-        got2[r] = torch.where(conv, xy2, got2[r])
-        active = active & ~conv
-        cur = torch.where(active, back, cur)
-    keep = got1.reshape(-1) >= 0
-    pairs = torch.unique(torch.stack([got1.reshape(-1)[keep], got2.reshape(-1)[keep]], 1), dim=0)   # the one host sync
-    return pairs[:, 0], pairs[:, 1]
+        _ffi.call("m3_frnn_round", _ffi.ptr(pk1), _ffi.ptr(pk2), _ffi.ptr(cur), _ffi.ptr(active), _ffi.ptr(got1[r]),
+                  _ffi.ptr(got2[r]), _ffi.ptr(xy2), _ffi.ptr(keys), P, s, n1, n2, f16, st)
+    pid = torch.arange(P, device=dev, dtype=torch.int64)[None, :, None].expand(max_iter, P, s)
+    keep = (got1 >= 0).reshape(-1)
+    trip = torch.stack([pid.reshape(-1)[keep], got1.reshape(-1)[keep].long(), got2.reshape(-1)[keep].long()], 1)
+    trip = torch.unique(trip, dim=0)                                      # the one host synchronisation
+    return (trip[:, 0], trip[:, 1], trip[:, 2]) if batched else (trip[:, 1], trip[:, 2])
 
 
 def fast_reciprocal_nn(D1: torch.Tensor, D2: torch.Tensor, subsample: int = 8, max_iter: int = 10):

@@ -86,3 +86,21 @@ def test_fast_reciprocal_nn_on_a_smooth_scene(dev):
     inside = (uv[:, 0] > 1) & (uv[:, 0] < 94) & (uv[:, 1] > 1) & (uv[:, 1] < 62)
     err = np.hypot(x2 - uv[:, 0], y2 - uv[:, 1])[inside]
     assert np.median(err) < 1.0 and np.percentile(err, 95) < 2.5
+
+
+def test_fast_reciprocal_nn_batched_equals_per_pair(dev):
+    """P pairs in one set of launches (m3_frnn_pack once per map, m3_frnn_round per round) give, pair by pair, exactly
+    the single-pair result - fp32 and fp16 descriptors; pairs of different content, so a mix-up of the pair axis shows."""
+    scs = [synthetic.geometric_pair(64, 96, seed=10 + k, batch=1) for k in range(3)]
+    D1 = torch.from_numpy(np.stack([s["D21"][0] for s in scs])).to(dev)
+    D2 = torch.from_numpy(np.stack([s["D11"][0] for s in scs])).to(dev)
+    for half in (False, True):
+        A, B = (D1.half(), D2.half()) if half else (D1, D2)
+        pid, i1, i2 = matching.fast_reciprocal_nn_device(A, B, subsample=4, max_iter=6)
+        assert pid.dtype == torch.int64 and bool((pid[1:] >= pid[:-1]).all())
+        for k in range(3):
+            s1, s2 = matching.fast_reciprocal_nn_device(A[k], B[k], subsample=4, max_iter=6)
+            m = pid == k
+            assert torch.equal(i1[m], s1) and torch.equal(i2[m], s2) and s1.numel() > 100
+    with pytest.raises(ValueError):
+        matching.fast_reciprocal_nn_device(D1, D2[:2])

@@ -221,39 +221,56 @@ k_gn_reduce(const double *__restrict__ part, double *__restrict__ blocks, const 
 // 7x7 block (a, b) of H (and g_a when b == a) and walks the edges in index order, so every entry is summed in
 // a FIXED order - bitwise reproducible, unlike an atomicAdd scatter whose order changes from run to run (on
 // degenerate geometry that difference alone decided between a finite and an overflowing step).
+// Round 3: one workgroup (one wave) per block ROW a instead of one per 7 x 7 block.  The per-block grid was
+// num_free^2 workgroups that each walked all E edges - O(F^2 E): 65 025 x 1 524 edge visits for BASELINE configs[4]
+// (most of the 6.7 ms the 1 785-unknown step took in the first backend bench of this round).  Here 64 lanes test 64 edges
+// at a time (coalesced loads, one ballot), the few edges that touch keyframe a are then taken in ascending edge order:
+// the diagonal block and g_a accumulate in registers, an off-diagonal block (a, other) is a read-modify-write of the
+// row this workgroup alone owns.  Every entry is still summed in edge order - the same bits as before.  H must be
+// zero on entry (the launcher clears it on the stream).
 __global__ void __launch_bounds__(64)
 k_gn_assemble(const double *__restrict__ blocks, const int32_t *__restrict__ ii, const int32_t *__restrict__ jj,
               const int32_t *__restrict__ local, double *__restrict__ H, double *__restrict__ g,
               const double *__restrict__ done, int K, int dim, int E) {
     if (done && done[0] != 0.0) return;
-    const int a = blockIdx.y, bcol = blockIdx.x, t = threadIdx.x;
+    const int a = blockIdx.x, t = threadIdx.x;
     const int r = t / 7, c = t % 7;
     const int lo = r < c ? r : c, hi = r < c ? c : r;
     const int hidx = lo * 7 - lo * (lo - 1) / 2 + (hi - lo);
     double h = 0.0, gv = 0.0;
-    for (int e = 0; e < E; ++e) {                            // uniform loop: every lane sees the same edges
-        const int ix = ii[e], jx = jj[e];
-        if (ix < 0 || ix >= K || jx < 0 || jx >= K) continue;
-        const int il = local[ix], jl = local[jx];
-        const double *blk = blocks + (size_t)e * kSums;
-        if (blk[35] == 0.0) continue;
-        const bool diag_i = (il == a && bcol == a), diag_j = (jl == a && bcol == a);
-        const bool both = il >= 0 && jl >= 0;
-        const bool off_ij = both && il == a && jl == bcol, off_ji = both && jl == a && il == bcol;
-        if (!(diag_i || diag_j || off_ij || off_ji)) continue;
-        if (t < 49) {
-            const double v = blk[hidx];
-            if (diag_i) h += v;                              // (i,i)
-            if (diag_j) h += v;                              // (j,j)
-            if (off_ij) h -= v;                              // (i,j)
-            if (off_ji) h -= v;                              // (j,i)
-        } else if (t < 56 && bcol == a) {
-            if (diag_i) gv -= blk[28 + (t - 49)];
-            if (diag_j) gv += blk[28 + (t - 49)];
+    for (int e0 = 0; e0 < E; e0 += 64) {
+        const int e = e0 + t;
+        int il = -2, jl = -2;
+        bool touch = false;
+        if (e < E) {
+            const int ix = ii[e], jx = jj[e];
+            if (ix >= 0 && ix < K && jx >= 0 && jx < K && blocks[(size_t)e * kSums + 35] != 0.0) {
+                il = local[ix]; jl = local[jx];
+                touch = (il == a) || (jl == a);
+            }
+        }
+        unsigned long long m = __ballot(touch);
+        while (m) {                                          // ascending edge index: the summation order of every entry
+            const int bit = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int eil = __shfl(il, bit, 64), ejl = __shfl(jl, bit, 64);
+            const double *blk = blocks + (size_t)(e0 + bit) * kSums;
+            const bool diag_i = eil == a, diag_j = ejl == a, both = eil >= 0 && ejl >= 0;
+            if (t < 49) {
+                const double v = blk[hidx];
+                if (diag_i) h += v;                          // (i,i)
+                if (diag_j) h += v;                          // (j,j)
+                if (both && diag_i && ejl != a) H[(size_t)(a * 7 + r) * dim + ejl * 7 + c] -= v;   // (i,j)
+                if (both && diag_j && eil != a) H[(size_t)(a * 7 + r) * dim + eil * 7 + c] -= v;   // (j,i)
+                if (both && diag_i && diag_j) h -= 2.0 * v;  // a self edge (never built by the factor graph): (i,j) + (j,i) on the diagonal
+            } else if (t < 56) {
+                if (diag_i) gv -= blk[28 + (t - 49)];
+                if (diag_j) gv += blk[28 + (t - 49)];
+            }
         }
     }
-    if (t < 49) H[(size_t)(a * 7 + r) * dim + bcol * 7 + c] = h;
-    else if (t < 56 && bcol == a) g[a * 7 + (t - 49)] = gv;
+    if (t < 49) H[(size_t)(a * 7 + r) * dim + a * 7 + c] = h;
+    else if (t < 56) g[a * 7 + (t - 49)] = gv;
 }
 
 // After the solve (dx in x[0..dim)): |dx|, largest scale step, stop test, retraction T <- exp(dx) T of the free
@@ -456,8 +473,9 @@ int m3_gn_rays_assemble(const double *blocks, const int32_t *ii, const int32_t *
     M3_REQUIRE(blocks && ii && jj && local && H && g && K > 0 && E > 0 && num_free > 0);
     hipStream_t st = (hipStream_t)stream;
     const int dim = 7 * num_free;
-    hipLaunchKernelGGL(k_gn_assemble, dim3(num_free, num_free), dim3(64), 0, st, blocks, ii, jj, local, H, g,
-                       (const double *)nullptr, K, dim, E);       // writes every entry of H and g: no zero fill
+    M3_CHECK_HIP(hipMemsetAsync(H, 0, (size_t)dim * dim * sizeof(double), st), "m3_gn_rays_assemble/memset");
+    hipLaunchKernelGGL(k_gn_assemble, dim3(num_free), dim3(64), 0, st, blocks, ii, jj, local, H, g,
+                       (const double *)nullptr, K, dim, E);
     M3_CHECK_LAUNCH("m3_gn_rays_assemble");
     return M3_OK;
 }
@@ -488,7 +506,8 @@ int m3_gn_rays_solve(float *Twc, const float *Xs, const float *Cs, const int32_t
         int rc = launch_blocks(Twc, Xs, Cs, ii, jj, idx, valid, Q, blocks, ws, done, K, P, E, sigma_ray, C_thresh,
                                Q_thresh, point_mode, cal, st);
         if (rc != M3_OK) return rc;
-        hipLaunchKernelGGL(k_gn_assemble, dim3(num_free, num_free), dim3(64), 0, st, (const double *)blocks, ii, jj,
+        M3_CHECK_HIP(hipMemsetAsync(H, 0, (size_t)dim * dim * sizeof(double), st), "m3_gn_rays_solve/memset");
+        hipLaunchKernelGGL(k_gn_assemble, dim3(num_free), dim3(64), 0, st, (const double *)blocks, ii, jj,
                            local, H, g, done, K, dim, E);
         M3_CHECK_LAUNCH("m3_gn_rays_solve/iter");
         rc = launch_step(Hbuf, Twc, local, info, K, dim, delta_thresh, 1, st);
@@ -506,7 +525,8 @@ int m3_gn_rays_step(float *Twc, const double *blocks, const int32_t *ii, const i
     hipStream_t st = (hipStream_t)stream;
     const int dim = 7 * num_free;
     double *H = Hbuf, *g = Hbuf + (size_t)dim * dim;
-    hipLaunchKernelGGL(k_gn_assemble, dim3(num_free, num_free), dim3(64), 0, st, blocks, ii, jj, local, H, g,
+    M3_CHECK_HIP(hipMemsetAsync(H, 0, (size_t)dim * dim * sizeof(double), st), "m3_gn_rays_step/memset");
+    hipLaunchKernelGGL(k_gn_assemble, dim3(num_free), dim3(64), 0, st, blocks, ii, jj, local, H, g,
                        (const double *)(info + 2), K, dim, E);
     M3_CHECK_LAUNCH("m3_gn_rays_step/assemble");
     return launch_step(Hbuf, Twc, local, info, K, dim, delta_thresh, 1, st);

@@ -1,0 +1,742 @@
+// EXPERIMENT (round 3, not built into the library): k_attn with a software-pipelined MODE 2 loop - the S^T MFMAs of key
+// tile t + 1 issued in the same straight-line region as the exp2 / packs / PV MFMAs of tile t (K side one tile ahead, two
+// score register sets, iterations templated on the stage parity, key tail peeled into the last iteration).  Correct (all
+// attention tests pass, including the overflow -> recomputation ones), but SLOWER than the 4-waves-per-SIMD loop it was
+// meant to replace.  16 x 16 x 1024^2, same boxes (tools/bench_attn.py):
+//   round-2 loop, 4 waves / SIMD, 128 registers ...................................  89.0 us  (772 TFLOP/s)
+//   pipelined, 168 registers (3 waves / SIMD, 10 spills) ..........................  95.1 us
+//   pipelined, 230 registers (2 waves / SIMD), scheduler interleaves MFMA / v_exp .. 101.9 us
+//   + three K / V stages, loads two tiles ahead (48 KiB LDS) ....................... 112.9 us
+//   + incremental staging pointers, -m_ref as the C operand, compile-time stages
+//     (VALU instructions per wave and tile 176 -> ~100) ........................... 105.4 us
+// PMC (profiles/r03_attention_pmc.md): with two waves per SIMD nothing covers the LDS round trip in front of each MFMA
+// group (15 s_waitcnt lgkmcnt per iteration); the register file has no room left to prefetch the fragments (235 of 256).
+// The in-wave interleave does what it should in the ISA (1 MFMA : 2-3 v_exp_f32) - the loss is the occupancy it costs.
+// Fused (flash-style) multi-head attention for gfx950, head dim 64, bf16 in / bf16 out, fp32
+// softmax and accumulation.  Serves the ViT encoder self-attention, the decoder self-attention
+// and the decoder cross-attention (keys/values of the OTHER view via kv_batch_shift).
+//
+// Workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 query rows
+// (two 16-row tiles) and walks the keys in tiles of 64.  Everything is computed TRANSPOSED so
+// that a query row lives on one lane (q = lane & 15) for the whole kernel:
+//     S^T = K . Q^T      (MFMA A = K fragment, B = Q fragment)  -> lane holds 16 keys of its q
+//     O^T = V^T . P^T    (MFMA A = V^T fragment, B = P fragment)  -> lane holds 16 d of its q
+// so the row max / row sum need only in-lane work plus two xor-shuffles, the rescale factor is
+// lane-local, and P goes from the S accumulators to the next MFMA's B operand with a bf16 pack
+// and no LDS round trip.  K and V tiles are staged global -> LDS by global_load_lds (double
+// buffered); K fragments are ds_read_b128 from an XOR-swizzled image, V^T fragments come from
+// the row-major V image through ds_read_b64_tr_b16 (hardware transpose), conflict-free with a
+// chunk-pair swizzle.
+#include "gemm_common.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+using m3gemm::bf16x8;
+using m3gemm::f32x4;
+using m3gemm::bf16_t;
+using m3gemm::glds16;
+using m3gemm::pack16;
+using m3gemm::mfma16;
+using m3gemm::DT_BF16;
+using m3gemm::DT_F16;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+
+constexpr int kThreads = 256;
+constexpr int QROWS = 128;     // query rows per workgroup
+constexpr int KT = 64;         // keys per tile
+constexpr int HD = 64;         // head dim
+constexpr int kTileBytes = KT * HD * 2;          // 8 KiB
+constexpr int kLds = 4 * kTileBytes;             // K,V x 2 stages = 32 KiB
+
+using m3gemm::pack_bf16;
+
+struct AttnArgs {
+    const bf16_t *Q, *K, *V;
+    bf16_t *O;
+    int q_row_stride, kv_row_stride, o_row_stride;       // elements between consecutive tokens
+    long long q_batch_stride, kv_batch_stride, o_batch_stride;   // elements between batch items
+    int Tq, Tk, heads, nbatch, kv_batch_shift;
+    float scale_log2e;                                    // softmax scale * log2(e)
+};
+
+// QT = 16-row query tiles per wave: 2 -> 128 query rows per workgroup (throughput regime), 1 -> 64 rows
+// per workgroup (twice the workgroups: used when the 128-row grid would leave CUs with < 2 workgroups,
+// e.g. one pair = 2 images x 16 heads x 8 blocks = 256 workgroups on 256 CUs).
+// Any Tq, Tk >= 1: query rows past Tq are computed on a clamped row and not stored; keys past Tk (last
+// tile only) are staged from the clamped last row and their scores set to -inf before the softmax.
+// MODE 0: classic online softmax; scale * log2(e) is applied per score.
+// MODE 1, 2 ("prescaled"): q already carries softmax scale * log2(e) (folded in by the projection GEMM's RoPE
+// epilogue), so a score is an exp2 argument as it leaves the matrix core, and the reference maximum m_ref of a query
+// enters the S^T MFMA as its accumulator INITIALISER (C = -m_ref, lane-local): the MFMA returns s - m_ref.
+//   MODE 1 (safe, any magnitude): the tile maximum is still computed; m_ref is raised (and o, l rescaled) only when it
+//     exceeds the reference by more than kDefer (wave-uniform, rare after the first tiles).  Row sums as packed adds.
+//   MODE 2 (fast, bf16 P operand): the kernel is bound by VALU ISSUE (PMC: VALU + MFMA issue = 96 % of the SIMD
+//     cycles; per tile and wave 64 v_exp_f32 = 512 cycles, as many as its 32 MFMAs), so everything but the exp2 and
+//     the 16-bit packing leaves the VALU: m_ref is the TRUE maximum of the first tile and never recomputed; later
+//     tiles only need exp2(s - m_ref) to stay finite, and bf16 has the fp32 exponent range.  Softmax is invariant to
+//     the reference, so a lagging one costs no accuracy - numerator and denominator carry the same factor.  The row
+//     sums are one more MFMA per (query tile, k-step) against an all-ones A fragment - l accumulates in a matrix-core
+//     register across tiles, already summed over the lane groups, and sums exactly the rounded P that multiplies V.
+//     A per-lane test before the next tile (l > 2^60 -> scale o, l by 2^-64 and move m_ref) keeps the range.  Overflow
+//     (a score far above the reference - not seen on any network input, but possible in principle) makes the WHOLE
+//     workgroup recompute its block with the MODE 1 loop.  The test is sticky and conservative: l > 2^100 at a range
+//     check or at the end (then o = sum p v may already be inf although l = sum p is finite - l alone would come back
+//     into range and hide it: round-2 advisor finding), a non-finite l, or a non-finite o at the end.
+#define M3_ATTN_EXP 0
+constexpr float kDefer = 8.0f;
+template <int QT, int DT, int MODE>
+__global__ void __launch_bounds__(kThreads, MODE == 2 ? (QT == 2 ? 2 : 3) : ((MODE == 1 && QT == 2) ? 3 : 4))
+k_attn(const AttnArgs a) {
+    constexpr int QR = QT * 64;                                 // query rows per workgroup
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kLds];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 15, g = lane >> 4;
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so give every XCD one contiguous
+    // range of ids -- the Tq/128 query blocks of a (batch, head) then share its K/V through ONE L2
+    // instead of pulling them into eight (measured 5x the compulsory HBM reads before this remap).
+    const int nq = (a.Tq + QR - 1) / QR, nwg = gridDim.x;
+    const int per = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7;
+    const int id = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + (blockIdx.x >> 3);
+    const int qblk = id % nq, head = (id / nq) % a.heads, b = id / (nq * a.heads);
+    const int kvb = (b + a.kv_batch_shift) % a.nbatch;
+    const bf16_t *Qp = a.Q + (size_t)b * a.q_batch_stride + head * HD;
+    const bf16_t *Kp = a.K + (size_t)kvb * a.kv_batch_stride + head * HD;
+    const bf16_t *Vp = a.V + (size_t)kvb * a.kv_batch_stride + head * HD;
+
+    // Q fragments (B operand): lane -> q row (lane&15), d = 32*ks + 8*g + j
+    bf16x8 qf[QT][2];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        int row = qblk * QR + wave * (16 * QT) + qt * 16 + lq;
+        row = row < a.Tq ? row : a.Tq - 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[qt][ks] = *reinterpret_cast<const bf16x8 *>(Qp + (size_t)row * a.q_row_stride + ks * 32 + g * 8);
+    }
+
+    // staging: thread t moves 16-byte slot t (row = t/8, chunk' = t%8) of each 4 KiB half tile
+    const int srow = tid >> 3, sc = tid & 7;
+    const int kch = sc ^ ((srow >> 1) & 7);                 // K image: chunk ^ ((row>>1)&7)
+    const int vch = sc ^ (((srow >> 1) & 3) << 1);          // V image: chunk-pair ^ ((row>>1)&3)
+    auto stage = [&](int t, int buf) {
+        unsigned char *kb = lds + buf * 2 * kTileBytes, *vb = kb + kTileBytes;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int kr = t * KT + i * 32 + srow;
+            kr = kr < a.Tk ? kr : a.Tk - 1;
+            const size_t row = (size_t)kr * a.kv_row_stride;
+            glds16(Kp + row + kch * 8, kb + i * 4096 + wave * 1024);
+            glds16(Vp + row + vch * 8, vb + i * 4096 + wave * 1024);
+        }
+    };
+
+    f32x4 o[QT][4];
+    float m_run[QT], l_run[QT];
+    bool ovf = false;                                             // MODE 2: sticky "a row sum left the safe range"
+    const int nt = (a.Tk + KT - 1) / KT;
+    const int tq = lq >> 2, tp = lq & 3;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+    auto run = [&](auto mode_tag) {
+        constexpr int MD = decltype(mode_tag)::value;
+        f32x4 l_acc[QT];                                          // MODE 2: row sums, accumulated by the matrix core
+        bf16x8 ones;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ones[j] = (short)(DT == DT_BF16 ? 0x3F80 : 0x3C00);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            m_run[qt] = -INFINITY; l_run[qt] = 0.f;
+            l_acc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        stage(0, 0);
+        for (int t = 0; t < nt; ++t) {
+            const int buf = t & 1;
+            // ONE barrier per tile: it publishes tile t (every wave waited for its own share) and, because a wave
+            // reaches it only after its last fragment read of tile t-1, it also frees that tile's stage - which is
+            // where tile t+1 is staged right behind it, with the whole of tile t's arithmetic to land.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            m3gemm::lds_barrier();
+            if (t + 1 < nt) stage(t + 1, buf ^ 1);
+            const unsigned char *Ks = lds + buf * 2 * kTileBytes, *Vs = Ks + kTileBytes;
+
+            if constexpr (MD == 2) {
+                // range keeper for the row sums of the tiles so far (tested here, a tile late, so that the test does
+                // not wait for the matrix core); per query, identical in its 4 lanes
+                bool big = false;
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) big |= l_acc[qt][0] > 0x1p60f;
+                if (t > 0 && __any(big)) {
+                    asm volatile("; rare path" ::: "memory");
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) {
+                        const bool hit = l_acc[qt][0] > 0x1p60f;
+                        ovf |= !(l_acc[qt][0] <= 0x1p100f);          // sticky: o may have overflowed where l has not
+                        const float alpha = hit ? 0x1p-64f : 1.0f;
+                        m_run[qt] += hit ? 64.0f : 0.0f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) l_acc[qt][r] *= alpha;
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
+                    }
+                }
+            }
+
+            // ---- S^T = K . Q^T : s[qt][kt] holds keys kt*16 + g*4 + r of query lq ------------------
+            f32x4 s[QT][4];
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const float c0 = (MD >= 1 && t > 0) ? -m_run[qt] : 0.f;          // prescaled: m_run holds m_ref (log2 units)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) s[qt][kt] = f32x4{c0, c0, c0, c0};
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const int r = kt * 16 + lq;
+                    const int c = (ks * 4 + g) ^ ((r >> 1) & 7);
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + r * 128 + c * 16);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        s[qt][kt] = mfma16<DT>(kf, qf[qt][ks], s[qt][kt]);
+                }
+
+            if (t == nt - 1 && (a.Tk & (KT - 1))) {           // key tail: wave-uniform branch, last tile only
+                const int kbase = t * KT + g * 4;
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (kbase + kt * 16 + r >= a.Tk) s[qt][kt][r] = -INFINITY;
+            }
+
+            // ---- online softmax (row = lane-local query) -------------------------------------------
+            bf16x8 pf[QT][2];
+            auto tile_max = [&](int qt) {
+                float mx = fmaxf(__builtin_fmaxf(s[qt][0][0], s[qt][0][1]), s[qt][0][2]);
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = (kt == 0 ? 3 : 0); r < 4; r += 2)
+                        mx = (r + 1 < 4) ? fmaxf(__builtin_fmaxf(mx, s[qt][kt][r]), s[qt][kt][r + 1]) : fmaxf(mx, s[qt][kt][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                return fmaxf(mx, __shfl_xor(mx, 32, 64));
+            };
+            auto pack_p = [&](int qt) {
+                // P fragment for k-step kk: element j<4 -> key (2kk)*16 + g*4 + j, j>=4 -> key (2kk+1)*16 + g*4 + j-4
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    union { unsigned u[4]; bf16x8 v; } pk;
+                    pk.u[0] = pack16<DT>(s[qt][2 * kk][0], s[qt][2 * kk][1]);
+                    pk.u[1] = pack16<DT>(s[qt][2 * kk][2], s[qt][2 * kk][3]);
+                    pk.u[2] = pack16<DT>(s[qt][2 * kk + 1][0], s[qt][2 * kk + 1][1]);
+                    pk.u[3] = pack16<DT>(s[qt][2 * kk + 1][2], s[qt][2 * kk + 1][3]);
+                    pf[qt][kk] = pk.v;
+                }
+            };
+            if constexpr (MD == 2) {
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    if (t == 0) {                                            // the first tile's true maximum is the reference
+                        const float mx = tile_max(qt);
+                        m_run[qt] = mx;
+#pragma unroll
+                        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) s[qt][kt][r] -= mx;
+                    }
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[qt][kt][r] = __builtin_amdgcn_exp2f(s[qt][kt][r]);
+#if M3_ATTN_EXP == 1
+                    for (int kt = 0; kt < 4; ++kt) for (int r = 0; r < 4; ++r) l_run[qt] += s[qt][kt][r];
+#endif
+                    pack_p(qt);
+                }
+            } else if constexpr (MD == 1) {
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    const float mx = tile_max(qt);
+                    if (t == 0) {                                            // first tile: the true maximum becomes the reference
+                        m_run[qt] = mx;
+#pragma unroll
+                        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) s[qt][kt][r] -= mx;
+                    } else if (__any(mx > kDefer)) {                         // some query outgrew its reference: exact update
+                        asm volatile("; rare path: keep it a branch (if-converted, its 32 subtracts + selects ran on every tile)" ::: "memory");
+                        const float delta = fmaxf(mx, 0.f);
+                        const float alpha = __builtin_amdgcn_exp2f(-delta);
+                        m_run[qt] += delta;
+                        l_run[qt] *= alpha;
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
+#pragma unroll
+                        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) s[qt][kt][r] -= delta;
+                    }
+                    f32x2 rs2 = {0.f, 0.f};
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[qt][kt][r] = __builtin_amdgcn_exp2f(s[qt][kt][r]);
+                        rs2 += f32x2{s[qt][kt][0], s[qt][kt][1]};
+                        rs2 += f32x2{s[qt][kt][2], s[qt][kt][3]};
+                    }
+                    l_run[qt] += rs2.x + rs2.y;
+                    pack_p(qt);
+                }
+            } else {
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    float mx = s[qt][0][0];
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qt][kt][r]);
+                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    const float m_new = fmaxf(m_run[qt], mx);
+                    const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * a.scale_log2e);
+                    const float mb = m_new * a.scale_log2e;
+                    m_run[qt] = m_new;
+                    float rs = 0.f;
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float p = __builtin_amdgcn_exp2f(s[qt][kt][r] * a.scale_log2e - mb);
+                            s[qt][kt][r] = p;
+                            rs += p;
+                        }
+                    l_run[qt] = l_run[qt] * alpha + rs;
+                    if (!__all(alpha == 1.0f)) {       // exact skip: no row of this wave raised its running max
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
+                    }
+                    pack_p(qt);
+                }
+            }
+
+            // ---- O^T += V^T . P^T : A fragment = V^T[d = dt*16 + lq][same key permutation] ------------
+            // transposed read: lane (4q+p) of a 16-lane group addresses row (key0 + q), cols d0 + 4p..4p+3
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    union { bf16x4 h[2]; bf16x8 v; } vf;
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int row = (2 * kk + half) * 16 + g * 4 + tq;
+                        const int ch = (dt * 2 + (tp >> 1)) ^ (((row >> 1) & 3) << 1);
+                        const unsigned char *p = Vs + row * 128 + ch * 16 + (tp & 1) * 8;
+                        vf.h[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) bf16x4 *)p);
+                    }
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        o[qt][dt] = mfma16<DT>(vf.v, pf[qt][kk], o[qt][dt]);
+                }
+                if constexpr (MD == 2) {
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) l_acc[qt] = mfma16<DT>(ones, pf[qt][kk], l_acc[qt]);
+                }
+            }
+        }
+        m3gemm::lds_barrier();                      // the stages are reused right after the loop (flag word / recomputation)
+        if constexpr (MD == 2 && M3_ATTN_EXP != 1) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) l_run[qt] = l_acc[qt][0];       // complete row sum, no lane reduction left
+        } else {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                float l = l_run[qt];
+                l += __shfl_xor(l, 16, 64);
+                l_run[qt] = l + __shfl_xor(l, 32, 64);
+            }
+        }
+    };
+
+    // ---- MODE 2, software-pipelined over key tiles (round 3) --------------------------------------------------------
+    // Inside one wave a tile is a chain  S^T MFMAs -> exp2 -> pack -> PV MFMAs : while a wave exponentiates, its MFMAs
+    // are over, and four waves per SIMD did not fill the gaps (PMC: matrix pipe 36 % busy, VALU 44 %, 45 % of the wave
+    // cycles issue-stalled on dependencies).  Here the K side runs ONE TILE AHEAD: iteration t issues the 16 S^T MFMAs of
+    // tile t+1 (into a second score register set) in the same straight-line region as the 32 exp2 + 16 packs of tile t,
+    // which then feed the 20 PV / row-sum MFMAs of tile t - the matrix core always has independent work next to the
+    // transcendentals (one v_exp_f32 hides under one 16x16x32 MFMA: MI355X_MICROARCH.md, issue costs).  LDS is unchanged:
+    // two K and two V stages, K(t+2) and V(t+1) are requested at the top of iteration t, one barrier per iteration.
+    // The reference maximum of a query is fixed by tile 0 as before; when the range keeper moves it (rows whose sum
+    // passed 2^60), the PENDING scores of tile t - formed against the old reference - move with it, exactly once.
+    auto run_pipe = [&]() {
+        f32x4 l_acc[QT];
+        bf16x8 ones;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ones[j] = (short)(DT == DT_BF16 ? 0x3F80 : 0x3C00);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            m_run[qt] = 0.f; l_run[qt] = 0.f;
+            l_acc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // Staging with INCREMENTAL per-lane source pointers (one 64-bit add per request; the round-2 form recomputed
+        // row -> clamp -> 64-bit multiply-add per request: ~20 of the ~120 non-MFMA instructions of an iteration - and
+        // every one of them takes an issue slot the matrix core's partner wave could use).  Only a tile that reaches
+        // past Tk needs the clamp: it is staged through the slow path.
+        const bf16_t *kp[2], *vp[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            kp[i] = Kp + (size_t)(i * 32 + srow) * a.kv_row_stride + kch * 8;
+            vp[i] = Vp + (size_t)(i * 32 + srow) * a.kv_row_stride + vch * 8;
+        }
+        const size_t tile_step = (size_t)KT * a.kv_row_stride;
+        auto stage_k = [&](int t, int buf) {                        // tiles are requested in ascending order, each exactly once
+            unsigned char *kb = lds + buf * 2 * kTileBytes;
+            if ((t + 1) * KT <= a.Tk) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) glds16(kp[i], kb + i * 4096 + wave * 1024);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    int kr = t * KT + i * 32 + srow;
+                    kr = kr < a.Tk ? kr : a.Tk - 1;
+                    glds16(Kp + (size_t)kr * a.kv_row_stride + kch * 8, kb + i * 4096 + wave * 1024);
+                }
+            }
+            kp[0] += tile_step; kp[1] += tile_step;
+        };
+        auto stage_v = [&](int t, int buf) {
+            unsigned char *vb = lds + buf * 2 * kTileBytes + kTileBytes;
+            if ((t + 1) * KT <= a.Tk) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) glds16(vp[i], vb + i * 4096 + wave * 1024);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    int kr = t * KT + i * 32 + srow;
+                    kr = kr < a.Tk ? kr : a.Tk - 1;
+                    glds16(Vp + (size_t)kr * a.kv_row_stride + vch * 8, vb + i * 4096 + wave * 1024);
+                }
+            }
+            vp[0] += tile_step; vp[1] += tile_step;
+        };
+        // S^T of tile t into s: accumulators start at -m_ref (0 for tile 0, whose maximum BECOMES the reference)
+        // (the stage is a COMPILE-TIME constant - iterations alternate between two instantiations - so every LDS address
+        // below is a loop-invariant per-lane offset plus an immediate; the -m_ref splat is the C operand of the first
+        // MFMA of each accumulator, not 32 v_mov)
+        auto qk = [&](f32x4 (&s)[QT][4], auto stage_tag) {
+            const unsigned char *Ks = lds + decltype(stage_tag)::value * 2 * kTileBytes;
+            f32x4 cinit[QT];
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) { const float c0 = -m_run[qt]; cinit[qt] = f32x4{c0, c0, c0, c0}; }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const int r = kt * 16 + lq;
+                    const int c = (ks * 4 + g) ^ ((r >> 1) & 7);
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + r * 128 + c * 16);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) s[qt][kt] = mfma16<DT>(kf, qf[qt][ks], ks == 0 ? cinit[qt] : s[qt][kt]);
+                }
+        };
+        // key tail of the LAST tile (Tk not a multiple of 64): applied to the pending scores at the top of the last
+        // iteration, so that no branch splits the straight-line region of the steady-state iterations
+        auto mask_tail = [&](f32x4 (&s)[QT][4], int t) {
+            const int kbase = t * KT + g * 4;
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kbase + kt * 16 + r >= a.Tk) s[qt][kt][r] = -INFINITY;
+        };
+        // exp2 + pack of half a tile (key tiles 2 kk, 2 kk + 1), then its PV and row-sum MFMAs
+        auto pv_half = [&](f32x4 (&s)[QT][4], int kk, const unsigned char *Vs) {
+            bf16x8 pf[QT];
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[qt][2 * kk + h][r] = __builtin_amdgcn_exp2f(s[qt][2 * kk + h][r]);
+                union { unsigned u[4]; bf16x8 v; } pk;
+                pk.u[0] = pack16<DT>(s[qt][2 * kk][0], s[qt][2 * kk][1]);
+                pk.u[1] = pack16<DT>(s[qt][2 * kk][2], s[qt][2 * kk][3]);
+                pk.u[2] = pack16<DT>(s[qt][2 * kk + 1][0], s[qt][2 * kk + 1][1]);
+                pk.u[3] = pack16<DT>(s[qt][2 * kk + 1][2], s[qt][2 * kk + 1][3]);
+                pf[qt] = pk.v;
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                union { bf16x4 h[2]; bf16x8 v; } vf;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int row = (2 * kk + half) * 16 + g * 4 + tq;
+                    const int ch = (dt * 2 + (tp >> 1)) ^ (((row >> 1) & 3) << 1);
+                    const unsigned char *p = Vs + row * 128 + ch * 16 + (tp & 1) * 8;
+                    vf.h[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4 *)p);
+                }
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) o[qt][dt] = mfma16<DT>(vf.v, pf[qt], o[qt][dt]);
+            }
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) l_acc[qt] = mfma16<DT>(ones, pf[qt], l_acc[qt]);
+        };
+        auto tile_max = [&](const f32x4 (&sq)[4]) {
+            float mx = fmaxf(__builtin_fmaxf(sq[0][0], sq[0][1]), sq[0][2]);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = (kt == 0 ? 3 : 0); r < 4; r += 2)
+                    mx = (r + 1 < 4) ? fmaxf(__builtin_fmaxf(mx, sq[kt][r]), sq[kt][r + 1]) : fmaxf(mx, sq[kt][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            return fmaxf(mx, __shfl_xor(mx, 32, 64));
+        };
+        // one iteration: `cur` holds the scores of tile t (already relative to the reference), `nxt` receives tile t + 1
+        // (LAST: there is no tile t + 1).  PAR = t & 1 at compile time: V(t) lives in stage PAR, K(t+1) in stage 1 - PAR.
+        auto iter = [&](f32x4 (&cur)[QT][4], f32x4 (&nxt)[QT][4], int t, auto par_tag, auto last_tag) {
+            constexpr int PAR = decltype(par_tag)::value;
+            constexpr bool LAST = decltype(last_tag)::value;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's shares of K(t+1) and V(t) have landed
+            m3gemm::lds_barrier();                                          // ... everyone's; and K(t), V(t-1) are no longer read
+            if (t + 2 < nt) stage_k(t + 2, PAR);
+            if (t + 1 < nt) stage_v(t + 1, 1 - PAR);
+            const unsigned char *Vs = lds + PAR * 2 * kTileBytes + kTileBytes;
+            bool big = false;                                               // range keeper for the sums of the tiles so far
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) big |= l_acc[qt][0] > 0x1p60f;
+            if (t > 0 && __any(big)) {
+                asm volatile("; rare path" ::: "memory");
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    const bool hit = l_acc[qt][0] > 0x1p60f;
+                    ovf |= !(l_acc[qt][0] <= 0x1p100f);
+                    const float alpha = hit ? 0x1p-64f : 1.0f, shift = hit ? 64.0f : 0.0f;
+                    m_run[qt] += shift;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) l_acc[qt][r] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)                          // the pending tile was formed against the old reference
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) cur[qt][kt][r] -= shift;
+                }
+            }
+            if constexpr (LAST) {
+                if (a.Tk & (KT - 1)) mask_tail(cur, t);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- one straight-line region: the S^T MFMAs of tile t + 1 are independent of the exp2 / packs / PV MFMAs of
+            // tile t, the scheduler is free to interleave them
+            if constexpr (!LAST) qk(nxt, std::integral_constant<int, 1 - PAR>{});
+            pv_half(cur, 0, Vs);
+            pv_half(cur, 1, Vs);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        f32x4 sa[QT][4], sb[QT][4];
+        stage_k(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        m3gemm::lds_barrier();
+        if (nt > 1) stage_k(1, 1);
+        stage_v(0, 0);
+        qk(sa, P0{});                                                       // m_run = 0: raw scores of tile 0
+        if (nt == 1 && (a.Tk & (KT - 1))) mask_tail(sa, 0);                 // (then masked again by the last iteration: idempotent)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {                                   // their maximum is the reference from here on
+            const float mx = tile_max(sa[qt]);
+            m_run[qt] = mx;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sa[qt][kt][r] -= mx;
+        }
+        int t = 0;
+        for (; t + 2 < nt; t += 2) {                                        // two steady-state iterations per trip: the score register
+            iter(sa, sb, t, P0{}, std::false_type{});                       // sets and the LDS stages swap roles without moves
+            iter(sb, sa, t + 1, P1{}, std::false_type{});
+        }
+        if (t + 1 < nt) {
+            iter(sa, sb, t, P0{}, std::false_type{});
+            iter(sb, sa, t + 1, P1{}, std::true_type{});
+        } else {
+            iter(sa, sb, t, P0{}, std::true_type{});
+        }
+        m3gemm::lds_barrier();                      // the stages are reused right after the loop (flag word / recomputation)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) l_run[qt] = l_acc[qt][0];           // complete row sum, no lane reduction left
+    };
+
+    if constexpr (MODE == 2) {
+        run_pipe();
+        bool bad = ovf;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            bad |= !(l_run[qt] > 0.f && l_run[qt] <= 0x1p100f);
+            float osum = 0.f;                                     // inf / NaN anywhere in the row's outputs survives the sum
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) osum += (o[qt][dt][0] + o[qt][dt][1]) + (o[qt][dt][2] + o[qt][dt][3]);
+            bad |= !(fabsf(osum) < INFINITY);
+        }
+#if M3_ATTN_EXP == 3
+        bad = true;
+#endif
+        // workgroup-wide OR through a word of the (now idle) tile buffers; every wave passed the loop's last barrier
+        int *flag = reinterpret_cast<int *>(lds);
+        if (tid == 0) *flag = 0;
+        m3gemm::lds_barrier();
+        if (__any(bad) && lane == 0) atomicOr(flag, 1);
+        m3gemm::lds_barrier();
+        const int redo = *reinterpret_cast<volatile int *>(flag);
+        m3gemm::lds_barrier();                                  // everyone has read the flag before tile 0 is staged over it
+        if (redo) run(std::integral_constant<int, 1>{});        // exp2 overflowed somewhere: exact recomputation
+    } else {
+        run(std::integral_constant<int, MODE>{});
+    }
+
+    // ---- finalize: O[q][dt*16 + g*4 + r] = o / l ---------------------------------------------------
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const float inv = 1.0f / l_run[qt];
+        const int row = qblk * QR + wave * (16 * QT) + qt * 16 + lq;
+        if (row >= a.Tq) continue;
+        bf16_t *op = a.O + (size_t)b * a.o_batch_stride + (size_t)row * a.o_row_stride + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            uint2 w;
+            w.x = pack16<DT>(o[qt][dt][0] * inv, o[qt][dt][1] * inv);
+            w.y = pack16<DT>(o[qt][dt][2] * inv, o[qt][dt][3] * inv);
+            *reinterpret_cast<uint2 *>(op + dt * 16 + g * 4) = w;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- RoPE-2D (CroCo "RoPE100")
+// In place on a [tokens, row_stride] bf16 buffer: for every head, the first 32 dims rotate with
+// the token's y position, the last 32 with x; within a 32-block element i pairs with i+16:
+//   out[i]    = x[i] cos(p f_i) - x[i+16] sin(p f_i)
+//   out[i+16] = x[i+16] cos(p f_i) + x[i] sin(p f_i),   f_i = base^(-i/16), i = 0..15
+// cs: fp32 table [max_pos][16][2] = (cos, sin).  One thread handles one (token, head, 32-block).
+template <int DT>
+__global__ void __launch_bounds__(kThreads)
+k_rope2d(bf16_t *__restrict__ X, const int *__restrict__ pos_yx, const float *__restrict__ cs, int row_stride,
+         int tokens, int heads, int tokens_per_image) {
+    const int idx = blockIdx.x * kThreads + threadIdx.x;
+    const int total = tokens * heads * 2;
+    if (idx >= total) return;
+    const int blk = idx & 1, head = (idx >> 1) % heads, tok = (idx >> 1) / heads;
+    const int pos = pos_yx[(tok % tokens_per_image) * 2 + blk];
+    bf16_t *p = X + (size_t)tok * row_stride + head * HD + blk * 32;
+    union { uint4 q[4]; bf16_t h[32]; } v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v.q[i] = reinterpret_cast<const uint4 *>(p)[i];
+    const float *t = cs + (size_t)pos * 32;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float c = t[2 * i], sn = t[2 * i + 1];
+        const float x1 = m3gemm::lo16<DT>(v.h[i]), x2 = m3gemm::lo16<DT>(v.h[i + 16]);
+        const unsigned pk = pack16<DT>(x1 * c - x2 * sn, x2 * c + x1 * sn);
+        v.h[i] = (bf16_t)(pk & 0xffff);
+        v.h[i + 16] = (bf16_t)(pk >> 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) reinterpret_cast<uint4 *>(p)[i] = v.q[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+static int attention_launch(const void *Q, const void *K, const void *V, void *O, int q_row_stride, int kv_row_stride,
+                            int o_row_stride, int64_t q_batch_stride, int64_t kv_batch_stride, int64_t o_batch_stride,
+                            int nbatch, int heads, int Tq, int Tk, int kv_batch_shift, float scale, int dtype, bool pre,
+                            void *stream) {
+    M3_REQUIRE(Q && K && V && O && nbatch > 0 && heads > 0 && Tq > 0 && Tk > 0);
+    M3_REQUIRE((dtype == DT_BF16 || dtype == DT_F16) && ((int64_t)Tq / 64 + 1) * heads * nbatch < (1ll << 31));
+    M3_REQUIRE(q_row_stride % 8 == 0 && kv_row_stride % 8 == 0 && o_row_stride % 4 == 0);
+    M3_REQUIRE(kv_batch_shift >= 0);
+    AttnArgs a;
+    a.Q = (const bf16_t *)Q; a.K = (const bf16_t *)K; a.V = (const bf16_t *)V; a.O = (bf16_t *)O;
+    a.q_row_stride = q_row_stride; a.kv_row_stride = kv_row_stride; a.o_row_stride = o_row_stride;
+    a.q_batch_stride = q_batch_stride; a.kv_batch_stride = kv_batch_stride; a.o_batch_stride = o_batch_stride;
+    a.Tq = Tq; a.Tk = Tk; a.heads = heads; a.nbatch = nbatch; a.kv_batch_shift = kv_batch_shift;
+    a.scale_log2e = scale * 1.4426950408889634f;
+    const int64_t wg128 = (int64_t)m3_cdiv(Tq, QROWS) * heads * nbatch;
+    const int64_t wg64 = (int64_t)m3_cdiv(Tq, 64) * heads * nbatch;
+    hipStream_t st = (hipStream_t)stream;
+    // M3_ATTN_SAFE=1: prescaled bf16 launches take the max-tracking loop (MODE 1) instead of the fast one (experiments)
+    static const bool safe_bf16 = [] { const char *e = getenv("M3_ATTN_SAFE"); return e && atoi(e) != 0; }();
+#define M3_ATTN(QTV, GRID)                                                                                  \
+    do {                                                                                                    \
+        if (dtype == DT_F16) { if (pre) hipLaunchKernelGGL((k_attn<QTV, DT_F16, 1>), dim3((unsigned)(GRID)), dim3(kThreads), 0, st, a); \
+                               else hipLaunchKernelGGL((k_attn<QTV, DT_F16, 0>), dim3((unsigned)(GRID)), dim3(kThreads), 0, st, a); } \
+        else { if (pre) { if (safe_bf16) hipLaunchKernelGGL((k_attn<QTV, DT_BF16, 1>), dim3((unsigned)(GRID)), dim3(kThreads), 0, st, a); \
+                          else hipLaunchKernelGGL((k_attn<QTV, DT_BF16, 2>), dim3((unsigned)(GRID)), dim3(kThreads), 0, st, a); }          \
+               else hipLaunchKernelGGL((k_attn<QTV, DT_BF16, 0>), dim3((unsigned)(GRID)), dim3(kThreads), 0, st, a); }                    \
+    } while (0)
+    if (wg128 >= 512) M3_ATTN(2, wg128); else M3_ATTN(1, wg64);
+#undef M3_ATTN
+    M3_CHECK_LAUNCH("m3_attention");
+    return M3_OK;
+}
+
+int m3_attention_dt(const void *Q, const void *K, const void *V, void *O, int q_row_stride, int kv_row_stride,
+                    int o_row_stride, int64_t q_batch_stride, int64_t kv_batch_stride, int64_t o_batch_stride,
+                    int nbatch, int heads, int Tq, int Tk, int kv_batch_shift, float scale, int dtype, void *stream) {
+    return attention_launch(Q, K, V, O, q_row_stride, kv_row_stride, o_row_stride, q_batch_stride, kv_batch_stride,
+                            o_batch_stride, nbatch, heads, Tq, Tk, kv_batch_shift, scale, dtype, false, stream);
+}
+// q carries softmax scale * log2(e) already (m3_gemm_rope_dt's q_scale): O = softmax2(Q K^T) V with p = 2^(s - m)
+int m3_attention_prescaled_dt(const void *Q, const void *K, const void *V, void *O, int q_row_stride, int kv_row_stride,
+                              int o_row_stride, int64_t q_batch_stride, int64_t kv_batch_stride, int64_t o_batch_stride,
+                              int nbatch, int heads, int Tq, int Tk, int kv_batch_shift, int dtype, void *stream) {
+    return attention_launch(Q, K, V, O, q_row_stride, kv_row_stride, o_row_stride, q_batch_stride, kv_batch_stride,
+                            o_batch_stride, nbatch, heads, Tq, Tk, kv_batch_shift, 1.0f, dtype, true, stream);
+}
+int m3_attention_bf16(const void *Q, const void *K, const void *V, void *O, int q_row_stride, int kv_row_stride,
+                      int o_row_stride, int64_t q_batch_stride, int64_t kv_batch_stride, int64_t o_batch_stride,
+                      int nbatch, int heads, int Tq, int Tk, int kv_batch_shift, float scale, void *stream) {
+    return m3_attention_dt(Q, K, V, O, q_row_stride, kv_row_stride, o_row_stride, q_batch_stride, kv_batch_stride,
+                           o_batch_stride, nbatch, heads, Tq, Tk, kv_batch_shift, scale, DT_BF16, stream);
+}
+
+int m3_rope2d_dt(void *X, const int32_t *pos_yx, const float *cos_sin, int row_stride, int tokens, int heads,
+                 int tokens_per_image, int dtype, void *stream) {
+    M3_REQUIRE(X && pos_yx && cos_sin && tokens > 0 && heads > 0 && tokens_per_image > 0 && row_stride % 8 == 0);
+    M3_REQUIRE(dtype == DT_BF16 || dtype == DT_F16);
+    const int64_t total = (int64_t)tokens * heads * 2;
+    if (dtype == DT_F16)
+        hipLaunchKernelGGL(k_rope2d<DT_F16>, dim3(m3_cdiv(total, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                           (bf16_t *)X, pos_yx, cos_sin, row_stride, tokens, heads, tokens_per_image);
+    else
+        hipLaunchKernelGGL(k_rope2d<DT_BF16>, dim3(m3_cdiv(total, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                           (bf16_t *)X, pos_yx, cos_sin, row_stride, tokens, heads, tokens_per_image);
+    M3_CHECK_LAUNCH("m3_rope2d");
+    return M3_OK;
+}
+int m3_rope2d_bf16(void *X, const int32_t *pos_yx, const float *cos_sin, int row_stride, int tokens, int heads,
+                   int tokens_per_image, void *stream) {
+    return m3_rope2d_dt(X, pos_yx, cos_sin, row_stride, tokens, heads, tokens_per_image, DT_BF16, stream);
+}
+
+}  // extern "C"

@@ -164,6 +164,26 @@ def gemm_roofline(prof, tag=""):
             "all_mfma_kernels_tflops": sum(v[0] for v in by_kind.values()) / max(sum(v[1] for v in by_kind.values()), 1e-12) / 1e12}
 
 
+VALU_PEAK_GINSTR = 1024 * 2.4 / 2.0      # wave64 VALU instructions per ns the chip can issue: 1 024 SIMD-32s, 2 cycles per
+                                          # instruction at the 2.4 GHz maximum clock (MI355X_MICROARCH.md, cycle constants)
+
+
+def valu_rows(cprof, rows):
+    """Kernels the design classes as VALU-issue-bound (bit-exact matcher arithmetic): issue-rate roofline.  rows:
+    {entry point: (kernels, issue units per call, note)} - issue units = wave64 VALU instructions from the committed PMC
+    summary (profiles/r03_matcher_pmc.md, SQ_INSTS_VALU), float64 instructions counted twice (half rate)."""
+    out = {}
+    for name, (kern, units, note) in rows.items():
+        evs = cprof.get(name, [])
+        if not evs:
+            continue
+        us = sum(a.elapsed_time(b) for a, b in evs) / len(evs) * 1e3
+        out[name] = {"bound": "valu", "kernels": kern, "issue_units_per_call": units, "avg_us": us,
+                     "achieved": units / us / 1e3, "peak": VALU_PEAK_GINSTR, "unit": "G wave-instructions/s",
+                     "frac": units / us / 1e3 / VALU_PEAK_GINSTR, "note": note}
+    return out
+
+
 def hbm_rows(cprof, rows):
     """rows: {entry point: (kernels, algorithmic bytes per call, divisor)} -> hbm_rooflines dict from _ffi.PROFILE."""
     out = {}
@@ -373,6 +393,12 @@ class PairsWorkload:
             "m3_track_gather_batch": ("k_track_gather", (3.15 + 4 * 1.05 + 2.1 + 0.26 + 3.15 + 1.05 + 0.52) * MB * scale, 1),
             "m3_track_gn_ray_dist_batch": (f"k_track_accum + k_track_solve, per GN iteration ({iters} per call)", 8.7 * MB * scale, iters),
         })
+        valu = valu_rows(cprof, {
+            "m3_iter_proj": ("k_iter_proj", (57.8e6 + 2 * 28.9e6) / 8 * scale,
+                             "264 VALU instructions per LM step and point, a third of them float64 (numpy-twin interpolation)"),
+            "m3_refine_matches": ("k_refine_lds<24, float, 3>", 98.8e6 / 8 * scale,
+                                  "49 x 24 separately rounded multiply + add per point (bit-exact summation order)"),
+        })
         world = ctx.world
         result.update({
             "data": "synthetic: 512x512 textured pairs through the network (seeded random-init weights, no checkpoint available "
@@ -391,6 +417,7 @@ class PairsWorkload:
             "model_tflop_per_step": self.net.flops_per_pair(self.h, self.w) * P / 1e12,
             "roofline": gemm_roofline(prof),
             "hbm_rooflines": hbm,
+            "valu_rooflines": valu,
         })
         if world == 1 and not args.no_b1:
             self._extras(result, args)

@@ -67,6 +67,10 @@ def parse(argv=None):
     ap.add_argument("--gn-iters", type=int, default=1, help="Gauss-Newton iterations per step (SURVEY 8d config 5: one block pass)")
     ap.add_argument("--model", choices=("full", "tiny"), default="full", help="tiny: reduced depth, for tests only")
     ap.add_argument("--image", type=int, nargs=2, default=[H, W], metavar=("H", "W"))
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
+                    help="test hook: gloo lets several ranks share ONE GPU (RCCL refuses two ranks on a device); the data "
+                         "path is unchanged, only the collectives travel through host memory")
+    ap.add_argument("--single-device", action="store_true", help="test hook: every rank uses cuda:0")
     ap.add_argument("--stub", action="store_true",
                     help="test hook: gloo on the CPU with a trivial step (launcher, rendezvous, barrier, max-over-ranks timing, JSON)")
     return ap.parse_args(argv)
@@ -766,13 +770,15 @@ def run_rank(args) -> int:
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a ROCm device (the HIP path is the product; no CPU fallback)")
+        if args.single_device:
+            local = 0
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        if args.stub:
+        if args.stub or args.dist_backend == "gloo":
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -803,7 +809,7 @@ def run_rank(args) -> int:
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     n_ranks = dist.get_world_size() if dist is not None else 1

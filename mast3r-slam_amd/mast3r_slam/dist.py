@@ -50,14 +50,16 @@ class GatherHandle:
     """An all-gather in flight (all_gather_results(..., async_op=True)).  wait() makes the CURRENT stream
     wait for the collective (no host sync) and returns the gathered tuple."""
 
-    def __init__(self, work, out, parts, meta, world):
-        self._work, self._out, self._parts, self._meta, self._world = work, out, parts, meta, world
+    def __init__(self, work, out, parts, meta, world, device=None):
+        self._work, self._out, self._parts, self._meta, self._world, self._device = work, out, parts, meta, world, device
 
     def wait(self):
         if self._work is not None:
             self._work.wait()
             self._work = None
         out = self._out if self._parts is None else torch.stack(self._parts)
+        if self._device is not None:
+            out = out.to(self._device)
         return unpack(out, self._meta, self._world)
 
 
@@ -73,10 +75,12 @@ def all_gather_results(tensors, group=None, async_op: bool = False):
         out = torch.empty((world, buf.numel()), dtype=torch.uint8, device=buf.device)
         work = dist.all_gather_into_tensor(out.view(-1), buf, group=group, async_op=async_op)
         handle = GatherHandle(work if async_op else None, out, None, meta, world)
-    else:                                                       # gloo (CPU tests)
-        parts = [torch.empty_like(buf) for _ in range(world)]
-        work = dist.all_gather(parts, buf, group=group, async_op=async_op)
-        handle = GatherHandle(work if async_op else None, None, parts, meta, world)
+    else:                                                       # gloo: CPU tests, and ranks sharing one GPU in tests (gloo
+        dev = buf.device                                        # has no device all_gather: the packed buffer goes through the host)
+        hbuf = buf.cpu() if buf.is_cuda else buf
+        parts = [torch.empty_like(hbuf) for _ in range(world)]
+        work = dist.all_gather(parts, hbuf, group=group, async_op=async_op)
+        handle = GatherHandle(work if async_op else None, None, parts, meta, world, device=dev if buf.is_cuda else None)
     return handle if async_op else handle.wait()
 
 

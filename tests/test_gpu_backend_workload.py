@@ -94,3 +94,38 @@ def test_config5_edge_size_blocks_vs_oracle(dev):
     assert np.array_equal(again, blocks)
     one = kernels.gn_rays_blocks(poses, sc["Xs"], sc["C"], ii[200:201], jj[200:201], idx[200:201], valid[200:201], Q[200:201])
     assert np.abs(one.cpu().numpy()[0] - blocks[200]).max() <= 1e-9 * np.abs(blocks[200]).max()
+
+
+def _bench_two_ranks(extra):
+    """`python bench.py --gpus 2` (the self-launcher) with both ranks on THIS GPU: RCCL refuses two ranks on one device, so
+    the collectives go through gloo (--dist-backend gloo --single-device, test hooks); everything else - the launcher, the
+    sharding of pairs / edges, the device kernels on each rank, the gathered-block solve - is the N > 1 code the driver's
+    multi-GPU run executes."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-b1", "--no-cpu-baseline", "--dist-backend", "gloo", "--single-device", "--model", "tiny", *extra],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_two_ranks_pairs_workload():
+    res = _bench_two_ranks(["--pairs-per-gpu", "2", "--image", "256", "256"])
+    assert res["n_gpus"] == 2 and res["ranks"]["world_size_of_the_process_group"] == 2 and res["ranks"]["backend"] == "gloo"
+    assert res["config"]["global_pairs"] == 4 and res["value"] > 0
+    assert res["match_valid_frac"] > 0.5 and res["valid_frac"] > 0.5
+
+
+def test_two_ranks_edge_sharded_backend_workload():
+    """12 keyframes, 2 x 6 edges: each rank matches and linearises only its 6 edges, the 36-double blocks of all 24
+    directed edges are gathered, both ranks run the same dense step - and the solve moves the perturbed poses of the WHOLE
+    graph (which no rank could do from its own edges alone) towards the truth."""
+    res = _bench_two_ranks(["--workload", "backend", "--keyframes", "12", "--edges-per-gpu", "6", "--edge-batch", "3",
+                            "--image", "256", "256", "--gn-iters", "3"])
+    assert res["n_gpus"] == 2 and res["config"]["global_edges"] == 12 and res["config"]["edges_per_gpu"] == 6
+    assert res["edges_kept"] == 12 and res["match_valid_frac"] > 0.7
+    e0, e1 = res["pose_max_abs_err_before_after"]
+    assert e1 < 0.5 * e0
+    assert abs(res["value"] - 12 / (res["ms_per_step"] * 1e-3)) < 1e-6 * res["value"]

@@ -259,7 +259,7 @@ int m3_gn_rays_retract(float *Twc, const double *dx, const int32_t *local, int K
  * local int32 [K]: keyframe -> free-block index, < 0 = pinned or unused (host builds it
  * from unique(ii,jj) and pin, gauss_newton.py:73-81).  Twc is updated IN PLACE.
  * Hbuf double [m3_gn_rays_hbuf_doubles(dim)], dim = 7*num_free: ANY size - systems up to
- * m3_gn_rays_max_dim() (448) are factored by one workgroup, larger ones (BASELINE configs[4]: 256
+ * m3_gn_rays_max_dim() (63) are factored in place by one workgroup, larger ones (BASELINE configs[4]: 256
  * keyframes -> 1785 unknowns) by the blocked Cholesky of gn_chol.hip; either way the loop never
  * leaves the stream (the reference solves on the host, gauss_newton.py:253-260).
  * info double[4] = (iterations applied, last |dx|, converged/stopped flag, solver failure flag). */

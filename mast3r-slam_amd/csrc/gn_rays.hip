@@ -25,7 +25,9 @@ constexpr int kSums = 36;         // 28 Hjj upper + 7 gj + 1 count
 constexpr int kMaxChunks = 128;
 constexpr int kPtsPerChunk = 2048;
 constexpr int kSolveThreads = 1024;
-constexpr int kMaxDim = 448;      // 64 free keyframes in the single-workgroup Cholesky
+constexpr int kMaxDim = 63;       // 9 free keyframes: up to here ONE workgroup factors in place (63 serial steps); beyond, the blocked
+                                  // Cholesky of gn_chol.hip (round 3: the 231-unknown system of a 34-keyframe graph took 2.1 ms in
+                                  // the single-workgroup kernel - dim serial steps with three barriers each over a matrix in global memory)
 
 // residual_mode: 0 = "rays" (3-D point error), 1 = "points" (+ 1/(|Xi|+1e-6) weight), 2 = "calib"
 // (pixel + log-depth residual, gauss_newton_calib.py:17-274)

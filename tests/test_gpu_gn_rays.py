@@ -250,7 +250,7 @@ def test_blocked_cholesky_under_a_saturated_gpu(dev):
 
 
 def test_large_graph_solve_stays_on_the_device(dev):
-    """70 keyframes -> 483 unknowns > the single-workgroup limit (448): the whole Gauss-Newton loop (blocks, assembly,
+    """70 keyframes -> 483 unknowns (beyond the 63 a single workgroup factors in place: blocked Cholesky): the whole Gauss-Newton loop (blocks, assembly,
     blocked Cholesky, stop test, retraction) runs as one stream-ordered call and matches the float64 oracle; a
     converged solve stops by its device flag."""
     K_, P_ = 70, 4096

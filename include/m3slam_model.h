@@ -47,6 +47,11 @@ int m3_gemm_dt(const void *A, const void *W, const float *bias, void *C, const v
 /* Which kernel m3_gemm_bf16 / _rope / _grouped2 dispatch a dense [M,N] problem to: 256 or 192 = the
  * 256-row ping-pong kernel with 256- / 192-wide tiles, 128 or 64 = the small-problem kernel. */
 int m3_gemm_pick_tile(int M, int N, int groups);
+/* Diagnostic hook (tests, tools/gemm_shapes.py): force the tile shape of every later dense launch of the process -
+ * 64, 128, 192, 256 or 129 (= the 256x128 two-workgroups-per-CU kernel); 0 = automatic choice.  Every shape accumulates
+ * K in the same order, so the choice never changes a result bit.  Returns the previous setting (initially the value of
+ * the environment variable M3_GEMM_TILE, or 0). */
+int m3_gemm_set_tile(int tile);
 
 /* Projection GEMM with RoPE-2D fused into the epilogue: C(16-bit) = rope(A . W^T + bias) on the
  * 64-wide heads in columns [0, rope_cols) (q|k of a q|k|v projection), plain bias add beyond.

@@ -48,7 +48,7 @@ int m3_gemm_dt(const void *A, const void *W, const float *bias, void *C, const v
  * 256-row ping-pong kernel with 256- / 192-wide tiles, 128 or 64 = the small-problem kernel. */
 int m3_gemm_pick_tile(int M, int N, int groups);
 /* Diagnostic hook (tests, tools/gemm_shapes.py): force the tile shape of every later dense launch of the process -
- * 64, 128, 192, 256 or 129 (= the 256x128 two-workgroups-per-CU kernel); 0 = automatic choice.  Every shape accumulates
+ * 64, 128, 192 or 256; 0 = automatic choice.  Every shape accumulates
  * K in the same order, so the choice never changes a result bit.  Returns the previous setting (initially the value of
  * the environment variable M3_GEMM_TILE, or 0). */
 int m3_gemm_set_tile(int tile);

@@ -253,7 +253,6 @@ int pick_tile(int M, int N, int groups = 1, bool dense = true) {
     const bool can192 = dense && N % 192 == 0;
     if (forced == 128 || forced == 256) return forced;
     if (forced == 192) return can192 ? 192 : 256;
-    if (forced == 129) return dense ? 129 : 256;              // 256x128 dual-workgroup kernel (gemm_dual.hip)
     const long t256 = (long)m3_cdiv(M, 256) * m3_cdiv(N, 256) * groups, t128 = (long)m3_cdiv(M, 128) * m3_cdiv(N, 128) * groups;
     const double c256 = (double)((t256 + 255) / 256) * 4.0 / 1.4, c128 = (double)((t128 + 511) / 512) * 2.0;
     double c192 = 1e30;
@@ -335,12 +334,12 @@ int run_split(const GemmArgs &a, int S, int epi, void *ws, hipStream_t st) {
 
 int m3_launch_gemm256_dense(const GemmArgs &a, int epi, int bn, hipStream_t st);
 int m3_launch_gemm256_conv(const GemmArgs &a, int epi, hipStream_t st);
-int m3_launch_gemm_dual_dense(const GemmArgs &a, int epi, hipStream_t st);
 
 // Large dense tiles go to the ping-pong kernel.  (A one-wave-per-SIMD 256x256 variant with AGPR accumulators was built
-// and measured in round 2 - bit-identical, 20-80 % slower: tools/experiments/gemm4w.hip)
+// and measured in round 2 - bit-identical, 20-80 % slower: tools/experiments/gemm4w.hip, DESIGN.md section 3.  Round 3: a
+// 256x128x32 tile with TWO independent workgroups per CU, meant to run one tile's epilogue under the other's K loop -
+// bit-identical, 13-34 % slower: tools/experiments/gemm_dual.hip)
 static int launch_dense_big(const GemmArgs &a, int epi, int tile, hipStream_t st) {
-    if (tile == 129) return m3_launch_gemm_dual_dense(a, epi, st);
     return m3_launch_gemm256_dense(a, epi, tile, st);
 }
 
@@ -364,7 +363,7 @@ int m3_gemm_dt(const void *A, const void *W, const float *bias, void *C, const v
     a.A = (const bf16_t *)A; a.W = (const bf16_t *)W; a.bias = bias; a.C = C; a.R = R;
     a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.dt = dtype;
     const int tile = pick_tile(M, N);
-    if (tile >= 129) return launch_dense_big(a, epilogue, tile, (hipStream_t)stream);
+    if (tile >= 192) return launch_dense_big(a, epilogue, tile, (hipStream_t)stream);
     if (tile == 64) return launch<0, 64>(a, epilogue, (hipStream_t)stream);
     return launch<0>(a, epilogue, (hipStream_t)stream);
 }
@@ -385,7 +384,7 @@ int m3_gemm_rope_dt(const void *A, const void *W, const float *bias, void *C, in
     a.rope_tok = rope_tok; a.tokens_per_image = tokens_per_image; a.rope_cols = rope_cols;
     a.q_cols = q_cols; a.q_scale = q_scale;
     const int tile = pick_tile(M, N);
-    if (tile >= 129) return launch_dense_big(a, EPI_BF16_ROPE, tile, (hipStream_t)stream);
+    if (tile >= 192) return launch_dense_big(a, EPI_BF16_ROPE, tile, (hipStream_t)stream);
     if (tile == 64) return launch<0, 64>(a, EPI_BF16_ROPE, (hipStream_t)stream);
     return launch<0>(a, EPI_BF16_ROPE, (hipStream_t)stream);
 }
@@ -401,7 +400,7 @@ int m3_gemm_rope_pos_dt(const void *A, const void *W, const float *bias, void *C
     a.rope_pos = pos_yx; a.rope_log2_base = log2f(base); a.tokens_per_image = tokens_per_image; a.rope_cols = rope_cols;
     a.q_cols = q_cols; a.q_scale = q_scale;
     const int tile = pick_tile(M, N);
-    if (tile >= 129) return launch_dense_big(a, EPI_BF16_ROPE, tile, (hipStream_t)stream);
+    if (tile >= 192) return launch_dense_big(a, EPI_BF16_ROPE, tile, (hipStream_t)stream);
     if (tile == 64) return launch<0, 64>(a, EPI_BF16_ROPE, (hipStream_t)stream);
     return launch<0>(a, EPI_BF16_ROPE, (hipStream_t)stream);
 }
@@ -430,7 +429,7 @@ int m3_gemm_grouped2_dt(const void *A, const void *W0, const void *W1, const flo
     a.rope_tok = rope_tok; a.tokens_per_image = tokens_per_image; a.rope_cols = rope_cols;
     a.q_cols = q_cols; a.q_scale = q_scale;
     const int tile = pick_tile(M, N, 2);
-    if (tile >= 129) return launch_dense_big(a, epilogue, tile, (hipStream_t)stream);
+    if (tile >= 192) return launch_dense_big(a, epilogue, tile, (hipStream_t)stream);
     if (tile == 64) return launch<0, 64>(a, epilogue, (hipStream_t)stream);
     return launch<0>(a, epilogue, (hipStream_t)stream);
 }
@@ -448,7 +447,7 @@ int m3_gemm_grouped2_rope_pos_dt(const void *A, const void *W0, const void *W1, 
     a.rope_pos = pos_yx; a.rope_log2_base = log2f(base); a.tokens_per_image = tokens_per_image; a.rope_cols = rope_cols;
     a.q_cols = q_cols; a.q_scale = q_scale;
     const int tile = pick_tile(M, N, 2);
-    if (tile >= 129) return launch_dense_big(a, EPI_BF16_ROPE, tile, (hipStream_t)stream);
+    if (tile >= 192) return launch_dense_big(a, EPI_BF16_ROPE, tile, (hipStream_t)stream);
     if (tile == 64) return launch<0, 64>(a, EPI_BF16_ROPE, (hipStream_t)stream);
     return launch<0>(a, EPI_BF16_ROPE, (hipStream_t)stream);
 }

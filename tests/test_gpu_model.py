@@ -74,6 +74,32 @@ def test_gemm_192_wide_tiles(dev, epi):
     assert torch.equal(small, out[:256])
 
 
+@pytest.mark.parametrize("epi", [ops.EPI_BF16_GELU, ops.EPI_F32_ACCUM])
+def test_gemm_every_tile_shape_gives_the_same_bits(dev, epi):
+    """m3_gemm_set_tile forces the dispatcher (diagnostic hook): the 64-, 128-, 192- and 256-wide kernels accumulate K in
+    the same order, so one problem gives identical bits whichever of them runs it - the property that makes a pair's
+    result independent of the batch it travels in and of the rank it lands on."""
+    from mast3r_slam import _ffi
+    L = _ffi.lib()
+    m, n, k = 2048, 768, 1024
+    g = torch.Generator(device="cpu").manual_seed(23 + epi)
+    a = torch.randn(m, k, generator=g).bfloat16().to(dev)
+    w = (torch.randn(n, k, generator=g) * 0.05).bfloat16().to(dev)
+    b = torch.randn(n, generator=g).to(dev)
+    r = torch.randn(m, n, generator=g).to(dev) if epi == ops.EPI_F32_ACCUM else None
+    outs = {}
+    prev = L.m3_gemm_set_tile(0)
+    try:
+        for tile in (64, 128, 192, 256):
+            L.m3_gemm_set_tile(tile)
+            assert L.m3_gemm_pick_tile(m, n, 1) == tile
+            outs[tile] = ops.gemm(a, w, b, epi, resid=r)
+    finally:
+        L.m3_gemm_set_tile(prev)
+    for tile in (128, 192, 256):
+        assert torch.equal(outs[tile], outs[64]), tile
+
+
 def test_conv_splitk_is_batch_invariant(dev):
     """A 16x16 map with K = 9*256 takes the split-K path (fp32 partial planes, fixed-order sum, epilogue in
     the finishing kernel).  The slice count depends on the per-image geometry only, so an image gives the

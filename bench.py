@@ -499,6 +499,34 @@ class PairsWorkload:
                                                   "flops_note": "2 S N D with D = 24 (K is padded to 32 on the matrix core: x 4/3 issued)"},
                                      "note": f"m3_frnn_pack + 3 x m3_frnn_round on {P} pairs at once, fp16 descriptors, {seeds} seeds x {self.h * self.w} pixels per search"}
 
+        # calibrated tracking solve (tracker.py:326-406; pixel + log-depth residuals through a pinhole K): same streams as
+        # the ray-distance solve (Xf 12 + Xk 12 + Qk 4 + valid 1 B per point and iteration), all P problems per launch
+        import numpy as np
+        hh, ww = self.h, self.w
+        Kc = np.array([[float(ww), 0, ww / 2], [0, float(ww), hh / 2], [0, 0, 1]], dtype=np.float32)
+        gat = tracker.track_gather(sc["X11"].reshape(P, n, 3), sc["Cf"], sc["Ck"], sc["Qf"], sc["Qk"], self.state["idx"],
+                                   self.state["valid"].reshape(P, n), tcfg["C_conf"], tcfg["Q_conf"])
+        Xf_c, Qk_c, vo_c = gat[0], gat[1], gat[2]
+        Xk_c = tracker.constrain_points_to_ray((hh, ww), sc["Xk"].reshape(-1, 3), Kc).reshape(P, n, 3)
+        Xf_c = tracker.constrain_points_to_ray((hh, ww), Xf_c.reshape(-1, 3), Kc).reshape(P, n, 3)
+        run_c = lambda: tracker.opt_pose_calib_sim3(Xf_c, Xk_c, self.ident, self.ident, Qk_c, vo_c, Kc, (hh, ww), tcfg,
+                                                    fixed_iters=True)
+        for _ in range(2):
+            run_c()
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(5):
+            info_c = run_c()[2]
+        e1.record(); torch.cuda.synchronize()
+        it_c = int(tcfg["max_iters"])
+        us_c = e0.elapsed_time(e1) / 5 * 1e3 / it_c
+        by_c = 29.0 * P * n
+        result["calibrated_tracking"] = {"entry": "m3_track_gn_calib_batch", "kernels": "k_track_accum_calib + k_track_solve, per GN iteration",
+                                         "iterations": it_c, "avg_us_per_iteration": round(us_c, 2),
+                                         "algorithmic_bytes": by_c, "achieved": round(by_c / us_c / 1e3, 1), "unit": "GB/s",
+                                         "peak": HBM_PEAK_GBS, "frac": round(by_c / us_c / 1e3 / HBM_PEAK_GBS, 4),
+                                         "status": [int(x) for x in info_c[:, 3].tolist()][:2]}
+
         if P != 1:
             # BASELINE configs[1]: one pair per step (latency regime), same pipeline, graph-replayed
             net, ident = self.net, self.ident
@@ -598,10 +626,10 @@ class BackendWorkload:
         """(1) the network's share of a re-match: the symmetric decode of these edges from the cached tokens - real work,
         outputs dropped (random-init weights give nothing matchable); (2) the matcher's share on the synthetic
         keyframe graph: both directions as one batch of 2b maps, fp16 descriptors."""
-        from mast3r_slam.mast3r_utils import mast3r_decode_symmetric_batch
+        from mast3r_slam.mast3r_utils import _decode_symmetric      # what mast3r_match_symmetric runs before its matcher
         torch, sc = self.torch, self.scene
         b = feat_i.shape[0]
-        mast3r_decode_symmetric_batch(model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j)
+        _decode_symmetric(model, feat_i, feat_j, shape_i)
         sel = range(self.mine.start + self.cursor, self.mine.start + self.cursor + b)
         self.cursor += b
         i = torch.tensor([self.ii[k] for k in sel], device=self.ctx.dev)

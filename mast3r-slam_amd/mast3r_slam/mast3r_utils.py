@@ -180,15 +180,22 @@ def _hw(shape):
     return int(s.reshape(-1)[0]), int(s.reshape(-1)[1])
 
 
-def mast3r_decode_symmetric_batch(model: Mast3rFull, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j):
-    """mast3r_utils.py:572-632 -> X [4,B,H,W,3], C [4,B,H,W], D [4,B,H,W,24], Q [4,B,H,W] in the order
-    (ii, ji, jj, ij).  feat_* [B,T,1024] cached encoder tokens."""
+def _decode_symmetric(model: Mast3rFull, feat_i, feat_j, shape_i):
+    """Both decode directions of B pairs as ONE batch of 2B: items [0, B) are the pairs (i, j), items [B, 2B) the pairs
+    (j, i).  Returns the two branch outputs: o1[:B] = ii, o1[B:] = jj (view-1 branch), o2[:B] = ji, o2[B:] = ij."""
     b = feat_i.shape[0]
     h, w = _hw(shape_i)
     grid = (h // 16, w // 16)
     fi = feat_i.to(model.device, model.tdt)          # cached tokens are stored in the trunk's 16-bit type
     fj = feat_j.to(model.device, model.tdt)
     o1, o2 = model.decode_heads(torch.cat([fi, fj], 0), torch.cat([fj, fi], 0), 2 * b, grid)
+    return o1, o2, b
+
+
+def mast3r_decode_symmetric_batch(model: Mast3rFull, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j):
+    """mast3r_utils.py:572-632 -> X [4,B,H,W,3], C [4,B,H,W], D [4,B,H,W,24], Q [4,B,H,W] in the order
+    (ii, ji, jj, ij).  feat_* [B,T,1024] cached encoder tokens."""
+    o1, o2, b = _decode_symmetric(model, feat_i, feat_j, shape_i)
     sl = lambda o, lo: {n: v[lo:lo + b] for n, v in o.items()}
     parts = [sl(o1, 0), sl(o2, 0), sl(o1, b), sl(o2, b)]           # ii, ji, jj, ij
     X = torch.stack([p["pts3d"] for p in parts])
@@ -201,10 +208,18 @@ def mast3r_decode_symmetric_batch(model: Mast3rFull, feat_i, pos_i, feat_j, pos_
 def mast3r_match_symmetric(model: Mast3rFull, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j):
     """mast3r_utils.py:503-569 -> (idx_i2j, idx_j2i [B,N], valid_match_j, valid_match_i [B,N,1],
     Qii, Qjj, Qji, Qij [B,N,1]).  Both matching directions run as one batch of 2B maps."""
+    if get_config().get("dataset", {}).get("img_downsample", 1) <= 1:
+        # match(X11, X21): i->j uses (ii, ji), j->i uses (jj, ij) - in the 2B batch that IS the view-1 branch against the
+        # view-2 branch, so the decoder outputs go to the matcher as they are (the [4,B,...] stack of
+        # mast3r_decode_symmetric_batch and its re-concatenation copied 1.6 GB per 8 edges at 512x512)
+        o1, o2, b = _decode_symmetric(model, feat_i, feat_j, shape_i)
+        n = o1["pts3d"].shape[1] * o1["pts3d"].shape[2]
+        idx, valid = matching.match(o1["pts3d"], o2["pts3d"], o1["desc"], o2["desc"])
+        q1, q2 = o1["desc_conf"].reshape(2 * b, n, 1), o2["desc_conf"].reshape(2 * b, n, 1)
+        return idx[:b], idx[b:], valid[:b], valid[b:], q1[:b], q1[b:], q2[:b], q2[b:]
     X, C, D, Q = mast3r_decode_symmetric_batch(model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j)
     b, h, w = X.shape[1:4]
     n = h * w
-    # match(X11, X21): i->j uses (ii, ji); j->i uses (jj, ij)
     X11 = torch.cat([X[0], X[2]], 0)
     X21 = torch.cat([X[1], X[3]], 0)
     D11 = torch.cat([D[0], D[2]], 0)

@@ -196,7 +196,7 @@ def test_solve_is_bitwise_reproducible(dev):
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
-@pytest.mark.parametrize("n", [7, 64, 65, 449, 1785])
+@pytest.mark.parametrize("n", [7, 64, 65, 128, 130, 449, 1785])
 def test_blocked_cholesky_solve_any_size(dev, n):
     """kernels.cholesky_solve (linalg.py:17-50) through m3_chol_solve: blocked float64 Cholesky, block 64, for sizes
     below / at / across block boundaries and at BASELINE configs[4]'s 256 keyframes (7 * 255 = 1785 unknowns)."""
@@ -212,6 +212,25 @@ def test_blocked_cholesky_solve_any_size(dev, n):
             kernels.cholesky_solve(-H, g, 0.0)
         xb = kernels.cholesky_solve(np.stack([H, 2 * H]), np.stack([g, g]), 0.0)          # batched form
         assert np.allclose(xb[1], 0.5 * xb[0], rtol=1e-9, atol=1e-12)
+
+
+def test_blocked_cholesky_on_an_ill_conditioned_system(dev):
+    """Eigenvalues spread over 1e-3 .. 1e+6 (the spread of a Gauss-Newton normal matrix with its scale column: DESIGN
+    section 9 shows entries of 1e+1 beside a diagonal of 1e+8): the factorisation takes its 1 / sqrt(pivot) from
+    v_rsq_f64 + Goldschmidt steps and its trsm from an explicitly inverted 64 x 64 factor - the backward error must stay
+    at the float64 level, i.e. |H x - g| small against |H| |x|."""
+    n = 300
+    rng = np.random.default_rng(77)
+    Qm, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    lam = 10.0 ** rng.uniform(-3, 6, size=n)
+    H = (Qm * lam) @ Qm.T
+    H = 0.5 * (H + H.T)
+    g = rng.normal(size=n)
+    x = kernels.cholesky_solve(H, g, 0.0)
+    resid = np.abs(H @ x - g).max()
+    assert resid <= 1e-12 * np.abs(H).max() * np.abs(x).max() * n
+    ref = np.linalg.solve(H, g)
+    assert np.abs(x - ref).max() <= 1e-6 * np.abs(ref).max()          # condition number 1e9 x float64 epsilon
 
 
 def test_blocked_cholesky_under_a_saturated_gpu(dev):

@@ -55,6 +55,9 @@ def parse(argv=None):
     ap.add_argument("--workload", choices=("pairs", "backend"), default="pairs")
     ap.add_argument("--pairs-per-gpu", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--matcher", choices=["iter_proj", "fast_nn"], default="iter_proj",
+                    help="match leg of the pairs workload: the reference's dense matcher (iter_proj + refine_matches, default) or "
+                         "the fast reciprocal nearest-neighbour matcher BASELINE.json's north_star names (MFMA search, fp16 descriptors)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--force-dist", action="store_true",
@@ -255,6 +258,8 @@ class PairsWorkload:
         im = lambda off: torch.from_numpy(np.stack([synthetic.textured_image(self.h, self.w, 2 * (base + p) + off) for p in range(P)])).to(dev)
         self.im1, self.im2 = im(0), im(1)
         self.sc = self._make_scene(base)
+        if args.matcher == "fast_nn":
+            self.sc["D11h"], self.sc["D21h"] = self.sc["D11"].half(), self.sc["D21"].half()
         self.ident = torch.tensor([0, 0, 0, 0, 0, 0, 1, 1], dtype=torch.float32, device=dev)
         self.n = self.h * self.w
         self.tcfg = config.get_config()["tracking"]
@@ -288,6 +293,17 @@ class PairsWorkload:
 
     def leg_match(self):
         sc = self.sc
+        if self.args.matcher == "fast_nn":
+            # MASt3R sec. 3.3: reciprocal nearest neighbours in descriptor space from a subsampled seed grid (4096 seeds per
+            # pair at 512x512), all P pairs per launch; the sparse matches become the tracker's (index, validity) maps:
+            # idx[pair, pixel of view 2] = pixel of view 1
+            torch, P, n = self.torch, self.P, self.n
+            pp, p1, p2 = self.matching.fast_reciprocal_nn_device(sc["D11h"], sc["D21h"], subsample=8, max_iter=3)
+            idx = torch.zeros((P, n), dtype=torch.int64, device=p1.device)
+            valid = torch.zeros((P, n, 1), dtype=torch.bool, device=p1.device)
+            idx[pp, p2] = p1
+            valid[pp, p2, 0] = True
+            return idx, valid
         return self.matching.match(sc["X11"], sc["X21"], sc["D11"], sc["D21"])
 
     def leg_gn(self, idx, valid):
@@ -320,8 +336,11 @@ class PairsWorkload:
                 graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
                 with torch.cuda.graph(graphs[0]):
                     o1, o2 = self.leg_infer()
-                with torch.cuda.graph(graphs[1]):
-                    idx, valid = self.leg_match()
+                if self.args.matcher == "fast_nn":
+                    graphs[1] = None                                  # the reciprocal filter ends in a data-dependent compaction
+                else:
+                    with torch.cuda.graph(graphs[1]):
+                        idx, valid = self.leg_match()
                 with torch.cuda.graph(graphs[2]):
                     gn = self.leg_gn(idx, valid)
                 torch.cuda.synchronize()
@@ -340,10 +359,14 @@ class PairsWorkload:
         else:
             st["o1"], st["o2"] = self.leg_infer()
         if m: m[1].record()
-        if graphs is not None:
+        if graphs is not None and graphs[1] is not None:
             graphs[1].replay()
         else:
-            st["idx"], st["valid"] = self.leg_match()
+            idx, valid = self.leg_match()
+            if graphs is not None:                                    # the GN graph reads the buffers it was captured on
+                st["idx"].copy_(idx); st["valid"].copy_(valid)
+            else:
+                st["idx"], st["valid"] = idx, valid
         if m: m[2].record()
         if graphs is not None:
             graphs[2].replay()
@@ -374,7 +397,13 @@ class PairsWorkload:
         match_valid_frac = float(self.state["valid"].float().mean())
         valid_frac = float(vo.float().mean())
         pose_err = float(np.abs(T_rel.double().cpu().numpy() - sc["T_true"][None]).max())
-        if match_valid_frac < 0.5 or valid_frac < 0.5:
+        sparse = args.matcher == "fast_nn"
+        if sparse:
+            seeds = (self.h // 8) * (self.w // 8)
+            recip = float(self.state["valid"].sum()) / (P * seeds)
+            if recip < 0.5 or not pose_err < 2e-2:
+                raise SystemExit(f"bench invalid: {recip:.3f} of the seeds found a reciprocal match, pose error {pose_err:.3g}")
+        elif match_valid_frac < 0.5 or valid_frac < 0.5:
             raise SystemExit(f"bench invalid: match_valid_frac={match_valid_frac:.3f} valid_frac={valid_frac:.3f} (< 0.5): "
                              "the matcher / Gauss-Newton legs would be timed on rejected points")
         # ---- untimed instrumented pass (eager, launches serialised): per-launch device time by kernel family ----
@@ -408,11 +437,12 @@ class PairsWorkload:
             "data": "synthetic: 512x512 textured pairs through the network (seeded random-init weights, no checkpoint available "
                     "offline); matcher + Gauss-Newton on smooth synthetic two-view scenes of the same size (SURVEY 8d configs 2-3)",
             "config": {"workload": f"{P} keyframe pairs/GPU at {self.h}x{self.w} (BASELINE configs[3] per-GPU shard): "
-                                   "two-view MASt3R ViT-L infer (bf16 trunk, fp16 heads, fp32 accumulate) + iter_proj/refine match "
-                                   "+ 10-iter GN tracking" + ("" if ctx.dist is None else " + RCCL all-gather of results"),
-                       "pairs_per_gpu": P, "global_pairs": world * P, "image": [self.h, self.w], "gn_iters": iters,
+                                   "two-view MASt3R ViT-L infer (bf16 trunk, fp16 heads, fp32 accumulate) + "
+                                   + ("fast reciprocal-NN match (4096-seed grid, fp16 descriptors, MFMA search) " if sparse else "iter_proj/refine match ")
+                                   + "+ 10-iter GN tracking" + ("" if ctx.dist is None else " + RCCL all-gather of results"),
+                       "pairs_per_gpu": P, "global_pairs": world * P, "image": [self.h, self.w], "gn_iters": iters, "matcher": args.matcher,
                        "parallelism": f"pair-sharded x{world}",
-                       "launch": ("3 hipGraph replays per step (infer | match | GN)" + ("" if ctx.dist is None else " + RCCL all-gather of the previous step overlapped on the communicator stream")) if self.graphs is not None else "eager"},
+                       "launch": (("2 hipGraph replays per step (infer | GN) around the eagerly launched reciprocal-NN match leg" if sparse else "3 hipGraph replays per step (infer | match | GN)") + ("" if ctx.dist is None else " + RCCL all-gather of the previous step overlapped on the communicator stream")) if self.graphs is not None else "eager"},
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "stage_ms_note": "device time between stream events recorded around the three graph replays of every TIMED step (mean); sum ~ ms_per_step",
             "match_valid_frac": round(match_valid_frac, 4),

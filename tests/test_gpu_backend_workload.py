@@ -40,6 +40,19 @@ def test_pairs_workload_at_the_config4_shard_size():
     assert res["value"] > 0 and abs(res["value"] - 8 / (res["ms_per_step"] * 1e-3)) < 1e-6 * res["value"]
 
 
+def test_pairs_workload_with_the_fast_reciprocal_nn_matcher():
+    """--matcher fast_nn: the match leg is the MFMA fast-reciprocal-NN matcher (the matcher BASELINE.json's north_star
+    names) feeding the same gather + 10-iteration solve through sparse (index, validity) maps: most seeds must find a
+    reciprocal match on the smooth scene and the solve must recover the scene's Sim(3) from them (bench.py exits
+    non-zero otherwise)."""
+    res = _bench(["--model", "tiny", "--pairs-per-gpu", "4", "--matcher", "fast_nn"], 29626)
+    assert res["config"]["matcher"] == "fast_nn" and "reciprocal" in res["config"]["workload"]
+    seeds = 64 * 64
+    assert 0.5 * seeds / (512 * 512) < res["match_valid_frac"] <= seeds / (512 * 512)
+    assert res["gn_pose_max_abs_err_vs_true_sim3"] < 2e-2
+    assert res["stage_ms"]["match"] > 0 and res["value"] > 0
+
+
 def test_backend_workload_small_graph_end_to_end():
     """12 keyframes, 6 undirected edges on this rank, reduced-depth network, 256 x 256: decode from cached tokens, both
     matching directions with fp16 features, blocks, one-rank RCCL gather of the blocks, dense step."""

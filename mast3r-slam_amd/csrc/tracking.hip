@@ -7,11 +7,14 @@
 // The reference materialises [N,4,7] Jacobians in MLX and pulls a 7x7 system to
 // numpy every iteration (one host sync per iteration).  Here one streaming kernel
 // per iteration fuses act -> ray/dist -> residual -> Huber -> J^T W J / J^T W r
-// (28+7+1 sums per point, float32 per point, float64 accumulation), reduces with
-// wave shuffles + LDS to one partial row per workgroup, and a single-workgroup
-// kernel finishes the reduction in a FIXED order (bitwise reproducible), solves
-// the 7x7 system, retracts the pose and evaluates the stop test - the loop never
-// returns to the host.  HBM/L2 bound: 29 B per point per iteration.
+// (28+7+1 sums per point, float32 per point, float64 accumulation) and reduces with
+// wave shuffles + LDS to one partial row per workgroup.  The step that follows - finish
+// the reduction in a FIXED order (bitwise reproducible), solve the 7x7 system, retract
+// the pose, evaluate the stop test - runs in the PROLOGUE of the next iteration's kernel,
+// redundantly in every workgroup (64 x 36 partials out of L2, ~3 us) instead of as a
+// launch of its own (6 us): ONE launch per iteration; the loop never returns to the host.
+// State and partials are double-buffered by iteration parity so that no workgroup reads
+// what another one of the same launch writes.  HBM/L2 bound: 29 B per point per iteration.
 #include "common.h"
 #include <cstdlib>
 #include "sim3_dev.h"
@@ -21,17 +24,20 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kBlocks = 256;          // most partial rows a problem can have (workspace size)
 constexpr int kSums = 36;             // 28 (H upper) + 7 (g) + 1 (cost)
-// workspace layout (doubles)
+// workspace layout (doubles): two state slots and two partial buffers, indexed by the parity of the number of solved steps
 constexpr int WS_T = 0;               // T_CkCf [8]
 constexpr int WS_OLD = 8;             // old cost
-constexpr int WS_DONE = 9;            // != 0 once converged / failed
+constexpr int WS_DONE = 9;            // != 0 once converged (1) / failed (2)
 constexpr int WS_ITERS = 10;
 constexpr int WS_TAUN = 11;
 constexpr int WS_COST = 12;
 constexpr int WS_CONV = 13;
-constexpr int WS_PART = 16;           // partials [kBlocks][kSums]
+constexpr int WS_STATE = 16;          // doubles per state slot
+constexpr int WS_PART = 2 * WS_STATE; // partials [2][kBlocks][kSums]
+constexpr int WS_STRIDE = WS_PART + 2 * kBlocks * kSums;   // doubles per problem
 
-constexpr int WS_STRIDE = WS_PART + kBlocks * kSums;   // doubles per problem
+__device__ __forceinline__ double *ws_state(double *ws, int steps) { return ws + (steps & 1) * WS_STATE; }
+__device__ __forceinline__ double *ws_part(double *ws, int steps) { return ws + WS_PART + (size_t)(steps & 1) * kBlocks * kSums; }
 
 // Partial rows (= workgroups) per problem: ~2 workgroups per CU over the whole batch, so a thread sees
 // enough points to amortise the 36-value block reduction (at 256 rows x 8 problems it saw 4 points
@@ -56,6 +62,167 @@ __global__ void k_track_init(const float *__restrict__ T_WCf, const float *__res
     store_pose(ws + WS_T, T);
     ws[WS_OLD] = INFINITY;
     ws[WS_DONE] = 0.0; ws[WS_ITERS] = 0.0; ws[WS_TAUN] = 0.0; ws[WS_COST] = 0.0; ws[WS_CONV] = 0.0;
+}
+
+// Fixed-order final reduction of the kBlocks partial rows: wave w owns sums 9w..9w+8,
+// every lane adds rows lane, lane+64, lane+128, lane+192, then a shuffle tree.
+__device__ __forceinline__ void reduce_partials(const double *__restrict__ part, double *sums /*LDS[36]*/, int nblk) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int c = 0; c < 9; ++c) {
+        const int col = wv * 9 + c;
+        double s = 0.0;
+        for (int r = lane; r < nblk; r += 64) s += part[r * kSums + col];
+        s = m3_wave_sum(s);
+        if (lane == 0) sums[col] = s;
+    }
+    __syncthreads();
+}
+
+// One solved Gauss-Newton step = the per-iteration tail of the tracking solve, executed by a whole workgroup of 256:
+//   1. the nblk x 36 partial rows are reduced by 252 threads (thread = (row group of 7, column); rows in a fixed order),
+//      then 36 threads add the 7 group sums - one wave of independent, coalesced loads instead of nine dependent
+//      load -> shuffle-tree rounds;
+//   2. the 7 x 7 system [H + 1e-6 I | g] is solved by Gauss-Jordan elimination IN ONE WAVE, lane 8 i + j holding element
+//      (i, j) (column 7 = right-hand side): 7 steps of three broadcasts and one FMA instead of ~150 dependent float64
+//      operations on one lane.  No pivoting: the matrix is a Gram matrix plus 1e-6 I (symmetric positive definite); a
+//      pivot that is not positive and finite reports the failure the old pivoted elimination reported for a zero column;
+//   3. the retraction T <- T exp(tau) needs sin(th), cos(th), sin(th/2), cos(th/2) and exp(sigma) in float64: lanes 0-3
+//      evaluate sin at (th, th + pi/2, th/2, th/2 + pi/2) in ONE library call, lane 4 the exponential - five serial
+//      library calls before.
+// Step number `steps` (1, 2, ...) reads state and partials of parity steps - 1 and produces the state of parity
+// steps: every workgroup of the next accumulation launch runs it redundantly (identical inputs, identical operation
+// order -> identical bits) and ONE of them (`writer`) stores the new state; nobody reads what this launch writes.
+// Returns true when the problem is finished (converged, failed, or was already); T_out = the pose to linearise at.
+__device__ __forceinline__ double bcast(double v, int src) { return __shfl(v, src, 64); }
+
+struct StepLds { double red[7][kSums]; double sums[kSums]; double st[WS_STATE]; };
+
+__device__ __forceinline__ bool track_step(double *__restrict__ ws, int steps, bool writer, float rel_error, float delta_norm,
+                                           int fixed_iters, int nblk, StepLds &L, Pose<float> &T_out) {
+    const double *sin_ = ws_state(ws, steps - 1);
+    const double *part_in = ws_part(ws, steps - 1);
+    double *sout = ws_state(ws, steps);
+    const int t = threadIdx.x;
+    if (sin_[WS_DONE] != 0.0) {                            // workgroup-uniform: carry the final state forward
+        if (t < WS_STATE) {
+            L.st[t] = sin_[t];
+            if (writer) sout[t] = sin_[t];
+        }
+        __syncthreads();
+        T_out = load_pose<float>(L.st + WS_T);
+        return true;
+    }
+    if (t < 7 * kSums) {
+        const int rg = t / kSums, col = t - rg * kSums;
+        const double *part = part_in + col;
+        double s0 = 0.0, s1 = 0.0;
+        int r = rg;
+        for (; r + 7 < nblk; r += 14) { s0 += part[(size_t)r * kSums]; s1 += part[(size_t)(r + 7) * kSums]; }
+        if (r < nblk) s0 += part[(size_t)r * kSums];
+        L.red[rg][col] = s0 + s1;
+    }
+    __syncthreads();
+    if (t < kSums) L.sums[t] = ((L.red[0][t] + L.red[1][t]) + (L.red[2][t] + L.red[3][t])) + ((L.red[4][t] + L.red[5][t]) + L.red[6][t]);
+    __syncthreads();
+    if (t < 64) {                                          // one wave; every lane of it stays active to the end
+        const int i = (t >> 3) < 7 ? (t >> 3) : 6, j = t & 7;
+        // upper-triangular packing of the 28 sums: (a, b), a <= b -> a * 7 - a (a - 1) / 2 + (b - a)
+        const int a_ = i < j ? i : j, b_ = i < j ? j : i;
+        double e = (j < 7) ? L.sums[a_ * 7 - (a_ * (a_ - 1)) / 2 + (b_ - a_)] + (i == j ? 1e-6 : 0.0) : L.sums[28 + i];
+        const double cost = L.sums[35];
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const double piv = bcast(e, 8 * k + k), rk = bcast(e, 8 * k + j), ik = bcast(e, 8 * i + k);
+            ok = ok && (piv > 0.0) && isfinite(piv);
+            // 1 / pivot from v_rcp_f64 + two Newton steps (within 1 ulp) - a correctly rounded division is ~35 dependent
+            // instructions, seven of them in a row on this chain
+            double ip = __builtin_amdgcn_rcp(piv);
+            ip = fma(fma(-piv, ip, 1.0), ip, ip);
+            ip = fma(fma(-piv, ip, 1.0), ip, ip);
+            const double nrk = rk * ip;
+            e = (i == k) ? nrk : e - ik * nrk;
+        }
+        double tau[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) tau[k] = bcast(e, 8 * k + 7);
+        double tn = 0.0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) tn += tau[k] * tau[k];
+        tn = sqrt(tn);
+        // a step whose scale factor e^sigma leaves the float range (degenerate geometry) is refused like a singular
+        // system: stop and keep the pose (the reference raises inside _opt_pose_*, tracker.py:121-141)
+        const bool failed = !ok || !isfinite(tn) || fabs(tau[6]) > 30.0;
+        // exp(tau), liegroups/sim3.py:107-154 (exp_mlx of sim3_dev.h with the transcendentals shared across lanes)
+        const V3<double> v{tau[0], tau[1], tau[2]}, w{tau[3], tau[4], tau[5]};
+        const double th2 = dot(w, w), th = sqrt(th2 + 1e-10);
+        const bool small = th2 < 1e-8;
+        const double arg = (t & 2 ? 0.5 * th : th) + (t & 1 ? 1.5707963267948966 : 0.0);
+        const double tr = (t == 4) ? exp(failed ? 0.0 : tau[6]) : sin(failed ? 0.0 : arg);
+        const double sin_th = bcast(tr, 0), cos_th = bcast(tr, 1), sin_h = bcast(tr, 2), cos_h = bcast(tr, 3), es = bcast(tr, 4);
+        if (t == 0) {
+#pragma unroll
+            for (int k = 0; k < WS_STATE; ++k) L.st[k] = sin_[k];
+            if (failed) {
+                L.st[WS_DONE] = 2.0;
+            } else {
+                const double A = small ? 1.0 - th2 / 6.0 : sin_th / th;
+                const double B = small ? 0.5 - th2 / 24.0 : (1.0 - cos_th) / th2;
+                const double C = small ? 1.0 / 6.0 - th2 / 120.0 : (1.0 - A) / th2;
+                const V3<double> wv = cross(w, v);
+                Pose<double> E;
+                E.t = v + B * wv + C * cross(w, wv);
+                const double sinc_half = small ? 0.5 - th2 / 48.0 : sin_h / th;
+                const double cos_half = small ? 1.0 - th2 / 8.0 : cos_h;
+                E.q = {sinc_half * w.x, sinc_half * w.y, sinc_half * w.z, cos_half};
+                E.s = es;
+                store_pose(L.st + WS_T, mul(load_pose<double>(sin_ + WS_T), E));
+                const double old = sin_[WS_OLD];
+                const double rel_dec = fabs((old - cost) / (old + 1e-10));       // NaN on the first step, as in the reference
+                const bool conv = (rel_dec < (double)rel_error) || (tn < (double)delta_norm);
+                L.st[WS_ITERS] = sin_[WS_ITERS] + 1.0;
+                L.st[WS_TAUN] = tn;
+                L.st[WS_COST] = cost;
+                L.st[WS_OLD] = cost;
+                if (conv && !fixed_iters) { L.st[WS_DONE] = 1.0; L.st[WS_CONV] = 1.0; }
+            }
+        }
+    }
+    __syncthreads();
+    if (writer && t < WS_STATE) sout[t] = L.st[t];
+    T_out = load_pose<float>(L.st + WS_T);
+    return L.st[WS_DONE] != 0.0;
+}
+
+// What an accumulation launch needs to run the previous step in its prologue.  steps = number of steps solved BEFORE this
+// launch's linearisation (0 for the first launch of a solve: the state is the initial one, nothing to solve).
+struct StepArgs {
+    int steps; float rel_error, delta_norm; int fixed_iters, nblk;
+    const float *T_WCf, *T_WCk;       // [P][8] (steps == 0 only): the solve's initial T_CkCf = T_WCk^-1 T_WCf is formed here;
+};                                    // null = the state slot was initialised by k_track_init (m3_track_normal_eq)
+
+// Returns true when this workgroup has nothing to accumulate (problem finished); otherwise T = the pose to linearise at.
+__device__ __forceinline__ bool begin_iteration(double *__restrict__ ws, const StepArgs &sa, StepLds &L, Pose<float> &T) {
+    if (sa.steps == 0) {
+        double *st = ws_state(ws, 0);
+        if (sa.T_WCf) {                                    // first launch of a solve: every thread forms the initial pose
+            const size_t pb = blockIdx.y;                  // (uniform loads, ~150 flops), workgroup 0 records the state
+            const Pose<double> T0 = mul(inv_mlx(load_pose<double>(sa.T_WCk + 8 * pb)), load_pose<double>(sa.T_WCf + 8 * pb));
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                store_pose(st + WS_T, T0);
+                st[WS_OLD] = INFINITY;
+                st[WS_DONE] = 0.0; st[WS_ITERS] = 0.0; st[WS_TAUN] = 0.0; st[WS_COST] = 0.0; st[WS_CONV] = 0.0;
+            }
+            double tmp[8];
+            store_pose(tmp, T0);
+            T = load_pose<float>(tmp);
+            return false;
+        }
+        if (st[WS_DONE] != 0.0) return true;
+        T = load_pose<float>(st + WS_T);
+        return false;
+    }
+    return track_step(ws, sa.steps, blockIdx.x == 0, sa.rel_error, sa.delta_norm, sa.fixed_iters, sa.nblk, L, T);
 }
 
 __device__ __forceinline__ void block_reduce_store(const double *acc, double *__restrict__ out) { m3_block_reduce36(acc, out); }
@@ -108,13 +275,14 @@ __device__ __forceinline__ void track_point(const Pose<float> &T, const V3<float
 __global__ void __launch_bounds__(kThreads)
 k_track_accum(const float *__restrict__ Xf, const float *__restrict__ Xk, const float *__restrict__ Qk,
               const uint8_t *__restrict__ valid, double *__restrict__ ws, int N, float huber_k,
-              float inv_sigma_ray, float inv_sigma_dist) {
+              float inv_sigma_ray, float inv_sigma_dist, const StepArgs sa) {
     {
         const size_t pb = blockIdx.y;
         Xf += pb * N * 3; Xk += pb * N * 3; Qk += pb * N; valid += pb * N; ws += pb * WS_STRIDE;
     }
-    if (ws[WS_DONE] != 0.0) return;
-    const Pose<float> T = load_pose<float>(ws + WS_T);
+    __shared__ StepLds step_lds;
+    Pose<float> T;
+    if (begin_iteration(ws, sa, step_lds, T)) return;
     double acc[kSums];
 #pragma unroll
     for (int i = 0; i < kSums; ++i) acc[i] = 0.0;
@@ -162,7 +330,7 @@ k_track_accum(const float *__restrict__ Xf, const float *__restrict__ Xk, const 
         }
     }
 
-    block_reduce_store(acc, ws + WS_PART + blockIdx.x * kSums);
+    block_reduce_store(acc, ws_part(ws, sa.steps) + blockIdx.x * kSums);
 }
 
 // Calibrated variant (tracker.py:326-406, project_calib geometry.py:156-227): residual
@@ -172,13 +340,14 @@ struct TrackCalib { float fx, fy, cx, cy; int W, H; float border, z_eps; };
 __global__ void __launch_bounds__(kThreads)
 k_track_accum_calib(const float *__restrict__ Xf, const float *__restrict__ Xk, const float *__restrict__ Qk,
                     const uint8_t *__restrict__ valid, double *__restrict__ ws, int N, float huber_k,
-                    float inv_sigma_pixel, float inv_sigma_depth, const TrackCalib cal) {
+                    float inv_sigma_pixel, float inv_sigma_depth, const TrackCalib cal, const StepArgs sa) {
     {
         const size_t pb = blockIdx.y;
         Xf += pb * N * 3; Xk += pb * N * 3; Qk += pb * N; valid += pb * N; ws += pb * WS_STRIDE;
     }
-    if (ws[WS_DONE] != 0.0) return;
-    const Pose<float> T = load_pose<float>(ws + WS_T);
+    __shared__ StepLds step_lds;
+    Pose<float> T;
+    if (begin_iteration(ws, sa, step_lds, T)) return;
     double acc[kSums];
 #pragma unroll
     for (int i = 0; i < kSums; ++i) acc[i] = 0.0;
@@ -219,7 +388,7 @@ k_track_accum_calib(const float *__restrict__ Xf, const float *__restrict__ Xk, 
             acc[35] += (double)(0.5f * bb * bb);
         }
     }
-    block_reduce_store(acc, ws + WS_PART + blockIdx.x * kSums);
+    block_reduce_store(acc, ws_part(ws, sa.steps) + blockIdx.x * kSums);
 }
 
 // constrain_points_to_ray (geometry.py:273-302): keep z, move the point onto its pixel's ray
@@ -235,125 +404,40 @@ k_constrain_to_ray(const float *__restrict__ X, float *__restrict__ out, int N, 
     o[0] = ((float)px - cx) / fx * z; o[1] = ((float)py - cy) / fy * z; o[2] = z;
 }
 
-// Fixed-order final reduction of the kBlocks partial rows: wave w owns sums 9w..9w+8,
-// every lane adds rows lane, lane+64, lane+128, lane+192, then a shuffle tree.
-__device__ __forceinline__ void reduce_partials(const double *__restrict__ part, double *sums /*LDS[36]*/, int nblk) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int c = 0; c < 9; ++c) {
-        const int col = wv * 9 + c;
-        double s = 0.0;
-        for (int r = lane; r < nblk; r += 64) s += part[r * kSums + col];
-        s = m3_wave_sum(s);
-        if (lane == 0) sums[col] = s;
-    }
-    __syncthreads();
+// Results of a solve from its final state (one thread).
+// status: 0 = iteration budget used up, 1 = converged (optimizer.py:11-46), 2 = the solve FAILED (singular normal
+// matrix or a divergent step: the pose is the last good one) - what the reference reports by raising inside
+// _opt_pose_* (tracker.py:121-141), the caller then relocalises
+__device__ __forceinline__ void export_state(const double *st, const float *__restrict__ T_WCk, float *__restrict__ T_WCf_out,
+                                             float *__restrict__ T_rel_out, double *__restrict__ info) {
+    const Pose<double> T = load_pose<double>(st + WS_T);
+    store_pose(T_rel_out, T);
+    store_pose(T_WCf_out, mul(load_pose<double>(T_WCk), T));
+    info[0] = st[WS_ITERS]; info[1] = st[WS_COST]; info[2] = st[WS_TAUN];
+    info[3] = st[WS_DONE] == 2.0 ? 2.0 : st[WS_CONV];
 }
 
-// Per-iteration tail of the tracking solve, one workgroup per problem (round 3: 11.4 -> ~3 us):
-//   1. the nblk x 36 partial rows are reduced by 252 threads (thread = (row group of 7, column); rows in a fixed order),
-//      then 36 threads add the 7 group sums - one wave of independent, coalesced loads instead of nine dependent
-//      load -> shuffle-tree rounds;
-//   2. the 7 x 7 system [H + 1e-6 I | g] is solved by Gauss-Jordan elimination IN ONE WAVE, lane 8 i + j holding element
-//      (i, j) (column 7 = right-hand side): 7 steps of three broadcasts and one FMA instead of ~150 dependent float64
-//      operations on one lane.  No pivoting: the matrix is a Gram matrix plus 1e-6 I (symmetric positive definite); a
-//      pivot that is not positive and finite reports the failure the old pivoted elimination reported for a zero column;
-//   3. the retraction T <- T exp(tau) needs sin(th), cos(th), sin(th/2), cos(th/2) and exp(sigma) in float64: lanes 0-3
-//      evaluate sin at (th, th + pi/2, th/2, th/2 + pi/2) in ONE library call, lane 4 the exponential - five serial
-//      library calls before.
-__device__ __forceinline__ double bcast(double v, int src) { return __shfl(v, src, 64); }
-
+// The LAST step of a solve has no accumulation behind it to ride in: one workgroup per problem, which also exports the
+// results (T_WCf = T_WCk T_CkCf, T_CkCf, info).
 __global__ void __launch_bounds__(kThreads)
-k_track_solve(double *__restrict__ ws, float rel_error, float delta_norm, int fixed_iters, int nblk) {
-    ws += (size_t)blockIdx.x * WS_STRIDE;
-    if (ws[WS_DONE] != 0.0) return;
-    __shared__ double red[7][kSums];
-    __shared__ double sums[kSums];
-    const int t = threadIdx.x;
-    if (t < 7 * kSums) {
-        const int rg = t / kSums, col = t - rg * kSums;
-        const double *part = ws + WS_PART + col;
-        double s0 = 0.0, s1 = 0.0;
-        int r = rg;
-        for (; r + 7 < nblk; r += 14) { s0 += part[(size_t)r * kSums]; s1 += part[(size_t)(r + 7) * kSums]; }
-        if (r < nblk) s0 += part[(size_t)r * kSums];
-        red[rg][col] = s0 + s1;
-    }
-    __syncthreads();
-    if (t < kSums) sums[t] = ((red[0][t] + red[1][t]) + (red[2][t] + red[3][t])) + ((red[4][t] + red[5][t]) + red[6][t]);
-    __syncthreads();
-    if (t >= 64) return;                                   // one wave from here on; every lane of it stays active
-    const int i = (t >> 3) < 7 ? (t >> 3) : 6, j = t & 7;
-    // upper-triangular packing of the 28 sums: (a, b), a <= b -> a * 7 - a (a - 1) / 2 + (b - a)
-    const int a_ = i < j ? i : j, b_ = i < j ? j : i;
-    double e = (j < 7) ? sums[a_ * 7 - (a_ * (a_ - 1)) / 2 + (b_ - a_)] + (i == j ? 1e-6 : 0.0) : sums[28 + i];
-    const double cost = sums[35];
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        const double piv = bcast(e, 8 * k + k), rk = bcast(e, 8 * k + j), ik = bcast(e, 8 * i + k);
-        ok = ok && (piv > 0.0) && isfinite(piv);
-        const double nrk = rk / piv;
-        e = (i == k) ? nrk : e - ik * nrk;
-    }
-    double tau[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) tau[k] = bcast(e, 8 * k + 7);
-    double tn = 0.0;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) tn += tau[k] * tau[k];
-    tn = sqrt(tn);
-    // a step whose scale factor e^sigma leaves the float range (degenerate geometry) is refused like a singular system:
-    // stop and keep the pose (the reference raises inside _opt_pose_*, tracker.py:121-141)
-    if (!ok || !isfinite(tn) || fabs(tau[6]) > 30.0) {
-        if (t == 0) ws[WS_DONE] = 2.0;
-        return;
-    }
-    // exp(tau), liegroups/sim3.py:107-154 (exp_mlx of sim3_dev.h with the transcendentals shared across lanes)
-    const V3<double> v{tau[0], tau[1], tau[2]}, w{tau[3], tau[4], tau[5]};
-    const double th2 = dot(w, w), th = sqrt(th2 + 1e-10);
-    const bool small = th2 < 1e-8;
-    const double arg = (t & 2 ? 0.5 * th : th) + (t & 1 ? 1.5707963267948966 : 0.0);
-    const double tr = (t == 4) ? exp(tau[6]) : sin(arg);
-    const double sin_th = bcast(tr, 0), cos_th = bcast(tr, 1), sin_h = bcast(tr, 2), cos_h = bcast(tr, 3), es = bcast(tr, 4);
-    if (t != 0) return;
-    const double A = small ? 1.0 - th2 / 6.0 : sin_th / th;
-    const double B = small ? 0.5 - th2 / 24.0 : (1.0 - cos_th) / th2;
-    const double C = small ? 1.0 / 6.0 - th2 / 120.0 : (1.0 - A) / th2;
-    const V3<double> wv = cross(w, v);
-    Pose<double> E;
-    E.t = v + B * wv + C * cross(w, wv);
-    const double sinc_half = small ? 0.5 - th2 / 48.0 : sin_h / th;
-    const double cos_half = small ? 1.0 - th2 / 8.0 : cos_h;
-    E.q = {sinc_half * w.x, sinc_half * w.y, sinc_half * w.z, cos_half};
-    E.s = es;
-    const Pose<double> T = mul(load_pose<double>(ws + WS_T), E);
-    store_pose(ws + WS_T, T);
-    const double old = ws[WS_OLD];
-    const double rel_dec = fabs((old - cost) / (old + 1e-10));       // NaN on the first step, as in the reference
-    const bool conv = (rel_dec < (double)rel_error) || (tn < (double)delta_norm);
-    ws[WS_ITERS] += 1.0;
-    ws[WS_TAUN] = tn;
-    ws[WS_COST] = cost;
-    ws[WS_OLD] = cost;
-    if (conv && !fixed_iters) { ws[WS_DONE] = 1.0; ws[WS_CONV] = 1.0; }
+k_track_solve(double *__restrict__ ws, int steps, float rel_error, float delta_norm, int fixed_iters, int nblk,
+              const float *__restrict__ T_WCk, float *__restrict__ T_WCf_out, float *__restrict__ T_rel_out,
+              double *__restrict__ info) {
+    const size_t pb = blockIdx.x;
+    ws += pb * WS_STRIDE;
+    __shared__ StepLds L;
+    Pose<float> T;
+    track_step(ws, steps, true, rel_error, delta_norm, fixed_iters, nblk, L, T);
+    if (threadIdx.x == 0) export_state(L.st, T_WCk + 8 * pb, T_WCf_out + 8 * pb, T_rel_out + 8 * pb, info + 4 * pb);
 }
 
+// max_iters == 0: nothing was solved, the results are the initial state (k_track_init)
 __global__ void k_track_final(const double *__restrict__ ws, const float *__restrict__ T_WCk,
                               float *__restrict__ T_WCf_out, float *__restrict__ T_rel_out,
                               double *__restrict__ info) {
     if (threadIdx.x != 0) return;
-    {
-        const int pb = blockIdx.x;
-        ws += (size_t)pb * WS_STRIDE; T_WCk += 8 * pb; T_WCf_out += 8 * pb; T_rel_out += 8 * pb; info += 4 * pb;
-    }
-    Pose<double> T = load_pose<double>(ws + WS_T);
-    store_pose(T_rel_out, T);
-    store_pose(T_WCf_out, mul(load_pose<double>(T_WCk), T));
-    // status: 0 = iteration budget used up, 1 = converged (optimizer.py:11-46), 2 = the solve FAILED (singular normal
-    // matrix or a divergent step: the pose is the last good one) - what the reference reports by raising inside
-    // _opt_pose_* (tracker.py:121-141), the caller then relocalises
-    info[0] = ws[WS_ITERS]; info[1] = ws[WS_COST]; info[2] = ws[WS_TAUN];
-    info[3] = ws[WS_DONE] == 2.0 ? 2.0 : ws[WS_CONV];
+    const size_t pb = blockIdx.x;
+    export_state(ws + pb * WS_STRIDE, T_WCk + 8 * pb, T_WCf_out + 8 * pb, T_rel_out + 8 * pb, info + 4 * pb);
 }
 
 __global__ void __launch_bounds__(kThreads)
@@ -494,19 +578,22 @@ int m3_track_gn_ray_dist_batch(const float *Xf, const float *Xk, const float *Qk
     M3_REQUIRE(Xf && Xk && Qk && valid && T_WCf && T_WCk && T_WCf_out && T_CkCf_out && info && ws);
     M3_REQUIRE(N > 0 && P > 0 && P <= 65535 && max_iters >= 0 && sigma_ray > 0.f && sigma_dist > 0.f && huber_k > 0.f);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_track_init, dim3(P), dim3(64), 0, st, T_WCf, T_WCk, (const float *)nullptr, ws);
-    M3_CHECK_LAUNCH("m3_track_gn/init");
     const float isr = (float)(1.0 / (double)sigma_ray), isd = (float)(1.0 / (double)sigma_dist);
     const int nblk = track_blocks(P);
-    for (int it = 0; it < max_iters; ++it) {
-        hipLaunchKernelGGL(k_track_accum, dim3(nblk, P), dim3(kThreads), 0, st, Xf, Xk, Qk, valid, ws, N,
-                           huber_k, isr, isd);
-        hipLaunchKernelGGL(k_track_solve, dim3(P), dim3(kThreads), 0, st, ws, rel_error, delta_norm, fixed_iters, nblk);
+    if (max_iters == 0) {
+        hipLaunchKernelGGL(k_track_init, dim3(P), dim3(64), 0, st, T_WCf, T_WCk, (const float *)nullptr, ws);
+        hipLaunchKernelGGL(k_track_final, dim3(P), dim3(64), 0, st, (const double *)ws, T_WCk, T_WCf_out, T_CkCf_out, info);
+        M3_CHECK_LAUNCH("m3_track_gn/no iterations");
+        return M3_OK;
     }
+    // max_iters + 1 launches: launch 0 forms the initial pose and linearises at it; launch `it` solves step `it` (from the
+    // partials of launch it - 1) in its prologue and linearises at the result; the last step and the export share a launch
+    for (int it = 0; it < max_iters; ++it)
+        hipLaunchKernelGGL(k_track_accum, dim3(nblk, P), dim3(kThreads), 0, st, Xf, Xk, Qk, valid, ws, N,
+                           huber_k, isr, isd, StepArgs{it, rel_error, delta_norm, fixed_iters, nblk, T_WCf, T_WCk});
+    hipLaunchKernelGGL(k_track_solve, dim3(P), dim3(kThreads), 0, st, ws, max_iters, rel_error, delta_norm, fixed_iters, nblk,
+                       T_WCk, T_WCf_out, T_CkCf_out, info);
     M3_CHECK_LAUNCH("m3_track_gn/loop");
-    hipLaunchKernelGGL(k_track_final, dim3(P), dim3(64), 0, st, (const double *)ws, T_WCk, T_WCf_out,
-                       T_CkCf_out, info);
-    M3_CHECK_LAUNCH("m3_track_gn/final");
     return M3_OK;
 }
 
@@ -529,17 +616,20 @@ int m3_track_gn_calib_batch(const float *Xf, const float *Xk, const float *Qk, c
     M3_REQUIRE(sigma_pixel > 0.f && sigma_depth > 0.f && huber_k > 0.f);
     hipStream_t st = (hipStream_t)stream;
     TrackCalib cal{K4[0], K4[1], K4[2], K4[3], W, H, pixel_border, depth_eps};
-    hipLaunchKernelGGL(k_track_init, dim3(P), dim3(64), 0, st, T_WCf, T_WCk, (const float *)nullptr, ws);
     const float isp = (float)(1.0 / (double)sigma_pixel), isd = (float)(1.0 / (double)sigma_depth);
     const int nblk = track_blocks(P);
-    for (int it = 0; it < max_iters; ++it) {
-        hipLaunchKernelGGL(k_track_accum_calib, dim3(nblk, P), dim3(kThreads), 0, st, Xf, Xk, Qk, valid, ws, N,
-                           huber_k, isp, isd, cal);
-        hipLaunchKernelGGL(k_track_solve, dim3(P), dim3(kThreads), 0, st, ws, rel_error, delta_norm, fixed_iters, nblk);
+    if (max_iters == 0) {
+        hipLaunchKernelGGL(k_track_init, dim3(P), dim3(64), 0, st, T_WCf, T_WCk, (const float *)nullptr, ws);
+        hipLaunchKernelGGL(k_track_final, dim3(P), dim3(64), 0, st, (const double *)ws, T_WCk, T_WCf_out, T_CkCf_out, info);
+        M3_CHECK_LAUNCH("m3_track_gn_calib/no iterations");
+        return M3_OK;
     }
+    for (int it = 0; it < max_iters; ++it)
+        hipLaunchKernelGGL(k_track_accum_calib, dim3(nblk, P), dim3(kThreads), 0, st, Xf, Xk, Qk, valid, ws, N,
+                           huber_k, isp, isd, cal, StepArgs{it, rel_error, delta_norm, fixed_iters, nblk, T_WCf, T_WCk});
+    hipLaunchKernelGGL(k_track_solve, dim3(P), dim3(kThreads), 0, st, ws, max_iters, rel_error, delta_norm, fixed_iters, nblk,
+                       T_WCk, T_WCf_out, T_CkCf_out, info);
     M3_CHECK_LAUNCH("m3_track_gn_calib/loop");
-    hipLaunchKernelGGL(k_track_final, dim3(P), dim3(64), 0, st, (const double *)ws, T_WCk, T_WCf_out, T_CkCf_out, info);
-    M3_CHECK_LAUNCH("m3_track_gn_calib/final");
     return M3_OK;
 }
 
@@ -562,7 +652,7 @@ int m3_track_normal_eq(const float *Xf, const float *Xk, const float *Qk, const 
                        T_CkCf, ws);
     const float isr = (float)(1.0 / (double)sigma_ray), isd = (float)(1.0 / (double)sigma_dist);
     hipLaunchKernelGGL(k_track_accum, dim3(kBlocks), dim3(kThreads), 0, st, Xf, Xk, Qk, valid, ws, N, huber_k,
-                       isr, isd);
+                       isr, isd, StepArgs{0, 0.f, 0.f, 1, kBlocks, nullptr, nullptr});
     hipLaunchKernelGGL(k_track_export, dim3(1), dim3(kThreads), 0, st, (const double *)ws, out, kBlocks);
     M3_CHECK_LAUNCH("m3_track_normal_eq");
     return M3_OK;

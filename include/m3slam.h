@@ -212,6 +212,18 @@ enum { M3_FUSE_REPLACE = 0, M3_FUSE_INDEP_CONF = 1, M3_FUSE_WEIGHTED_POINTMAP = 
 int m3_fuse_pointmap(float *X_canon, float *C, const float *X_new, const float *C_new, const float *T,
                      int N, int mode, void *stream);
 
+/* "best_score" filtering (frame.py:59-73, :103-107) without the host: m3_median_f32 = the median of v[0..N) as
+ * np.median / mx.median define it (mean of the two middle order statistics, float32) by an exact radix select on the
+ * float bits - out float [1] on the device, ws uint32 [m3_median_ws_words()] scratch; any finite values, -0 < +0.
+ * m3_fuse_pointmap_if_better: best_state float [2] on the device = (best score so far, flag); if *score_new >
+ * best_state[0] the frame's pointmap is REPLACED (as M3_FUSE_REPLACE, T as above), best_state[0] <- *score_new and
+ * best_state[1] <- 1, else nothing changes and best_state[1] <- 0.  Initialise best_state[0] with the first pointmap's
+ * score (the first update always replaces, frame.py:88-92). */
+int64_t m3_median_ws_words(void);
+int m3_median_f32(const float *v, int N, uint32_t *ws, float *out, void *stream);
+int m3_fuse_pointmap_if_better(float *X_canon, float *C, const float *X_new, const float *C_new, const float *T, int N,
+                               const float *score_new, float *best_state, void *stream);
+
 /* Number of distinct values among idx[n] with valid[n] != 0 (tracker.py:153-155, mx.unique(idx[valid])),
  * values in [0, range): bitmap (atomicOr) + popcount, an exact integer.  bitmap_ws: uint32
  * [m3_count_unique_ws_words(range)] scratch; count_out: int32 [1] on the device. */

@@ -39,21 +39,31 @@ class Frame:
     N_updates: int = 0
     K: Optional[torch.Tensor] = None
     filtering_mode: Optional[str] = None    # None: config tracking.filtering_mode (frame.py:82-83)
-    _score: Optional[float] = None
+    _best: Optional[torch.Tensor] = None     # "best_score" mode: device float [2] = (best score, last update replaced)
+
+    @property
+    def _score(self) -> Optional[float]:
+        return None if self._best is None else float(self._best[0])
 
     def __post_init__(self):
         if self.T_WC is None:
             self.T_WC = identity_pose(self.img.device if self.img.is_cuda else "cuda")
 
+    def score_tensor(self, C: torch.Tensor) -> torch.Tensor:
+        """frame.py:59-73 on the device: float32 [1] = the median (mean of the two middle values for an even count, as
+        mx.median / np.median) or the mean of C - m3_median_f32 is an exact radix select, no sort and no host sync."""
+        v = _ffi.check(C.reshape(-1), torch.float32, "C")
+        if get_config()["tracking"].get("filtering_score", "median") != "median":
+            return v.mean().reshape(1)
+        out = torch.empty(1, dtype=torch.float32, device=v.device)
+        ws = torch.empty(int(_ffi.lib().m3_median_ws_words()), dtype=torch.int32, device=v.device)
+        _ffi.call("m3_median_f32", _ffi.ptr(v), v.numel(), _ffi.ptr(ws), _ffi.ptr(out), _ffi.stream_ptr())
+        return out
+
     def get_score(self, C: torch.Tensor) -> float:
-        """frame.py:59-73 (one host sync, only in "best_score" mode).  median = mean of the two middle
-        values for an even count, as mx.median / np.median."""
-        if get_config()["tracking"].get("filtering_score", "median") == "median":
-            v = C.reshape(-1).float()
-            k = v.numel()
-            hi = torch.kthvalue(v, k // 2 + 1).values
-            return float(hi) if k % 2 else float((hi + torch.kthvalue(v, k // 2).values) * 0.5)
-        return float(C.float().mean())
+        """frame.py:59-73 as the reference returns it: a host float (ONE synchronisation; update_pointmap itself does not
+        call this - its "best_score" decision stays on the device)."""
+        return float(self.score_tensor(C))
 
     def update_pointmap(self, X: torch.Tensor, C: torch.Tensor, T: Optional[torch.Tensor] = None) -> None:
         """frame.py:75-133.  X [N,3] (any shape with N*3 elements), C [N,1]; `T` ([1,8] Sim3, optional)
@@ -77,8 +87,8 @@ class Frame:
             self.C = torch.empty((n, 1), dtype=torch.float32, device=X.device)
             fuse(FUSE_REPLACE)
             self.N, self.N_updates = 1, 1
-            if mode == "best_score":
-                self._score = self.get_score(C)
+            if mode == "best_score":                      # device state: (best score so far, replaced-flag of the last update)
+                self._best = torch.cat([self.score_tensor(C), torch.ones(1, dtype=torch.float32, device=X.device)])
             return
         if self.X_canon.shape[0] != n:
             raise ValueError("pointmap size changed")
@@ -87,10 +97,13 @@ class Frame:
                 fuse(FUSE_REPLACE); self.N = 1
         elif mode == "recent":
             fuse(FUSE_REPLACE); self.N = 1
-        elif mode == "best_score":
-            s = self.get_score(C)
-            if s > (self._score or 0.0):
-                fuse(FUSE_REPLACE); self.N = 1; self._score = s
+        elif mode == "best_score":                        # frame.py:103-107: winner takes all, decided on the device
+            if self._best is None:
+                self._best = torch.zeros(2, dtype=torch.float32, device=X.device)
+            score = self.score_tensor(C)
+            _ffi.call("m3_fuse_pointmap_if_better", _ffi.ptr(self.X_canon), _ffi.ptr(self.C), _ffi.ptr(X), _ffi.ptr(C),
+                      _ffi.ptr(T), n, _ffi.ptr(score), _ffi.ptr(self._best), _ffi.stream_ptr())
+            self.N = 1
         elif mode == "indep_conf":
             fuse(FUSE_INDEP_CONF); self.N = 1
         elif mode == "weighted_pointmap":

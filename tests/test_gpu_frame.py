@@ -42,6 +42,48 @@ def test_update_pointmap_modes(dev, mode):
         config.set_config({"tracking": {"filtering_mode": "weighted_pointmap"}})
 
 
+@pytest.mark.parametrize("n", [1, 2, 5, 6, 1000, 70001, 262144])
+def test_device_median_is_exact(dev, n):
+    """m3_median_f32 (the score of "best_score" filtering, frame.py:59-73): exact radix select on the float bits - equal
+    to np.median bit for bit for odd and even counts, heavy duplicates, negative values and signed zeros."""
+    from mast3r_slam import _ffi
+    L = _ffi.lib()
+    rng = np.random.default_rng(n)
+    cases = [rng.normal(size=n).astype(np.float32),
+             (rng.integers(0, 7, size=n) / 3.0).astype(np.float32),                     # few distinct values
+             np.concatenate([np.zeros(n // 2, np.float32), -np.zeros(n - n // 2, np.float32)]),
+             (rng.uniform(0.5, 4.0, size=n) * 10.0 ** rng.integers(-20, 20, size=n)).astype(np.float32)]
+    for v in cases:
+        d = torch.from_numpy(v).to(dev)
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        ws = torch.empty(int(L.m3_median_ws_words()), dtype=torch.int32, device=dev)
+        _ffi.call("m3_median_f32", _ffi.ptr(d), n, _ffi.ptr(ws), _ffi.ptr(out), _ffi.stream_ptr())
+        ref = np.median(v)
+        got = out.cpu().numpy()[0]
+        assert got == ref or (np.isnan(got) and np.isnan(ref)), (n, got, ref)
+
+
+@pytest.mark.parametrize("score", ["median", "mean"])
+def test_best_score_mode_decides_on_the_device(dev, score):
+    """Winner takes all (frame.py:103-107) with an EVEN point count and both score kinds; the decision and the running best
+    score live in a device buffer (no host synchronisation inside update_pointmap)."""
+    n = 4096
+    config.set_config({"tracking": {"filtering_mode": "best_score", "filtering_score": score}})
+    try:
+        f = create_frame(0, torch.zeros(3, 16, 16, device=dev))
+        o = OF.FrameState("best_score", score)
+        for k, scale in enumerate((1.0, 0.6, 1.7, 1.2, 1.7, 2.5)):
+            X, C = _cloud(n, 40 + k)
+            C = (C * scale).astype(np.float32)
+            f.update_pointmap(torch.from_numpy(X).to(dev), torch.from_numpy(C).to(dev))
+            o.update_pointmap(X, C)
+            assert np.array_equal(f.X_canon.cpu().numpy(), o.X_canon) and np.array_equal(f.C.cpu().numpy(), o.C)
+            assert (f.N, f.N_updates) == (o.N, o.N_updates)
+            assert abs(f._score - o._score) <= 1e-6 * abs(o._score)
+    finally:
+        config.set_config({"tracking": {"filtering_mode": "weighted_pointmap", "filtering_score": "median"}})
+
+
 def test_fused_sim3_act_update(dev):
     """keyframe.update_pointmap(T_CkCf.act(Xkf), Ckf) (tracker.py:146-147) in one kernel."""
     n = 4096

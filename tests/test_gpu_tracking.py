@@ -84,6 +84,28 @@ def test_full_size_recovers_known_sim3_and_is_deterministic(dev):
     assert np.abs(np.abs(T[3:7]) - np.abs(pr["T_true"][3:7])).max() < 1e-3
 
 
+@pytest.mark.parametrize("iters", [0, 1, 2, 3])
+def test_iteration_budgets_across_the_double_buffered_state(dev, iters):
+    """One launch per iteration: the step that follows an accumulation runs in the prologue of the NEXT launch and the
+    state / partial buffers alternate by parity - budgets of 0 (no launch at all: the initial relative pose comes back),
+    1 (launch 0 + the stand-alone last step), 2 and 3 (odd / even final slots) must all agree with the oracle loop."""
+    pr = _problem(40, 56, 11)
+    cfg = dict(max_iters=iters)
+    Tf, Trel, info = tracker.opt_pose_ray_dist_sim3(_t(pr["Xf"], dev), _t(pr["Xk"], dev), _t(pr["T_WCf"], dev),
+                                                    _t(pr["T_WCk"], dev), _t(pr["Qk"], dev), _t(pr["valid"], dev), cfg,
+                                                    fixed_iters=True)
+    info = info.cpu().numpy()
+    assert int(info[0]) == iters and info[3] == 0.0
+    if iters == 0:
+        T0 = S.sim3_mul_mlx(S.sim3_inv_mlx(pr["T_WCk"].astype(np.float64)), pr["T_WCf"].astype(np.float64))
+        assert np.abs(Trel.cpu().numpy() - T0).max() < 1e-6
+        return
+    To, Trel_o, io = ot.opt_pose_ray_dist_sim3(pr["Xf"], pr["Xk"], pr["T_WCf"], pr["T_WCk"], pr["Qk"], pr["valid"],
+                                               fixed_iters=iters)
+    assert np.abs(Trel.cpu().numpy() - Trel_o).max() < 5e-5
+    assert np.abs(Tf.cpu().numpy() - To).max() < 5e-5
+
+
 def test_all_invalid_and_degenerate_input_do_not_crash(dev):
     pr = _problem(16, 16, 7)
     zeros = np.zeros_like(pr["valid"])

@@ -92,14 +92,33 @@ def opt_pose_ray_dist_sim3(Xf, Xk, T_WCf, T_WCk, Qk, valid, cfg=None, fixed_iter
     return out_f[0], out_rel[0], info[0]
 
 
+_K4_CACHE: dict = {}
+
+
 def _k4(K):
-    """[3,3] or (fx, fy, cx, cy) -> ctypes float[4] (host)."""
+    """[3,3] or (fx, fy, cx, cy) -> ctypes float[4] (host).  The intrinsics are launch PARAMETERS of the calibrated
+    kernels; a device tensor is pulled to the host once per (storage, version) - not once per frame: with use_calib the
+    tracker calls this three times per frame, each a host synchronisation in the first version."""
     import ctypes
 
     import numpy as np
-    Kh = K.detach().cpu().numpy() if isinstance(K, torch.Tensor) else np.asarray(K)
+    import weakref
+    key = None
+    if isinstance(K, torch.Tensor):
+        key = id(K)
+        hit = _K4_CACHE.get(key)
+        if hit is not None and hit[0]() is K and hit[1] == K._version:      # the SAME tensor object, unmodified since
+            return hit[2]
+        Kh = K.detach().cpu().numpy()
+    else:
+        Kh = np.asarray(K)
     vals = (Kh[0, 0], Kh[1, 1], Kh[0, 2], Kh[1, 2]) if Kh.shape == (3, 3) else tuple(Kh.reshape(-1)[:4])
-    return (ctypes.c_float * 4)(*[float(v) for v in vals])
+    out = (ctypes.c_float * 4)(*[float(v) for v in vals])
+    if key is not None:
+        if len(_K4_CACHE) > 64:
+            _K4_CACHE.clear()
+        _K4_CACHE[key] = (weakref.ref(K), K._version, out)
+    return out
 
 
 def constrain_points_to_ray(img_size, Xs, K):

@@ -584,6 +584,33 @@ class PairsWorkload:
                 run1()
             torch.cuda.synchronize()
             ms1 = (time.perf_counter() - t1) / 10 * 1e3
+            # the tracker's real per-frame call (mast3r_match_asymmetric, mast3r_utils.py:451-500, with frame.feat cached as
+            # this repo's operator does): the KEYFRAME's encoder tokens exist already, only the new frame is encoded
+            tok_kf, grid1 = net.encode_tokens(b1)
+            tok_kf = tok_kf.clone()
+
+            def step1_cached():
+                tok_f, _ = net.encode_tokens(a1)
+                net.decode_heads(tok_f, tok_kf, 1, grid1)
+                i1, v1 = matching.match(s1["X11"], s1["X21"], s1["D11"], s1["D21"])
+                Xf, Qk, vo1, vk, cnt = tracker.track_gather(s1["X11"].reshape(1, n, 3), s1["Cf"], s1["Ck"], s1["Qf"], s1["Qk"],
+                                                            i1, v1.reshape(1, n), tcfg["C_conf"], tcfg["Q_conf"])
+                return tracker.opt_pose_ray_dist_sim3(Xf, s1["Xk"], ident, ident, Qk, vo1, tcfg, fixed_iters=True)
+            for _ in range(2):
+                step1_cached()
+            torch.cuda.synchronize()
+            run1c = step1_cached
+            if self.graphs is not None:
+                g1c = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1c):
+                    keepc = step1_cached()  # noqa: F841
+                run1c = g1c.replay
+            run1c(); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                run1c()
+            torch.cuda.synchronize()
+            ms1c = (time.perf_counter() - t1) / 10 * 1e3
             from mast3r_slam import ops
             ops.PROFILE = []
             net.reconstruct_batch(a1, b1)
@@ -593,6 +620,9 @@ class PairsWorkload:
             sec = sum(p[2].elapsed_time(p[3]) for p in prof1) * 1e-3
             result["batch1"] = {"workload": "BASELINE configs[1]: 1 pair/step at 512x512, same pipeline", "pairs_per_s": 1e3 / ms1,
                                 "ms_per_pair": ms1,
+                                "ms_per_frame_with_cached_keyframe_tokens": ms1c,
+                                "cached_note": "the per-frame tracking call: the keyframe's encoder tokens are cached (Frame.feat), one image is "
+                                               "encoded, then decoders + heads + match + 10 GN iterations",
                                 "roofline": {"bound": "mfma", "kernel": "all MFMA kernels of one pair (dense GEMMs, convolutions, attention)",
                                              "achieved": fl / sec / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                              "frac": fl / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS,

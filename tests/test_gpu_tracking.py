@@ -157,9 +157,11 @@ def test_batched_solve_equals_loop_of_single_solves(dev):
         assert cnt[b].cpu().tolist()[1] == int((vm[b] & (np.sqrt(Q[b][idx[b]] * Q[b]) > 1.5)).sum())
 
 
-def test_calibrated_tracking_matches_oracle(dev):
-    """opt_pose_calib_sim3 (tracker.py:326-406) vs the float64 oracle; also constrain_points_to_ray."""
-    h, w = 48, 64
+@pytest.mark.parametrize("h,w", [(48, 64), (48, 62), (33, 47)])
+def test_calibrated_tracking_matches_oracle(dev, h, w):
+    """opt_pose_calib_sim3 (tracker.py:326-406) vs the float64 oracle; also constrain_points_to_ray.  64-wide rows take the
+    four-points-per-lane path of k_track_accum_calib, widths that are not multiples of 4 (and odd point counts) the
+    one-point path."""
     K = np.array([[float(w), 0, w / 2], [0, float(w), h / 2], [0, 0, 1]], dtype=np.float32)
     pr = synthetic.tracking_problem(h, w, seed=8)
     Xk_c = ot.constrain_points_to_ray((h, w), pr["Xk"].astype(np.float64), K.astype(np.float64))

@@ -302,7 +302,12 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
         bj[j] = (g.bias && n < g.N) ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (F32LDS) {
-        constexpr int RS = NJ * 64 + 16;                          // 16*NJ fp32 + 16 bytes of padding
+        // fp32 output of 64-column sub-tiles: unpadded 256-byte rows, 16-byte chunk c of row r at chunk c ^ (r & 7) - the
+        // 8 consecutive lanes (= 8 rows at one column quad) a ds_write_b128 is served in hit 8 different chunks (32 banks),
+        // and the 16-lane groups of the ds_read_b128 (half a row + the complementary half of the next) every bank once.
+        // (272-byte padded rows before: conflict-free writes, 2-way reads.)
+        constexpr bool SWZ32 = F32OUT && (NJ == 4);
+        constexpr int RS = SWZ32 ? 256 : NJ * 64 + 16;            // 16*NJ fp32 (+ 16 bytes of padding)
         constexpr bool RESID = (EPI == EPI_F32_ACCUM || EPI == EPI_BF16_ADD);
         constexpr int PT = RESID ? 1 : 2;                         // accumulator row tiles per pass (residual tiles are
         constexpr int PR = 16 * PT;                               // double-buffered in registers: keep a pass small)
@@ -335,7 +340,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const f32x4 v = acc[pass * PT + ii][j];
-                    *reinterpret_cast<float4 *>(wlds + (ii * 16 + r) * RS + (j * 16 + gq * 4) * 4) =
+                    *reinterpret_cast<float4 *>(wlds + (ii * 16 + r) * RS + ((SWZ32 ? ((j * 4 + gq) ^ (r & 7)) : (j * 4 + gq)) << 4)) =
                         make_float4(v[0] + bj[j].x, v[1] + bj[j].y, v[2] + bj[j].z, v[3] + bj[j].w);
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -343,7 +348,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     const int c = it * 64 + lane, rl = c / CPR, ch = c - rl * CPR;
-                    float4 v = *reinterpret_cast<const float4 *>(wlds + rl * RS + ch * 16);
+                    float4 v = *reinterpret_cast<const float4 *>(wlds + rl * RS + ((SWZ32 ? (ch ^ (rl & 7)) : ch) << 4));
                     const int m = m_base + pass * PR + rl, n = n_base + ch * 4;
                     if (EPI == EPI_F32_ACCUM) {
                         const uint4 u = q[pass & 1][it];
@@ -372,7 +377,18 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
             asm volatile("" ::: "memory");
         }
     } else {
-        constexpr int RS = NJ * 32 + 16;                          // 16*NJ bf16 + 16 bytes of padding
+        // 64-column sub-tiles (NJ = 4: 128-byte rows) use an UNPADDED scratch: the 16-byte chunk c of row r is stored at
+        // chunk c ^ ((r >> 1) & 7), and odd rows store the two 8-byte halves of a chunk swapped.
+        //   reads  (ds_read_b128: four groups of 16 lanes, {0-3, 12-15, 20-27} ..., 64 banks): a group covers two half
+        //          rows and one row pair; consecutive rows sit 32 banks apart and the XOR moves row pairs to different
+        //          chunks - every bank once;
+        //   writes (ds_write_b64: four groups of 16 CONSECUTIVE lanes = 16 rows at one column quad, 32 banks): the row
+        //          offset (128 B) vanishes mod 32 banks, the XOR gives the 8 row pairs 8 different chunks and the half
+        //          swap separates the two rows of a pair - every bank once.
+        // The first form padded rows to 144 bytes: 2-way conflicts on both sides, SQ_LDS_BANK_CONFLICT ~1500 cycles per
+        // 256 x 256 tile (profiles/r03_gemm_pmc.md).  Other widths keep the padded rows.
+        constexpr bool SWZ = (NJ == 4);
+        constexpr int RS = SWZ ? 128 : NJ * 32 + 16;              // 16*NJ 16-bit values (+ 16 bytes of padding)
         constexpr int TP = NI < 4 ? NI : 4;                       // accumulator row tiles per pass
         constexpr int PR = 16 * TP, CPR = NJ * 2;                 // rows per pass, 16-byte chunks (8 columns) per row
         RopeFreq fr{};
@@ -402,14 +418,18 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
                     }
                     uint2 pk;
                     pk.x = pack16<DT>(v[0], v[1]); pk.y = pack16<DT>(v[2], v[3]);
-                    *reinterpret_cast<uint2 *>(wlds + (ii * 16 + r) * RS + (j * 16 + gq * 4) * 2) = pk;
+                    if constexpr (SWZ)
+                        *reinterpret_cast<uint2 *>(wlds + (ii * 16 + r) * RS + (((j * 2 + (gq >> 1)) ^ ((r >> 1) & 7)) << 4) + (((gq ^ r) & 1) << 3)) = pk;
+                    else
+                        *reinterpret_cast<uint2 *>(wlds + (ii * 16 + r) * RS + (j * 16 + gq * 4) * 2) = pk;
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int it = 0; it < PR * CPR / 64; ++it) {
                 const int c = it * 64 + lane, rl = c / CPR, ch = c - rl * CPR;
-                const uint4 v = *reinterpret_cast<const uint4 *>(wlds + rl * RS + ch * 16);
+                uint4 v = *reinterpret_cast<const uint4 *>(wlds + rl * RS + ((SWZ ? (ch ^ ((rl >> 1) & 7)) : ch) << 4));
+                if (SWZ && (rl & 1)) v = uint4{v.z, v.w, v.x, v.y};
                 const int m = m_base + pass * PR + rl, n = n_base + ch * 8;
                 if (m < g.M && n < g.N)
                     *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(g.C) + (size_t)m * g.ldc + n) = v;

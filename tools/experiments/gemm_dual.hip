@@ -5,11 +5,10 @@
 // torch.mm): 13-34 % SLOWER than the ping-pong kernel on every shape - enc qkv+RoPE 105.3 -> 121.6 us, fc1+GELU 137.5 ->
 // 157.7, fc2+residual 119.5 -> 149.4, proj 47.5 -> 58.1, feature fc2 (K = 7168, 6 rounds) 1351 -> 1808 (1113 -> 831
 // TFLOP/s).  The epilogue does overlap, but the K loop loses more than that returns: (i) a 256x128 tile stages
-// 24 KiB per 32 of K for 4 waves = 6 LDS-DMA issues per wave and k-step against 4 in the 256x256 tile, and with the 12
-// fragment reads the two workgroups of a CU ask the LDS for 144 KiB per 1024 matrix-pipe cycles - more than its
-// 128 B/clk can deliver (the ping-pong kernel sits at exactly 100 %: 48 KiB of reads + 16 KiB of DMA per 512-cycle
-// phase); (ii) nothing but s_setprio orders the two workgroups, so reads and MFMAs of the waves that share a SIMD
-// collide instead of alternating.
+// 24 KiB per 32 of K for 4 waves = 6 LDS-DMA issues per wave and k-step against 4 in the 256x256 tile (an issue occupies
+// the issuing wave for 60-185 cycles) and every k-step ends in a workgroup barrier; (ii) nothing but s_setprio orders
+// the two workgroups, so the read / load phases and the MFMA blocks of the waves that share a SIMD collide instead of
+// alternating - the barrier-enforced alternation of the ping-pong kernel is what keeps its matrix pipe at 77-79 %.
 //
 // Why: k_gemm256 (gemm256.hip) runs one 8-wave workgroup per CU.  Its K loop sits at the practical ceiling of the
 // matrix pipe (77-79 % duty), but prologue and epilogue of a tile run with the pipe idle: at K = 1024 a 256x256 tile

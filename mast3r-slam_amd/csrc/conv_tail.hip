@@ -167,12 +167,19 @@ k_conv_tail(const TailArgs ain) {
     // halo fragment addresses: the swizzle depends on the halo COLUMN only (chunk' = chunk ^ ((hx >> 1) & 7)), so the
     // per-lane part is one of six column offsets (kx = 0..2, left / right 16-pixel tile) and the rest is uniform:
     // 12 address instructions per read phase (a per-pixel swizzle cost ~100, as much VALU time as the MFMAs took)
+    // MFMA row t of a 16-pixel tile is PIXEL kPixOf[t], not pixel t: a ds_read_b128 is served in the lane groups
+    // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+ 32) - all 16 rows at two different k-chunks - and with the natural
+    // order two of the three tap shifts kx put two lanes of a group on the same (pixel parity, swizzled chunk) = the same
+    // banks: SQ_LDS_BANK_CONFLICT was 24 % of the kernel's LDS cycles, 7 % of its time.  This order (found by search
+    // over the 16! permutations, swizzle unchanged) is conflict-free for kx = 0, 1, 2, both tile halves and all four
+    // groups; the epilogue maps accumulator rows back through the same table.
+    const int pix_of_row = (int)((0x3D9F2A40E6C851B7ULL >> (4 * frow)) & 15);     // {7,11,1,5,8,12,6,14,0,4,10,2,15,9,13,3}
     int colofs[3][2];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
-            const int hx = h2 * 16 + frow + kx;
+            const int hx = h2 * 16 + pix_of_row + kx;
             colofs[kx][h2] = hx * 128 + ((fch ^ ((hx >> 1) & 7)) << 4);
         }
     auto read_frags = [&](int g, int ks) {
@@ -313,7 +320,7 @@ k_conv_tail(const TailArgs ain) {
         const int i = 4 * wc + gq;
         const float4 p0 = *reinterpret_cast<const float4 *>(red + (((wp * 2 + 0) * 8 + i) * 16 + r) * 4);
         const float4 p1 = *reinterpret_cast<const float4 *>(red + (((wp * 2 + 1) * 8 + i) * 16 + r) * 4);
-        const int oy = oy0 + wp * 4 + (i >> 1), ox = ox0 + (i & 1) * 16 + r;
+        const int oy = oy0 + wp * 4 + (i >> 1), ox = ox0 + (i & 1) * 16 + pix_of_row;      // r == frow
         if (ox < a.W) {                                       // W = 16 (mod 32): the tile's right half is outside
             const float x = p0.x + p1.x + a.b4[0], y = p0.y + p1.y + a.b4[1];
             const float z = p0.z + p1.z + a.b4[2], c = p0.w + p1.w + a.b4[3];

@@ -174,21 +174,17 @@ k_conv_tail(const TailArgs ain) {
     // over the 16! permutations, swizzle unchanged) is conflict-free for kx = 0, 1, 2, both tile halves and all four
     // groups; the epilogue maps accumulator rows back through the same table.
     const int pix_of_row = (int)((0x3D9F2A40E6C851B7ULL >> (4 * frow)) & 15);     // {7,11,1,5,8,12,6,14,0,4,10,2,15,9,13,3}
-    int colofs[3][2];
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-            const int hx = h2 * 16 + pix_of_row + kx;
-            colofs[kx][h2] = hx * 128 + ((fch ^ ((hx >> 1) & 7)) << 4);
-        }
+    // (A table colofs[kx][half] of the six column offsets, indexed by the runtime tap column, was placed in SCRATCH memory by
+    // the compiler: two scratch loads - a vector-memory round trip - in front of every tap's fragment reads.  The ten VALU
+    // instructions that compute the two offsets cost nothing next to that.)
+    auto col_offset = [&](int hx) { return hx * 128 + ((fch ^ ((hx >> 1) & 7)) << 4); };
     auto read_frags = [&](int g, int ks) {
         const int tap = g >= 9 ? g - 9 : g;
         const int ky = tap / 3, kx = tap - ky * 3;
         const unsigned char *wsrc = wst + (g & 1) * kWStage;
         const int flip = ks << 6;
-        const int c0 = (kx == 0 ? colofs[0][0] : kx == 1 ? colofs[1][0] : colofs[2][0]) ^ flip;
-        const int c1 = (kx == 0 ? colofs[0][1] : kx == 1 ? colofs[1][1] : colofs[2][1]) ^ flip;
+        const int c0 = col_offset(pix_of_row + kx) ^ flip;
+        const int c1 = col_offset(16 + pix_of_row + kx) ^ flip;
         const unsigned char *rowp = halo + (wp * 4 + ky) * (HW * 128);
 #pragma unroll
         for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8 *>(wsrc + (w_off[j] ^ flip));

@@ -373,15 +373,30 @@ k_refine_lds(const TD *__restrict__ D11, const TD *__restrict__ D21, const int32
     const int rw = x1 - x0 + 1, rh = y1 - y0 + 1;
     int bx = cx, by = cy;
     if (rw > 0 && rh > 0 && (long long)rw * rh <= kMaxPix) {            // uniform over the workgroup
-        const int per_row = rw * CH;
-        for (int i = threadIdx.x; i < rh * per_row; i += kThreads) {
-            const int ry = i / per_row, rem = i - ry * per_row;
-            const int rx = rem / CH, k = rem - rx * CH;
-            float v[V];
-            DescIO<TD>::load16(img + ((size_t)(y0 + ry) * W + x0 + rx) * D + k * V, v);
-            float4 *dst = tile + (ry * rw + rx) * PS4 + k * (V / 4);
+        // Staging, four 16-byte pieces per thread IN FLIGHT: the first form loaded, waited and stored one piece per loop
+        // trip - ~14 dependent L2 round trips per workgroup, ~40 % of the kernel (profiles/r03_matcher_pmc.md: the fp16
+        // variant, which stages half the pieces, was 50-65 us faster for that reason alone).
+        const int per_row = rw * CH, total = rh * per_row;
+        constexpr int U = 4;                                   // (8 in flight measured the same)
+        for (int i0 = threadIdx.x; i0 < total; i0 += kThreads * U) {
+            float v[U][V];
+            int dofs[U];
 #pragma unroll
-            for (int j = 0; j < V / 4; ++j) dst[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * kThreads;
+                const int ic = i < total ? i : total - 1;             // clamped: the load is harmless, the store is skipped
+                const int ry = ic / per_row, rem = ic - ry * per_row;
+                const int rx = rem / CH, k = rem - rx * CH;
+                DescIO<TD>::load16(img + ((size_t)(y0 + ry) * W + x0 + rx) * D + k * V, v[u]);
+                dofs[u] = (ry * rw + rx) * PS4 + k * (V / 4);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (i0 + u * kThreads >= total) continue;
+                float4 *dst = tile + dofs[u];
+#pragma unroll
+                for (int j = 0; j < V / 4; ++j) dst[j] = make_float4(v[u][4 * j], v[u][4 * j + 1], v[u][4 * j + 2], v[u][4 * j + 3]);
+            }
         }
         __syncthreads();
         float best = -INFINITY;

@@ -84,18 +84,18 @@ def parse(argv=None):
 def launch(args) -> int:
     """Start one child process per rank (before this process has imported torch or touched the GPU: children are
     plain fork+exec of the interpreter), relay rank 0's stdout, return non-zero if any rank failed."""
-    import socket
     import subprocess
+    import tempfile
     import threading
     n = args.gpus
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    # rendezvous through a file in a directory of this launch's own (torch.distributed FileStore): no TCP port is
+    # guessed, so launchers started at the same moment (tests, concurrent benches) cannot collide or cross-connect
+    rdzv_dir = tempfile.mkdtemp(prefix="m3bench_rdzv_")
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), M3_BENCH_SPAWNED="1")
+                   M3_BENCH_RDZV_FILE=os.path.join(rdzv_dir, "store"), M3_BENCH_SPAWNED="1")
+        env.pop("MASTER_PORT", None)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
@@ -123,6 +123,8 @@ def launch(args) -> int:
         except subprocess.TimeoutExpired:
             p.kill()
     reader.join(timeout=10)
+    import shutil
+    shutil.rmtree(rdzv_dir, ignore_errors=True)
     sys.stdout.write("".join(lines))
     sys.stdout.flush()
     if rc == 0 and not any(l.startswith("{") for l in lines):
@@ -557,6 +559,8 @@ class PairsWorkload:
                                          "peak": HBM_PEAK_GBS, "frac": round(by_c / us_c / 1e3 / HBM_PEAK_GBS, 4),
                                          "status": [int(x) for x in info_c[:, 3].tolist()][:2]}
 
+        self._backend_block(result, args)
+
         if P != 1:
             # BASELINE configs[1]: one pair per step (latency regime), same pipeline, graph-replayed
             net, ident = self.net, self.ident
@@ -629,13 +633,45 @@ class PairsWorkload:
                                              "whole_pair_frac": net.flops_per_pair(self.h, self.w) / (ms1 * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}}
 
 
+    def _backend_block(self, result, args, edges: int = 16, steps: int = 2):
+        """BASELINE configs[4] in the default line: a short run of the backend workload (`--workload backend`, reference flow
+        slam.py:292-319 -> global_opt.py:49-166) after the timed region - `edges` undirected edges of the 256-keyframe graph
+        through the FULL network (symmetric decode from cached tokens, both match directions on fp16 features), the rays-GN
+        blocks of their directed edges and the 1785-unknown dense step.  The pairs model is reused (same weights; the
+        descriptor output switched to half storage)."""
+        import copy
+        torch = self.torch
+        bargs = copy.copy(args)
+        bargs.keyframes, bargs.edges_per_gpu, bargs.edge_batch, bargs.gn_iters, bargs.no_cpu_baseline = 256, edges, 8, 1, True
+        net16 = copy.copy(self.net)
+        net16.desc_dtype = torch.float16
+        wl = BackendWorkload(bargs, self.ctx, net=net16)
+        wl.warm()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            wl.step(timed=True)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        r = {}
+        wl.report(r, bargs)
+        result["backend"] = {"workload": r["config"]["workload"], "edges_per_s": wl.total_edges / (ms * 1e-3), "ms_per_step": ms,
+                             "steps": steps, "stage_ms": r["stage_ms"], "match_valid_frac": r["match_valid_frac"],
+                             "edges_kept": r["edges_kept"], "pose_max_abs_err_before_after": r["pose_max_abs_err_before_after"],
+                             "hbm_rooflines": {"m3_gn_rays_blocks": r["hbm_rooflines"].get("m3_gn_rays_blocks")},
+                             "dense_step": r["dense_step"], "roofline": r["roofline"],
+                             "note": "outside the timed region of this command; `python bench.py --workload backend` times the "
+                                     "96-edge per-GPU shard of BASELINE configs[4] as the headline"}
+        del wl
+
+
 class BackendWorkload:
     """BASELINE configs[4] per-GPU shard.  reference flow: slam.py:292-319 -> global_opt.py:49-138 (add_factors with
     mast3r_match_symmetric) -> :168-211 (solve_GN_rays) -> kernels.py:262-322."""
     unit, metric = "edges/s", "graph-edges/sec (256-keyframe loop-closure re-match + local-BA blocks + 1785-dim step, fp16 features)"
     dtype = "bf16"
 
-    def __init__(self, args, ctx):
+    def __init__(self, args, ctx, net=None):
         import numpy as np
         import torch
         from mast3r_slam import config, frame as frame_mod, matching, model as model_mod, synthetic
@@ -647,7 +683,9 @@ class BackendWorkload:
         config.set_config({"matching": {"use_simple": False}})
         self.lcfg = config.get_config()["local_opt"]
         cfg = model_mod.TINY_CFG if args.model == "tiny" else None
-        self.net = model_mod.Mast3rFull(seed=0, device=dev, precision="bf16", cfg=cfg, features="fp16")
+        if net is None:
+            net = model_mod.Mast3rFull(seed=0, device=dev, precision="bf16", cfg=cfg, features="fp16")
+        self.net = net
         K = self.K = args.keyframes
         ii, jj = synthetic.chain_edges(K)
         tot = min(len(ii), ctx.world * args.edges_per_gpu)            # weak scaling: 96 edges per rank, all 762 at N = 8
@@ -875,12 +913,17 @@ def run_rank(args) -> int:
         dev = torch.device("cuda", local)
     if world > 1 or args.force_dist:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
+        rdzv = os.environ.get("M3_BENCH_RDZV_FILE")                   # set by launch(): per-launch FileStore, no port
+        if rdzv:
+            kw = dict(init_method="file://" + rdzv)
+        else:                                                        # external launcher: its MASTER_ADDR / MASTER_PORT
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            kw = {}
         if args.stub or args.dist_backend == "gloo":
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, **kw)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, **kw)
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
     ctx = SimpleNamespace(rank=rank, world=world, local=local, dev=dev, dist=dist, group=None if dist is None else dist.group.WORLD)

@@ -296,7 +296,11 @@ int m3_gn_rays_step(float *Twc, const double *blocks, const int32_t *ii, const i
  * Cholesky (block 64), stream-ordered.  H [dim,dim] row-major (lower triangle read; destroyed), b [dim]
  * (destroyed), x [dim], ws double[m3_chol_ws_doubles(dim)]: ws[0] = 0 ok / 1 not positive definite (the rest is
  * scratch: the substitution vector and the 64 x 64 diagonal factors, which are kept OUT of H so that no
- * workgroup of a panel launch ever reads a diagonal block another one has already overwritten). */
+ * workgroup of a panel launch ever reads a diagonal block another one has already overwritten).
+ * The backward substitution is ONE launch whose workgroups hand x_k to each other through device flags; a consumer
+ * always has a higher workgroup index than its producer, i.e. the chain assumes workgroups are dispatched in index
+ * order (true on gfx950, not promised by HIP).  The wait is bounded: if a producer has not published after ~0.3 s
+ * of polling the launch gives up and ws[0] = 1 (status "failed"), it never hangs the stream. */
 int64_t m3_chol_ws_doubles(int dim);
 int m3_chol_solve(double *H, double *b, double *x, double *ws, int dim, double shift, void *stream);
 

@@ -442,6 +442,9 @@ int m3_layernorm_dual2_dt(const float *x, const float *ga0, const float *ba0, co
 
 int m3_patchify16_dt(const uint8_t *img, void *A, int B, int H, int W, int dtype, void *stream) {
     M3_REQUIRE(img && A && B > 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0);
+    // k_patchify reads the image with 8-byte loads and stores 16-byte pieces: a uint8 view with an odd storage offset is
+    // a status, not a misaligned vector access
+    M3_REQUIRE(reinterpret_cast<uintptr_t>(img) % 8 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0);
     M3_DT_OK(dtype);
     const int64_t total = (int64_t)B * (H / 16) * (W / 16) * 32;      // 8 pixels x 3 channels per thread
     M3_DT_LAUNCH(dtype, k_patchify, dim3(m3_cdiv(total, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, img,

@@ -287,13 +287,16 @@ k_chol_update(double *__restrict__ H, int dim, int k, const double *__restrict__
 // consumer can never keep its producer off the machine.  The tile of the next term is fetched BEFORE its flag is
 // awaited: a stage of the chain costs one flag hand-over + 64 x 64 multiply-adds + the triangular product from LDS.
 // (28 dependent launches of ~10 us each before.)
+constexpr unsigned kChainPolls = 1u << 23;
 __global__ void __launch_bounds__(kThreads)
 k_chol_bwd_chain(const double *__restrict__ H, const double *__restrict__ Li, const double *__restrict__ yv, double *xout,
-                 unsigned *flags, int dim, int nblk, const double *__restrict__ fail, const double *__restrict__ off) {
+                 unsigned *flags, int dim, int nblk, double *fail, const double *__restrict__ off) {
     if (solve_off(off) || fail[0] != 0.0) return;
     __shared__ double li[NB][NB + 1];
     __shared__ double xs[NB], v[NB];
     __shared__ double red[kThreads / NB][NB];
+    __shared__ int bail;
+    if (threadIdx.x == 0) bail = 0;
     const int t = threadIdx.x, k = nblk - 1 - (int)blockIdx.x, k0 = k * NB, nb = min(NB, dim - k0);
     const double *I = Li + (size_t)k * NB * NB;
     for (int idx = t; idx < NB * NB; idx += kThreads) li[idx >> 6][idx & 63] = I[idx];
@@ -309,9 +312,24 @@ k_chol_bwd_chain(const double *__restrict__ H, const double *__restrict__ Li, co
     };
     if (k < nblk - 1) load_tile(nblk - 1);
     for (int i = nblk - 1; i > k; --i) {
-        if (t == 0)
-            while (__hip_atomic_load(&flags[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);
+        if (t == 0) {
+            // The wait is BOUNDED (kChainPolls polls of >= 64 cycles each, ~0.3 s): the chain relies on workgroups being
+            // dispatched in index order (see above and include/m3slam.h), which HIP does not promise; if a producer never
+            // shows up the solve reports failure through fail[0] instead of hanging the stream.
+            unsigned polls = 0;
+            while (__hip_atomic_load(&flags[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                if (++polls > kChainPolls) { bail = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
         __syncthreads();
+        if (bail) {                                          // workgroup-uniform: give up, tell the host, release consumers
+            if (t == 0) {
+                __hip_atomic_store(&fail[0], 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&flags[k], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (t < NB) xs[t] = i * NB + t < dim ? __hip_atomic_load(&xout[i * NB + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
         __syncthreads();
@@ -361,7 +379,7 @@ int m3_chol_solve_launch(double *H, double *b, double *y, double *x, double *Ld,
         }
     }
     hipLaunchKernelGGL(k_chol_bwd_chain, dim3(nblk), dim3(kThreads), 0, st, (const double *)H, (const double *)Li,
-                       (const double *)y, x, flags, dim, nblk, (const double *)fail, off);
+                       (const double *)y, x, flags, dim, nblk, fail, off);
     M3_CHECK_LAUNCH("m3_chol_solve");
     return M3_OK;
 }

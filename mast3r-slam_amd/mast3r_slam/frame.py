@@ -43,7 +43,16 @@ class Frame:
 
     @property
     def _score(self) -> Optional[float]:
+        """frame.py's host-side `_score` (read-only view of the device state; one synchronisation per read)."""
         return None if self._best is None else float(self._best[0])
+
+    @_score.setter
+    def _score(self, value: Optional[float]) -> None:
+        if value is None:
+            self._best = None
+        else:
+            dev = self._best.device if self._best is not None else (self.img.device if self.img.is_cuda else "cuda")
+            self._best = torch.tensor([float(value), 0.0], dtype=torch.float32, device=dev)
 
     def __post_init__(self):
         if self.T_WC is None:
@@ -103,7 +112,10 @@ class Frame:
             score = self.score_tensor(C)
             _ffi.call("m3_fuse_pointmap_if_better", _ffi.ptr(self.X_canon), _ffi.ptr(self.C), _ffi.ptr(X), _ffi.ptr(C),
                       _ffi.ptr(T), n, _ffi.ptr(score), _ffi.ptr(self._best), _ffi.stream_ptr())
-            self.N = 1
+            # frame.py:103-109 resets N only when the new score WINS.  In a pure best_score run N is 1 already (no
+            # sync); after weighted_* updates (a per-frame mode override) N > 1 and the device's verdict is read once.
+            if self.N != 1 and bool(self._best[1] > 0):
+                self.N = 1
         elif mode == "indep_conf":
             fuse(FUSE_INDEP_CONF); self.N = 1
         elif mode == "weighted_pointmap":

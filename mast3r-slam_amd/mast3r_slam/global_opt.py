@@ -47,6 +47,7 @@ class FactorGraph:
         e = lambda dt: torch.empty((0,), dtype=dt, device=self._dev)
         self.ii, self.jj = e(torch.int32), e(torch.int32)   # ALL edges of the graph (every rank holds the full list)
         self.owner = e(torch.int32)                          # rank that stores edge k's matches (0 without a group)
+        self._kept_per_rank: list[int] = []                  # host mirror of the owner counts (no sync when sizing the gather)
         self.idx_ii2jj = self.idx_jj2ii = None               # [E_own,N] int64 - this rank's edges only
         self.valid_match_j = self.valid_match_i = None       # [E_own,N,1] bool
         self.Q_ii2jj = self.Q_jj2ii = None                   # [E_own,N,1] float32
@@ -98,7 +99,12 @@ class FactorGraph:
         if int((~invalid_h).sum()) == 0:
             return False
         keep = ~invalid
-        own = torch.cat([torch.full((len(shard_range(len(ii), r, world)),), r, dtype=torch.int32) for r in range(world)]).to(dev)
+        own_h = torch.cat([torch.full((len(shard_range(len(ii), r, world)),), r, dtype=torch.int32) for r in range(world)])
+        kept_h = torch.bincount(own_h[~invalid_h].long(), minlength=world).tolist()      # invalid_h is on the host already
+        if len(self._kept_per_rank) != world:
+            self._kept_per_rank = [0] * world
+        self._kept_per_rank = [a + b for a, b in zip(self._kept_per_rank, kept_h)]
+        own = own_h.to(dev)
         self.ii, self.jj = torch.cat([self.ii, ii_t[keep]]), torch.cat([self.jj, jj_t[keep]])
         self.owner = torch.cat([self.owner, own[keep]])
         if outs:
@@ -149,7 +155,7 @@ class FactorGraph:
                 m = self.owner == r
                 gi += [self.ii[m], self.jj[m]]
                 gj += [self.jj[m], self.ii[m]]
-                sizes.append(2 * int(m.sum()))
+                sizes.append(2 * self._kept_per_rank[r])              # host-side count kept by add_factors: no device sync
             graph = (pos(torch.cat(gi)), pos(torch.cat(gj)), sizes)
         return pos(ii), pos(jj), idx.to(torch.int32), valid[..., 0], Q[..., 0], graph
 

@@ -185,8 +185,9 @@ def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray:
     group: a torch.distributed process group -> the edges are split over its ranks: each rank evaluates the
     per-point blocks of its own edges (10.8 MB of reads per edge), the 36-double blocks are all-gathered (288 B per
     edge) and EVERY rank runs the same deterministic device step on the gathered blocks (fixed-order assembly,
-    Cholesky, stop test, retraction): bit-identical poses on all ranks, no broadcast, no host synchronisation
-    inside the loop.
+    Cholesky, stop test, retraction): bit-identical poses on all ranks, no broadcast.  With the nccl (RCCL) backend
+    nothing inside the loop synchronises with the host (the edge list is read to the host ONCE before it, to build the
+    keyframe map); with gloo (CPU tests, several ranks on one GPU) the blocks travel through host memory every iteration.
       * graph=None: every rank passes the FULL graph and takes its shard_range() slice of the edges;
       * graph=(ii_all, jj_all, sizes): the edge arguments are this rank's OWN directed edges only (sizes[rank]
         of them - the matches never leave the rank that computed them, BASELINE configs[4]) and ii_all / jj_all

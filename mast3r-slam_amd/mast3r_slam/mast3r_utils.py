@@ -33,15 +33,19 @@ __all__ = [
 ]
 
 
-def load_mast3r(model_type: str = "mast3r_full", variant: str = "base", resolution: int = 512,
-                precision: str = "bf16", weights_path: Optional[str] = None, **kw) -> Mast3rFull:
-    """mast3r_utils.py:47-80.  Only the full ViT-L model named by the hot path is provided.  `precision`:
-    "bf16" | "fp16" | "fp32" as the reference (see model.py for what each selects on the MI355X);
-    `weights_path`: a torch / safetensors state dict with the public MASt3R key names."""
+def load_mast3r(model_type: str = "dunemast3r", variant: str = "base", resolution: int = 336,
+                precision: str = "fp16", weights_path: Optional[str] = None, **kw) -> Mast3rFull:
+    """mast3r_utils.py:47-80, with the reference's own defaults ("dunemast3r", "base", 336, "fp16") - a caller that
+    relies on them gets the reference's behaviour or a loud error, never a different model.  Only the full ViT-L
+    model the hot path names ("mast3r_full") is provided: the DUNE default raises NotImplementedError (out of scope,
+    DESIGN.md section 7), so the call a SLAM loop makes here is `load_mast3r("mast3r_full", resolution=512, ...)`.
+    `precision`: "fp16" | "fp32" | "bf16" as the reference (see model.py for what each selects on the MI355X);
+    `weights_path` (extension): a torch / safetensors state dict with the public MASt3R key names."""
     if model_type == "mast3r_full":
         return Mast3rFull.from_pretrained(resolution=resolution, precision=precision, weights_path=weights_path, **kw)
     if model_type == "dunemast3r":
-        raise ValueError("model_type 'dunemast3r' (DUNE encoder) is outside this build's scope; use 'mast3r_full'")
+        raise NotImplementedError("model_type 'dunemast3r' (DUNE encoder + MASt3R decoder, the reference's default) is outside "
+                                  "this build's scope; pass model_type='mast3r_full' (ViT-L encoder, resolution=512)")
     raise ValueError(f"Unknown model type: {model_type}. Use 'dunemast3r' or 'mast3r_full'")
 
 

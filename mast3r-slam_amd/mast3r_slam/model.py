@@ -53,10 +53,29 @@ def _round_bf16(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.bfloat16).to(torch.float32)
 
 
-def init_random_weights(cfg: Optional[dict] = None, seed: int = 0, std: float = 0.02) -> dict:
+# Gains of the "trained_like" weight family (init_random_weights): chosen on the fp32 CPU oracle at full depth
+# (tools/emul_precision.py --family trained_like --stats) so that the statistics a trained ViT-L shows - and a
+# trunc-normal(0.02) network does not - are present: see the docstring.
+TRAINED_LIKE = dict(ln_log_sigma=0.55, ln_beta=0.1, qk_gain=5.0, fc1_gain=4.0, fc2_gain=0.25,
+                    massive_enc=((17, 24.0), (301, -30.0), (777, 36.0)), massive_dec=((5, 40.0), (412, -48.0)))
+
+
+def init_random_weights(cfg: Optional[dict] = None, seed: int = 0, std: float = 0.02, family: str = "plain") -> dict:
     """Seeded random weights with the public checkpoint's key names (fp32 CPU tensors whose matrix
-    entries are bf16-representable).  trunc-normal(std) matrices, N(0, std) biases, LayerNorm
-    gamma = 1 + N(0, std), beta = N(0, std)."""
+    entries are bf16-representable).
+
+    family="plain": trunc-normal(std) matrices, N(0, std) biases, LayerNorm gamma = 1 + N(0, std), beta = N(0, std).
+    Such a network is close to the identity: attention logits ~ 0 (uniform softmax), no outlier channels, the
+    residual stream dominated by the patch embedding.
+
+    family="trained_like": the same draw, then the statistics of a trained ViT that stress 16-bit operands
+    (TRAINED_LIKE): LayerNorm gains log-normal over about a decade (exp N(0, 0.55)) with betas N(0, 0.1); the q and k
+    projections (self- and cross-attention) scaled so that softmax rows peak (largest logit of a row ~ 30 and more);
+    fc1 scaled so that GELU sees |x| > 6 (fc2 scaled back so the residual stream keeps its order of magnitude); a few
+    "massive activation" channels, 50-100x the median magnitude of the stream where they enter (three in the encoder
+    through the bias of block 1's fc2, two in each decoder through decoder_embed's bias)."""
+    if family not in ("plain", "trained_like"):
+        raise ValueError(f"family must be 'plain' or 'trained_like', got {family!r}")
     cfg = cfg or FULL_CFG
     g = torch.Generator().manual_seed(seed)
     w: dict[str, torch.Tensor] = {}
@@ -120,7 +139,40 @@ def init_random_weights(cfg: Optional[dict] = None, seed: int = 0, std: float = 
         conv(p + ".head.4", 4, L, 1)
         linear(hname + ".head_local_features.fc1", r * (E + D), E + D)
         linear(hname + ".head_local_features.fc2", (cfg["desc_dim"] + 1) * 256, r * (E + D))
+    if family == "trained_like":
+        _make_trained_like(w, cfg, g)
     return w
+
+
+def _make_trained_like(w: dict, cfg: dict, g: torch.Generator) -> None:
+    """In place: the plain draw -> the "trained_like" family (init_random_weights)."""
+    t = TRAINED_LIKE
+    E, D = cfg["enc_dim"], cfg["dec_dim"]
+    for k in [k for k in w if ".norm" in k or k.startswith(("enc_norm", "dec_norm"))]:
+        n = w[k].shape[0]
+        if k.endswith(".weight"):
+            w[k] = torch.exp(torch.randn(n, generator=g) * t["ln_log_sigma"])
+        else:
+            w[k] = torch.randn(n, generator=g) * t["ln_beta"]
+
+    def scale_rows(key, rows, gain):
+        w[key + ".weight"][rows] = _round_bf16(w[key + ".weight"][rows] * gain)
+        w[key + ".bias"][rows] = w[key + ".bias"][rows] * gain
+
+    blocks = [(f"enc_blocks.{i}", E) for i in range(cfg["enc_depth"])]
+    blocks += [(f"{n}.{i}", D) for n in ("dec_blocks", "dec_blocks2") for i in range(cfg["dec_depth"])]
+    for p, c in blocks:
+        scale_rows(p + ".attn.qkv", slice(0, 2 * c), t["qk_gain"])                 # q | k rows; v untouched
+        if p.startswith("dec"):
+            scale_rows(p + ".cross_attn.projq", slice(None), t["qk_gain"])
+            scale_rows(p + ".cross_attn.projk", slice(None), t["qk_gain"])
+        scale_rows(p + ".mlp.fc1", slice(None), t["fc1_gain"])
+        w[p + ".mlp.fc2.weight"] = _round_bf16(w[p + ".mlp.fc2.weight"] * t["fc2_gain"])
+    if cfg["enc_depth"] > 1:
+        for ch, val in t["massive_enc"]:
+            w["enc_blocks.1.mlp.fc2.bias"][ch % E] = val
+    for ch, val in t["massive_dec"]:
+        w["decoder_embed.bias"][ch % D] = val
 
 
 def load_state_dict(path: str) -> dict:

@@ -307,6 +307,8 @@ def layernorm(x, gamma, beta, eps=1e-6, out=None, dtype=torch.bfloat16):
 
 def patchify16(img_u8, dtype=torch.bfloat16):
     img_u8 = _ffi.check(img_u8, torch.uint8, "img")
+    if img_u8.data_ptr() % 8:                      # a uint8 view with an odd storage offset: the kernel reads 8-byte pieces
+        img_u8 = img_u8.clone()                    # (the C entry point rejects a misaligned pointer with a status)
     b, h, w, _ = img_u8.shape
     out = torch.empty((b * (h // 16) * (w // 16), 768), dtype=dtype, device=img_u8.device)
     _ffi.call("m3_patchify16_dt", _ffi.ptr(img_u8), _ffi.ptr(out), b, h, w, DT_CODE[dtype], _ffi.stream_ptr())

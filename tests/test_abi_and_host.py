@@ -66,6 +66,23 @@ def test_reference_operator_names_and_signatures():
         assert callable(getattr(matching, fn))
     assert list(inspect.signature(matching.match).parameters) == ["X11", "X21", "D11", "D21", "idx_1_to_2_init"]
     assert hasattr(tracker.FrameTracker, "track") and hasattr(tracker.FrameTracker, "reset_idx_f2k")
+    # load_mast3r: the reference's parameter names AND defaults (mast3r_utils.py:47-52); the DUNE default is out of
+    # scope and must say so instead of silently handing back another model
+    from mast3r_slam import mast3r_utils
+    sig = inspect.signature(mast3r_utils.load_mast3r).parameters
+    assert [(k, sig[k].default) for k in list(sig)[:4]] == [
+        ("model_type", "dunemast3r"), ("variant", "base"), ("resolution", 336), ("precision", "fp16")]
+    with pytest.raises(NotImplementedError, match="mast3r_full"):
+        mast3r_utils.load_mast3r()
+    with pytest.raises(ValueError, match="Unknown model type"):
+        mast3r_utils.load_mast3r("mast3r_small")
+    # kernels.py:325-346, :396-412 (calibrated / point variants keep the rays signature's leading arguments)
+    assert list(inspect.signature(kernels.gauss_newton_calib).parameters)[:20] == [
+        "Twc", "Xs", "Cs", "K", "ii", "jj", "idx_ii2jj", "valid_match", "Q", "img_size", "pixel_border", "z_eps",
+        "sigma_pixel", "sigma_depth", "C_thresh", "Q_thresh", "max_iter", "delta_thresh", "pin", "use_metal"]
+    assert list(inspect.signature(kernels.gauss_newton_points).parameters)[:15] == [
+        "Twc", "Xs", "Cs", "ii", "jj", "idx_ii2jj", "valid_match", "Q", "sigma_point", "C_thresh", "Q_thresh", "max_iter",
+        "delta_thresh", "pin", "use_metal"]
 
 
 def test_cpu_tensors_fail_loudly_no_fallback():

@@ -53,6 +53,30 @@ def test_pairs_workload_with_the_fast_reciprocal_nn_matcher():
     assert res["stage_ms"]["match"] > 0 and res["value"] > 0
 
 
+def test_default_line_carries_a_backend_block():
+    """The driver runs the default command only, so BASELINE configs[4] is part of ITS line: after the timed region the
+    pairs workload runs 16 undirected edges of the 256-keyframe graph through the full network (symmetric decode from cached
+    tokens + both match directions on fp16 features), the rays-GN blocks and the 1785-unknown dense step (reference flow
+    slam.py:292-319 -> global_opt.py:49-166).  The block must be there, on valid matches, and its one Gauss-Newton iteration
+    must at least halve the pose error of the keyframes it constrains."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["config"]["pairs_per_gpu"] == 8 and "roofline" in res and "batch1" in res
+    b = res["backend"]
+    assert "256 keyframes" in b["workload"] and b["edges_kept"] == 16 and b["match_valid_frac"] > 0.9
+    assert b["edges_per_s"] > 0 and b["stage_ms"]["rematch"] > 0 and b["stage_ms"]["solve"] > 0
+    e0, e1 = b["pose_max_abs_err_before_after"]
+    assert e1 < 0.5 * e0, (e0, e1)
+    blk = b["hbm_rooflines"]["m3_gn_rays_blocks"]
+    assert 0 < blk["frac"] < 1 and blk["unit"] == "GB/s"
+    assert b["dense_step"]["unknowns"] == 7 * 255 and b["dense_step"]["avg_us"] > 0
+
+
 def test_backend_workload_small_graph_end_to_end():
     """12 keyframes, 6 undirected edges on this rank, reduced-depth network, 256 x 256: decode from cached tokens, both
     matching directions with fp16 features, blocks, one-rank RCCL gather of the blocks, dense step."""

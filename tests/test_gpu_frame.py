@@ -84,6 +84,32 @@ def test_best_score_mode_decides_on_the_device(dev, score):
         config.set_config({"tracking": {"filtering_mode": "weighted_pointmap", "filtering_score": "median"}})
 
 
+def test_best_score_after_weighted_updates_keeps_n_when_the_new_score_loses(dev):
+    """frame.py:103-109 resets N only when the new score WINS (round-3 advisor finding: the device path set N = 1
+    unconditionally).  Two weighted_pointmap updates (N = 2), then the frame's mode is overridden to best_score: a losing
+    update must leave N, the pointmap and get_average_conf() = C / N alone, a winning one resets N to 1."""
+    n = 2048
+    f = create_frame(0, torch.zeros(3, 16, 16, device=dev))
+    o = OF.FrameState("weighted_pointmap")
+    for k in range(2):
+        X, C = _cloud(n, 70 + k)
+        f.update_pointmap(torch.from_numpy(X).to(dev), torch.from_numpy(C).to(dev))
+        o.update_pointmap(X, C)
+    assert f.N == o.N == 2
+    f.filtering_mode = o.mode = "best_score"
+    o._score = f._score = 1e9                                           # the stored best beats anything below
+    X, C = _cloud(n, 80)
+    f.update_pointmap(torch.from_numpy(X).to(dev), torch.from_numpy(C).to(dev))
+    o.update_pointmap(X, C)
+    assert f.N == o.N == 2 and np.array_equal(f.X_canon.cpu().numpy(), o.X_canon)
+    assert np.array_equal(f.get_average_conf().cpu().numpy(), o.get_average_conf())
+    o._score = f._score = 0.0                                           # ... and now anything wins
+    f.update_pointmap(torch.from_numpy(X).to(dev), torch.from_numpy(C).to(dev))
+    o.update_pointmap(X, C)
+    assert f.N == o.N == 1 and np.array_equal(f.X_canon.cpu().numpy(), o.X_canon)
+    assert np.array_equal(f.get_average_conf().cpu().numpy(), o.get_average_conf())
+
+
 def test_fused_sim3_act_update(dev):
     """keyframe.update_pointmap(T_CkCf.act(Xkf), Ckf) (tracker.py:146-147) in one kernel."""
     n = 4096

@@ -32,6 +32,20 @@ def _pair(h, w, s0):
     return synthetic.textured_image(h, w, s0)[None], synthetic.textured_image(h, w, s0 + 1)[None]
 
 
+_ORACLE = {}
+
+
+def _oracle_pair(weights, family, h, w, s0=0):
+    """fp32 oracle outputs of the pair (s0, s0 + 1) at h x w, computed once per module run (~10 s of CPU at full depth)."""
+    key = (family, h, w, s0)
+    if key not in _ORACLE:
+        im1, im2 = _pair(h, w, s0)
+        torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+        with torch.no_grad():
+            _ORACLE[key] = OM.reconstruct(weights, torch.from_numpy(im1), torch.from_numpy(im2), M.FULL_CFG)
+    return _ORACLE[key]
+
+
 # Tolerances per precision mode, rel-L2 against the fp32 oracle at FULL depth.  A CPU emulation of operand
 # rounding (DESIGN.md section 4) predicts pts3d 1.0e-3 / 4e-4 / 1.3e-4 for all-bf16 / bf16 trunk + fp16 heads /
 # fp16; the shipped default ("bf16") must meet BASELINE.json's 1e-3.
@@ -49,9 +63,7 @@ def test_full_depth_network_vs_cpu_oracle(dev, full_weights, shape):
     3e-3: it is what the fp16 heads buy."""
     h, w = shape
     im1, im2 = _pair(h, w, 0)
-    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
-    with torch.no_grad():
-        r1, r2 = OM.reconstruct(full_weights, torch.from_numpy(im1), torch.from_numpy(im2), M.FULL_CFG)
+    r1, r2 = _oracle_pair(full_weights, "plain", h, w)
     report = {}
     for prec, kw in (("bf16", {}), ("fp16", {}), ("bf16", dict(head_precision="bf16"))):
         net = M.Mast3rFull(weights=full_weights, device=dev, precision=prec, **kw)
@@ -73,6 +85,79 @@ def test_full_depth_network_vs_cpu_oracle(dev, full_weights, shape):
     # the fp16 heads must actually pay: pointmap error below the all-bf16 variant in both views
     for v in range(2):
         assert report[("bf16", v)]["pts3d"] < report[("bf16+bf16heads", v)]["pts3d"]
+
+
+def test_benchmarked_configuration_eight_pairs_through_the_graph(dev, full_weights):
+    """What bench.py times (BASELINE configs[3]'s per-GPU shard): FULL_CFG, 8 pairs at 512x512, default precision,
+    replayed from the hipGraph of `net.graphed(8, 512, 512)` - i.e. the k_gemm256 256x256 / 256x192 tiles, the 2-group
+    launches and the XCD-ordered grids, none of which a one-pair eager pass reaches (it runs on the 64 / 128 tiles).
+    Contract: mast3r_utils.py:281-294.
+      * every output of every pair equals the same pair run ALONE, eagerly, bit for bit ("same bits alone or in a
+        batch": all tile shapes accumulate K in the same order, split-K slice counts depend on the per-image geometry
+        only, attention works per (image, head));
+      * pair 0 is within FULL_TOL of the fp32 oracle (hence every pair of the batch is as good as the one-pair test says)."""
+    h = w = 512
+    P = 8
+    im1 = np.stack([synthetic.textured_image(h, w, 2 * p) for p in range(P)])          # bench.py's images of rank 0
+    im2 = np.stack([synthetic.textured_image(h, w, 2 * p + 1) for p in range(P)])
+    net = M.Mast3rFull(weights=full_weights, device=dev, precision="bf16")
+    g = net.graphed(P, h, w)
+    o1, o2 = g(im1, im2)
+    o1, o2 = ({k: v.clone() for k, v in o.items()} for o in (o1, o2))
+    q1, q2 = g(im1, im2)                                                                # a second replay: same bits
+    keys = ("pts3d", "conf", "desc", "desc_conf")
+    for k in keys:
+        assert torch.equal(q1[k], o1[k]) and torch.equal(q2[k], o2[k]), k
+    for p in range(P):
+        e1, e2 = net.reconstruct_batch(im1[p:p + 1], im2[p:p + 1])
+        for k in keys:
+            assert torch.equal(o1[k][p], e1[k][0]), (p, k, "view 1", _rel(o1[k][p], e1[k][0]))
+            assert torch.equal(o2[k][p], e2[k][0]), (p, k, "view 2", _rel(o2[k][p], e2[k][0]))
+    r1, r2 = _oracle_pair(full_weights, "plain", h, w)
+    for o, r in ((o1, r1), (o2, r2)):
+        for k, tol in FULL_TOL["bf16"].items():
+            assert _rel(o[k][0], r[k][0]) < tol, (k, _rel(o[k][0], r[k][0]))
+    assert not torch.equal(o1["pts3d"][0], o1["pts3d"][1])                             # the pairs really differ
+
+
+# Trained-like statistics (model.init_random_weights(family="trained_like")): rel-L2 bounds at FULL depth, 512x512.
+# CPU emulation of operand rounding (tools/emul_precision.py --family trained_like --res 512 512): pts3d view 1 / view 2
+#   bf16 trunk + fp16 heads 1.28e-3 / 2.34e-3 (encoder GEMM operands 9e-4 / 1.7e-3, encoder q|k|v|P 9e-4 / 1.6e-3: an
+#   8-bit mantissa on logits of 30-80 moves softmax weights by percents), fp16 1.8e-4 / 3.4e-4.
+TRAINED_TOL = {
+    "fp16": dict(pts3d=1e-3, conf=1e-4, desc=6e-3, desc_conf=8e-3),      # BASELINE.json's 1e-3 is met by the fp16 trunk
+    "bf16": dict(pts3d=5e-3, conf=2e-4, desc=3e-2, desc_conf=4e-2),      # stated bound of the bf16 trunk: it does NOT meet 1e-3 here
+}
+
+
+def test_trained_like_weight_statistics_at_full_depth(dev):
+    """The plain random family is a near-identity network (uniform softmax, no outlier channels) and flatters 16-bit
+    operands.  This family has what trained ViT-L checkpoints have - LayerNorm gains over a decade, softmax rows that
+    peak (row maxima of 20-80), massive-activation channels 50x the stream's median, GELU inputs beyond 6 - and both
+    precision modes are held to a written bound at the shipped depth and size:
+      * precision="fp16" (load_mast3r's default, as the reference's): pts3d < 1e-3 in both views;
+      * precision="bf16" (BASELINE configs[1]): < 5e-3 - measured 1.3e-3 / 2.3e-3, i.e. it misses 1e-3 on such weights,
+        which is why it is not the loader's default.
+    Also exercises the deferred-maximum attention loop (MODE 2) on scores that outgrow the first tile's maximum."""
+    h = w = 512
+    wt = M.init_random_weights(M.FULL_CFG, seed=0, family="trained_like")
+    im1, im2 = _pair(h, w, 0)
+    r1, r2 = _oracle_pair(wt, "trained_like", h, w)
+    report = {}
+    for prec in ("fp16", "bf16"):
+        net = M.Mast3rFull(weights=wt, device=dev, precision=prec)
+        o1, o2 = net.reconstruct_batch(im1, im2)
+        for v, (o, r) in enumerate(((o1, r1), (o2, r2))):
+            errs = {k: _rel(o[k], r[k]) for k in ("pts3d", "conf", "desc", "desc_conf")}
+            report[(prec, v)] = errs
+            assert all(torch.isfinite(o[k]).all() for k in errs), (prec, v)
+            for k, tol in TRAINED_TOL[prec].items():
+                assert errs[k] < tol, (prec, v, k, errs)
+        del net
+        torch.cuda.empty_cache()
+    print("\ntrained-like family, full depth, rel-L2 vs fp32 oracle", {k: {n: f"{e:.2e}" for n, e in v.items()} for k, v in report.items()})
+    for v in range(2):
+        assert report[("fp16", v)]["pts3d"] < 0.5 * report[("bf16", v)]["pts3d"]       # the 3 extra mantissa bits pay
 
 
 @pytest.fixture(scope="module")

@@ -268,6 +268,24 @@ def test_blocked_cholesky_under_a_saturated_gpu(dev):
     assert np.abs(x32 - r32).max() <= 1e-6 * max(1.0, np.abs(r32).max())
 
 
+def test_blocked_cholesky_more_block_columns_than_compute_units(dev):
+    """Round-3 advisor finding: the backward substitution is one launch of flag-chained workgroups (consumer index >
+    producer index).  320 block columns (20 480 unknowns) are more workgroups than the chip has CUs (256), so late
+    workgroups are dispatched while earlier ones already spin on their flags; the solve must finish (the spin is
+    bounded: a stuck chain would come back as `not positive definite`, never hang) and reach a float64 residual."""
+    n = 64 * 320
+    g = torch.Generator(device="cpu").manual_seed(9)
+    R = torch.randn(n, n, generator=g, dtype=torch.float32).to(dev).double() * 0.005
+    H = 0.5 * (R + R.T)
+    del R
+    H.diagonal().add_(200.0)                                         # strictly diagonally dominant: |off-diagonal row sum| ~ 80
+    b = torch.randn(n, generator=g, dtype=torch.float64).to(dev)
+    x = kernels.cholesky_solve(H, b, 0.0)
+    resid = float((H @ x - b).abs().max())
+    assert resid <= 1e-10 * float(b.abs().max())
+    assert x.dtype == torch.float64 and bool(torch.isfinite(x).all())
+
+
 def test_large_graph_solve_stays_on_the_device(dev):
     """70 keyframes -> 483 unknowns (beyond the 63 a single workgroup factors in place: blocked Cholesky): the whole Gauss-Newton loop (blocks, assembly,
     blocked Cholesky, stop test, retraction) runs as one stream-ordered call and matches the float64 oracle; a

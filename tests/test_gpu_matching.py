@@ -169,6 +169,29 @@ def test_full_size_512_properties(dev):
         config.reset_config()
 
 
+@pytest.mark.parametrize("features", ["fp32", "fp16"])
+def test_full_size_512_match_bit_exact_vs_oracle(dev, features):
+    """The size and the kernels that are TIMED (bench.py: 512x512, all 262 144 points, the LDS-tiled k_refine_lds<24> path
+    with its halo staging and image borders, fp32 and half descriptor storage): index and validity of
+    matching.match equal oracle.matching.match_iterative_proj (kernels.py:151-254, :496-537; matching.py:339-461) bit
+    for bit on every point.  Two maps per call so that the second map's tiles start behind the first one's."""
+    h = w = 512
+    sc = synthetic.geometric_pair(h, w, seed=3, batch=2)
+    D11, D21 = sc["D11"], sc["D21"]
+    if features == "fp16":
+        D11, D21 = D11.astype(np.float16), D21.astype(np.float16)
+    config.set_config({"matching": {"use_simple": False}})
+    try:
+        i, v = matching.match(_t(sc["X11"], dev), _t(sc["X21"], dev), _t(D11, dev), _t(D21, dev))
+        io, vo = om.match_iterative_proj(sc["X11"], sc["X21"], D11.astype(np.float32), D21.astype(np.float32), None,
+                                         dilation_max=2)
+    finally:
+        config.reset_config()
+    assert vo.mean() > 0.9                                            # the comparison is on matched points, not rejects
+    assert np.array_equal(i.cpu().numpy(), io)
+    assert np.array_equal(v.cpu().numpy(), vo)
+
+
 # ----------------------------------------------------------------- "fp16 features" (BASELINE configs[4])
 @pytest.mark.parametrize("d", [24, 16, 32, 64, 20])
 @pytest.mark.parametrize("chained", [False, True])

@@ -84,6 +84,30 @@ def test_full_size_recovers_known_sim3_and_is_deterministic(dev):
     assert np.abs(np.abs(T[3:7]) - np.abs(pr["T_true"][3:7])).max() < 1e-3
 
 
+@pytest.mark.parametrize("fixed", [False, True])
+def test_full_size_512_solve_matches_the_oracle_loop(dev, fixed):
+    """BASELINE configs[2] at its own size (262 144 points, the size bench.py times): the device loop stops at the same
+    iteration as oracle.tracking.opt_pose_ray_dist_sim3 (tracker.py:258-324, float64) and returns its pose - relative
+    pose and frame pose within 5e-5 absolute, final cost within 1e-3 relative - with the convergence test on
+    (reference behaviour) and with the bench's 10 fixed iterations."""
+    pr = _problem(512, 512, 4)
+    a = [_t(pr[k], dev) for k in ("Xf", "Xk", "T_WCf", "T_WCk", "Qk", "valid")]
+    Tf, Trel, info = tracker.opt_pose_ray_dist_sim3(*a, fixed_iters=fixed)
+    To, Trel_o, io = ot.opt_pose_ray_dist_sim3(pr["Xf"], pr["Xk"], pr["T_WCf"], pr["T_WCk"], pr["Qk"], pr["valid"],
+                                               fixed_iters=10 if fixed else None)
+    info = info.cpu().numpy()
+    assert int(info[0]) == io["iters"] and (fixed or io["iters"] < 10)
+    assert np.abs(Trel.cpu().numpy() - Trel_o).max() < 5e-5
+    assert np.abs(Tf.cpu().numpy() - To).max() < 5e-5
+    assert abs(info[1] - io["costs"][-1]) <= 1e-3 * io["costs"][-1]
+    # batch of the bench's shape: 8 problems per launch sequence, problem 3 is this one
+    others = [_problem(512, 512, 40 + i) for i in range(2)]
+    st = lambda k: torch.stack([_t(p[k], dev) for p in (others[0], pr, others[1])])
+    Tfb, Trelb, infob = tracker.opt_pose_ray_dist_sim3(st("Xf"), st("Xk"), st("T_WCf"), st("T_WCk"), st("Qk"), st("valid"),
+                                                       fixed_iters=fixed)
+    assert torch.equal(Trelb[1], Trel) and torch.equal(Tfb[1], Tf) and torch.equal(infob[1].cpu(), torch.from_numpy(info))
+
+
 @pytest.mark.parametrize("iters", [0, 1, 2, 3])
 def test_iteration_budgets_across_the_double_buffered_state(dev, iters):
     """One launch per iteration: the step that follows an accumulation runs in the prologue of the NEXT launch and the

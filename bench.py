@@ -58,6 +58,9 @@ def parse(argv=None):
     ap.add_argument("--matcher", choices=["iter_proj", "fast_nn"], default="iter_proj",
                     help="match leg of the pairs workload: the reference's dense matcher (iter_proj + refine_matches, default) or "
                          "the fast reciprocal nearest-neighbour matcher BASELINE.json's north_star names (MFMA search, fp16 descriptors)")
+    ap.add_argument("--precision", choices=("bf16", "fp16"), default="bf16",
+                    help="16-bit operand type of the ViT trunk: bf16 (BASELINE configs[1], default) or fp16 (the reference's and "
+                         "load_mast3r's default precision; same MFMA rate, 3 more mantissa bits); the heads are fp16 either way")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--force-dist", action="store_true",
@@ -255,7 +258,8 @@ class PairsWorkload:
         dev = ctx.dev
         config.set_config({"matching": {"use_simple": False}})            # the iter_proj + refine matcher
         cfg = model_mod.TINY_CFG if args.model == "tiny" else None
-        self.net = model_mod.Mast3rFull(seed=0, device=dev, precision="bf16", cfg=cfg)
+        self.net = model_mod.Mast3rFull(seed=0, device=dev, precision=args.precision, cfg=cfg)
+        self.dtype = args.precision
         base = ctx.rank * P
         im = lambda off: torch.from_numpy(np.stack([synthetic.textured_image(self.h, self.w, 2 * (base + p) + off) for p in range(P)])).to(dev)
         self.im1, self.im2 = im(0), im(1)
@@ -439,7 +443,7 @@ class PairsWorkload:
             "data": "synthetic: 512x512 textured pairs through the network (seeded random-init weights, no checkpoint available "
                     "offline); matcher + Gauss-Newton on smooth synthetic two-view scenes of the same size (SURVEY 8d configs 2-3)",
             "config": {"workload": f"{P} keyframe pairs/GPU at {self.h}x{self.w} (BASELINE configs[3] per-GPU shard): "
-                                   "two-view MASt3R ViT-L infer (bf16 trunk, fp16 heads, fp32 accumulate) + "
+                                   f"two-view MASt3R ViT-L infer ({args.precision} trunk, fp16 heads, fp32 accumulate) + "
                                    + ("fast reciprocal-NN match (4096-seed grid, fp16 descriptors, MFMA search) " if sparse else "iter_proj/refine match ")
                                    + "+ 10-iter GN tracking" + ("" if ctx.dist is None else " + RCCL all-gather of results"),
                        "pairs_per_gpu": P, "global_pairs": world * P, "image": [self.h, self.w], "gn_iters": iters, "matcher": args.matcher,

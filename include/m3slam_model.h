@@ -143,6 +143,17 @@ int m3_dpt_tail_grouped2_dt(const void *X, const void *Wc0, const void *Wc1, con
                             float *conf, const void *zero16, int B, int H, int Wd, int upsample, int dtype,
                             void *stream);
 
+/* head.0 of the public DPT head with ITS x2 upsample fused in, as the same direct convolution (oracle/model.py
+ * dpt_head: refinenet1's trailing x2 interpolation -> head.0 conv3x3 256 -> 128): X NHWC [B,H/2,W/2,Cin] when upsample
+ * != 0, else [B,H,W,Cin]; W [128,3,3,Cin] (Cin = 256 or 128); Y NHWC [B,H,W,128] = conv(up(X)) + bias in the 16-bit
+ * dtype.  The upsampled Cin-channel map is neither written nor re-read.  H, W multiples of 16. */
+int m3_conv3x3_up_direct_dt(const void *X, const void *W, const float *bias, void *Y, const void *zero16, int B, int H,
+                            int Wd, int Cin, int upsample, int dtype, void *stream);
+/* ... for both heads in one launch: X [2,B,h,w,Cin], Y [2,B,H,W,128]; head g uses (W_g, bias_g). */
+int m3_conv3x3_up_direct_grouped2_dt(const void *X, const void *W0, const void *W1, const float *bias0,
+                                     const float *bias1, void *Y, const void *zero16, int B, int H, int Wd, int Cin,
+                                     int upsample, int dtype, void *stream);
+
 /* Fused multi-head attention, head dim 64: O = softmax(scale * Q K^T) V, bf16 in/out, fp32
  * softmax.  Q/K/V/O are addressed as base + batch*batch_stride + token*row_stride + head*64
  * (element units), so q, k, v may live interleaved in one [tokens, 3C] projection buffer.

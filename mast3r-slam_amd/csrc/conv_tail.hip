@@ -18,6 +18,12 @@
 // column) is staged once, then nine taps x 64 channels of weights (16 KiB each, double-buffered LDS-DMA) are
 // multiplied from LDS.  Weights streamed per workgroup: 288 KiB per 512 pixels (a 16 x 16 tile version streamed
 // them per 256 pixels and was bound by exactly that L2 -> LDS traffic: 2.4 GB per launch, 913 us).
+//
+// The same kernel body, templated on the input width and the epilogue, is also head.0 with ITS upsample fused in
+// (k_conv_tail<DT, true, 256, false>): [x2 upsample of refinenet1's 256-channel output] -> conv3x3 256->128 + bias ->
+// 16-bit NHWC map.  Four 64-channel quarters instead of two halves, outputs transposed through LDS (the dead halo) into
+// full 128-byte rows.  Before: k_upsample2x wrote the 256 x 256 x 256 map (537 MB for 16 images) and the implicit-GEMM
+// convolution read 1.71 GB for it (208 + 717 us per step).
 #include "gemm_common.h"
 
 using namespace m3gemm;
@@ -35,12 +41,13 @@ constexpr int kPatchBytes = (PH * PW * 128 + 1023) / 1024 * 1024;   // 27 648: w
 constexpr int kLdsBytes = kHaloBytes + 2 * kWStage + kPatchBytes;   // 138 752
 
 struct TailArgs {
-    const bf16_t *X;        // NHWC [B, IH, IW, 128]: IH = H (no upsample) or H / 2 (fused x2 upsample)
-    const bf16_t *Wc;       // [128][3][3][128]
+    const bf16_t *X;        // NHWC [B, IH, IW, CIN]: IH = H (no upsample) or H / 2 (fused x2 upsample)
+    const bf16_t *Wc;       // [128][3][3][CIN]
     const float *bias;      // [128] or null
     const bf16_t *W4;       // [4][128]
     const float *b4;        // [4]
-    float *pts, *conf;      // [B,H,W,3], [B,H,W]
+    float *pts, *conf;      // [B,H,W,3], [B,H,W]                      (TAIL)
+    bf16_t *Y;              // NHWC [B,H,W,128] 16-bit: conv + bias     (!TAIL)
     const bf16_t *zero16;
     int B, H, W, IH, IW;
     // second head (blockIdx.y = 1): its own weights; X / pts / conf advance by one head's extent
@@ -48,15 +55,21 @@ struct TailArgs {
     const float *bias2, *b42;
 };
 
-template <int DT, bool UPS>
+template <int DT, bool UPS, int CIN, bool TAIL>
 __global__ void __launch_bounds__(kThreads, 2)
 k_conv_tail(const TailArgs ain) {
+    static_assert(CIN % 64 == 0 && (TAIL ? CIN == 128 : true), "64-channel steps; the fused tail is the 128-channel head.2");
+    constexpr int NQ = CIN / 64;                            // 64-channel input slices ("halves" of the 128-channel tail)
     TailArgs a = ain;
     if (blockIdx.y == 1) {
         a.Wc = ain.Wc2; a.W4 = ain.W42; a.bias = ain.bias2; a.b4 = ain.b42;
-        a.X = ain.X + (size_t)ain.B * ain.IH * ain.IW * 128;
-        a.pts = ain.pts + (size_t)ain.B * ain.H * ain.W * 3;
-        a.conf = ain.conf + (size_t)ain.B * ain.H * ain.W;
+        a.X = ain.X + (size_t)ain.B * ain.IH * ain.IW * CIN;
+        if (TAIL) {
+            a.pts = ain.pts + (size_t)ain.B * ain.H * ain.W * 3;
+            a.conf = ain.conf + (size_t)ain.B * ain.H * ain.W;
+        } else {
+            a.Y = ain.Y + (size_t)ain.B * ain.H * ain.W * 128;
+        }
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char *halo = lds, *wst = lds + kHaloBytes, *patch = lds + kHaloBytes + 2 * kWStage;
@@ -68,7 +81,7 @@ k_conv_tail(const TailArgs ain) {
     const int b = bid / (tiles_x * tiles_y), trem = bid - b * tiles_x * tiles_y;
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
     const int oy0 = ty * TH, ox0 = tx * TW;
-    const bf16_t *img = a.X + (size_t)b * a.IH * a.IW * 128;
+    const bf16_t *img = a.X + (size_t)b * a.IH * a.IW * CIN;
 
     // weights of (tap, input half) -> stage buf: 128 rows x 8 chunks' = 1024 slots, 2 per thread
     auto stage_w = [&](int tap, int half, int buf) {
@@ -78,7 +91,7 @@ k_conv_tail(const TailArgs ain) {
             const int slot = i * kThreads + tid;
             const int row = slot >> 3, cp = slot & 7;
             const int c = half * 8 + (cp ^ ((row >> 1) & 7));
-            glds16(a.Wc + ((size_t)row * 9 + tap) * 128 + c * 8, base + i * (kThreads * 16) + wave * 1024);
+            glds16(a.Wc + ((size_t)row * 9 + tap) * CIN + c * 8, base + i * (kThreads * 16) + wave * 1024);
         }
     };
     // x2 bilinear (align_corners): the 18 x 34 halo of the H x W image blends an (at most) 11 x 19 input patch
@@ -91,7 +104,7 @@ k_conv_tail(const TailArgs ain) {
             slot = slot < PH * PW * 8 ? slot : PH * PW * 8 - 1;
             const int pp = slot >> 3, c = slot & 7;
             const int y = min(py0 + pp / PW, a.IH - 1), x = min(px0 + pp % PW, a.IW - 1);
-            glds16(img + ((size_t)y * a.IW + x) * 128 + (half * 8 + c) * 8, patch + wi * 1024);
+            glds16(img + ((size_t)y * a.IW + x) * CIN + (half * 8 + c) * 8, patch + wi * 1024);
         }
     };
     auto stage_halo_direct = [&](int half) {    // 612 pixels x 8 chunks' = 4896 slots = 76.5 wave-instructions
@@ -104,7 +117,7 @@ k_conv_tail(const TailArgs ain) {
             const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
             const int c = half * 8 + (cp ^ ((hx >> 1) & 7));
             const bool in = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            const void *src = in ? (const void *)(img + ((size_t)iy * a.IW + ix) * 128 + c * 8) : (const void *)a.zero16;
+            const void *src = in ? (const void *)(img + ((size_t)iy * a.IW + ix) * CIN + c * 8) : (const void *)a.zero16;
             // the last wave-instruction is half full: its upper 32 lanes would land in the weight stage - use a plain store
             if (wi * 64 + 64 <= kHaloPix * 8) glds16(src, halo + wi * 1024);
             else if (live) *reinterpret_cast<uint4 *>(halo + (size_t)slot * 16) = *reinterpret_cast<const uint4 *>(src);
@@ -178,8 +191,7 @@ k_conv_tail(const TailArgs ain) {
     // the compiler: two scratch loads - a vector-memory round trip - in front of every tap's fragment reads.  The ten VALU
     // instructions that compute the two offsets cost nothing next to that.)
     auto col_offset = [&](int hx) { return hx * 128 + ((fch ^ ((hx >> 1) & 7)) << 4); };
-    auto read_frags = [&](int g, int ks) {
-        const int tap = g >= 9 ? g - 9 : g;
+    auto read_frags = [&](int g, int tap, int ks) {
         const int ky = tap / 3, kx = tap - ky * 3;
         const unsigned char *wsrc = wst + (g & 1) * kWStage;
         const int flip = ks << 6;
@@ -211,20 +223,20 @@ k_conv_tail(const TailArgs ain) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto prefetch_w = [&](int g) { if (g + 1 < 18) stage_w((g + 1) % 9, (g + 1) / 9, (g + 1) & 1); };
+    auto prefetch_w = [&](int g) { if (g + 1 < 9 * NQ) stage_w((g + 1) % 9, (g + 1) / 9, (g + 1) & 1); };
     // nine steps on the halo half that is in LDS; both groups execute the same number of barriers (4 * 9 + 1)
     auto run_half = [&](int half) {
         if (group == 0) {
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
                 const int g = half * 9 + tap;
-                read_frags(g, 0);                              // phase 0
+                read_frags(g, tap, 0);                         // phase 0
                 prefetch_w(g);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 phase_end();
                 mfma_all();                                    // phase 1
                 phase_end();
-                read_frags(g, 1);                              // phase 2
+                read_frags(g, tap, 1);                         // phase 2
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 phase_end();
                 mfma_all();                                    // phase 3
@@ -237,13 +249,13 @@ k_conv_tail(const TailArgs ain) {
                 const int g = half * 9 + tap;
                 if (tap > 0) mfma_all();                       // phase 0: k-step 1 of the previous tap
                 phase_end();
-                read_frags(g, 0);                              // phase 1
+                read_frags(g, tap, 0);                         // phase 1
                 prefetch_w(g);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 phase_end();
                 mfma_all();                                    // phase 2
                 phase_end();
-                read_frags(g, 1);                              // phase 3
+                read_frags(g, tap, 1);                         // phase 3
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 phase_end_wait();
             }
@@ -256,75 +268,115 @@ k_conv_tail(const TailArgs ain) {
     if (UPS) stage_patch(0); else stage_halo_direct(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
-    if (UPS) {
-        blend_halo();
-        lds_barrier();
-        stage_patch(1);                                       // streams in under the nine taps of half 0
+#pragma unroll 1
+    for (int q = 0; q < NQ; ++q) {
+        if (UPS) {
+            blend_halo();                                     // slice q: patch -> halo (q > 0: the patch streamed in under the
+            lds_barrier();                                    //   previous slice's taps and was waited for by their vmcnt(0))
+            if (q + 1 < NQ) stage_patch(q + 1);
+        } else if (q > 0) {
+            stage_halo_direct(q);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+        }
+        run_half(q);                                          // ends behind a barrier: every read of this halo slice is done
     }
-    run_half(0);                                              // ends behind a barrier: every read of halo half 0 is done
-    if (UPS) blend_halo();                                    // (its patch was waited for by the steps' vmcnt(0))
-    else { stage_halo_direct(1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    lds_barrier();
-    run_half(1);
 
-    // ---- epilogue: h = relu(acc + bias) in fp32, raw[o] = sum_n h[n] W4[o][n] + b4[o], pointmap post-processing ----
-    const int r = lane & 15, gq = lane >> 4;
-    float part[8][4];
+    if constexpr (!TAIL) {
+        // ---- epilogue (head.0): acc + bias -> 16 bits, transposed through the dead halo (8 KiB per wave) so that the 64 channels
+        // a wave owns leave as full 128-byte pieces of a pixel's 256-byte row (the scratch layout and its swizzle are
+        // epilogue_rows' 16-bit form, gemm_common.h: 8-byte writes / 16-byte reads, every bank once)
+        const int r = lane & 15, gq = lane >> 4;
+        unsigned char *wl = halo + wave * 8192;
+        float4 bj[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 4; ++j)
+            bj[j] = a.bias ? *reinterpret_cast<const float4 *>(a.bias + wc * 64 + j * 16 + gq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int o = 0; o < 4; ++o) part[i][o] = 0.f;
+        for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = wc * 64 + j * 16 + gq * 4;
-        const float4 bq = a.bias ? *reinterpret_cast<const float4 *>(a.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float w4[4][4];
+            for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            const uint2 q = *reinterpret_cast<const uint2 *>(a.W4 + (size_t)o * 128 + n);
-            w4[o][0] = lo16<DT>(q.x); w4[o][1] = hi16<DT>(q.x); w4[o][2] = lo16<DT>(q.y); w4[o][3] = hi16<DT>(q.y);
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = acc[pass * 4 + ii][j];
+                    uint2 pk;
+                    pk.x = pack16<DT>(v[0] + bj[j].x, v[1] + bj[j].y); pk.y = pack16<DT>(v[2] + bj[j].z, v[3] + bj[j].w);
+                    *reinterpret_cast<uint2 *>(wl + (ii * 16 + r) * 128 + (((j * 2 + (gq >> 1)) ^ ((r >> 1) & 7)) << 4) + (((gq ^ r) & 1) << 3)) = pk;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int c = it * 64 + lane, rl = c >> 3, ch = c & 7;
+                uint4 v = *reinterpret_cast<const uint4 *>(wl + rl * 128 + ((ch ^ ((rl >> 1) & 7)) << 4));
+                if (rl & 1) v = uint4{v.z, v.w, v.x, v.y};
+                const int i = pass * 4 + (rl >> 4);
+                const int oy = oy0 + wp * 4 + (i >> 1);
+                const int ox = ox0 + (i & 1) * 16 + (int)((0x3D9F2A40E6C851B7ULL >> (4 * (rl & 15))) & 15);
+                if (ox < a.W)
+                    *reinterpret_cast<uint4 *>(a.Y + (((size_t)b * a.H + oy) * a.W + ox) * 128 + wc * 64 + ch * 8) = v;
+            }
+            asm volatile("" ::: "memory");
         }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const f32x4 v = acc[i][j];
-            const float h[4] = {fmaxf(v[0] + bq.x, 0.f), fmaxf(v[1] + bq.y, 0.f), fmaxf(v[2] + bq.z, 0.f), fmaxf(v[3] + bq.w, 0.f)};
-#pragma unroll
-            for (int o = 0; o < 4; ++o)
-                part[i][o] += (h[0] * w4[o][0] + h[1] * w4[o][1]) + (h[2] * w4[o][2] + h[3] * w4[o][3]);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            float v = part[i][o];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            part[i][o] = v;
-        }
-    // both channel halves' partial sums through LDS, then ONE pixel per lane: lane (r, gq) of wave (wp, wc) finishes
-    // accumulator row tile i = 4 wc + gq (the first version left the 8 x (sqrt, expm1, exp) of a row to 16 lanes of
-    // every second wave)
-    float *red = reinterpret_cast<float *>(wst);             // weight stages are dead after the last barrier
-    if (gq == 0) {
-#pragma unroll
+    } else {
+        // ---- epilogue: h = relu(acc + bias) in fp32, raw[o] = sum_n h[n] W4[o][n] + b4[o], pointmap post-processing ----
+        const int r = lane & 15, gq = lane >> 4;
+        float part[8][4];
+    #pragma unroll
         for (int i = 0; i < 8; ++i)
-            *reinterpret_cast<float4 *>(red + (((wp * 2 + wc) * 8 + i) * 16 + r) * 4) = make_float4(part[i][0], part[i][1], part[i][2], part[i][3]);
-    }
-    __syncthreads();
-    {
-        const int i = 4 * wc + gq;
-        const float4 p0 = *reinterpret_cast<const float4 *>(red + (((wp * 2 + 0) * 8 + i) * 16 + r) * 4);
-        const float4 p1 = *reinterpret_cast<const float4 *>(red + (((wp * 2 + 1) * 8 + i) * 16 + r) * 4);
-        const int oy = oy0 + wp * 4 + (i >> 1), ox = ox0 + (i & 1) * 16 + pix_of_row;      // r == frow
-        if (ox < a.W) {                                       // W = 16 (mod 32): the tile's right half is outside
-            const float x = p0.x + p1.x + a.b4[0], y = p0.y + p1.y + a.b4[1];
-            const float z = p0.z + p1.z + a.b4[2], c = p0.w + p1.w + a.b4[3];
-            const float d = sqrtf(x * x + y * y + z * z);
-            const float sc = expm1f(d) / fmaxf(d, 1e-8f);
-            const size_t m = ((size_t)b * a.H + oy) * a.W + ox;
-            a.pts[3 * m + 0] = x * sc; a.pts[3 * m + 1] = y * sc; a.pts[3 * m + 2] = z * sc;
-            a.conf[m] = 1.0f + expf(c);
+    #pragma unroll
+            for (int o = 0; o < 4; ++o) part[i][o] = 0.f;
+    #pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = wc * 64 + j * 16 + gq * 4;
+            const float4 bq = a.bias ? *reinterpret_cast<const float4 *>(a.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float w4[4][4];
+    #pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const uint2 q = *reinterpret_cast<const uint2 *>(a.W4 + (size_t)o * 128 + n);
+                w4[o][0] = lo16<DT>(q.x); w4[o][1] = hi16<DT>(q.x); w4[o][2] = lo16<DT>(q.y); w4[o][3] = hi16<DT>(q.y);
+            }
+    #pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f32x4 v = acc[i][j];
+                const float h[4] = {fmaxf(v[0] + bq.x, 0.f), fmaxf(v[1] + bq.y, 0.f), fmaxf(v[2] + bq.z, 0.f), fmaxf(v[3] + bq.w, 0.f)};
+    #pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    part[i][o] += (h[0] * w4[o][0] + h[1] * w4[o][1]) + (h[2] * w4[o][2] + h[3] * w4[o][3]);
+            }
+        }
+    #pragma unroll
+        for (int i = 0; i < 8; ++i)
+    #pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float v = part[i][o];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                part[i][o] = v;
+            }
+        // both channel halves' partial sums through LDS, then ONE pixel per lane: lane (r, gq) of wave (wp, wc) finishes
+        // accumulator row tile i = 4 wc + gq (the first version left the 8 x (sqrt, expm1, exp) of a row to 16 lanes of
+        // every second wave)
+        float *red = reinterpret_cast<float *>(wst);             // weight stages are dead after the last barrier
+        if (gq == 0) {
+    #pragma unroll
+            for (int i = 0; i < 8; ++i)
+                *reinterpret_cast<float4 *>(red + (((wp * 2 + wc) * 8 + i) * 16 + r) * 4) = make_float4(part[i][0], part[i][1], part[i][2], part[i][3]);
+        }
+        __syncthreads();
+        {
+            const int i = 4 * wc + gq;
+            const float4 p0 = *reinterpret_cast<const float4 *>(red + (((wp * 2 + 0) * 8 + i) * 16 + r) * 4);
+            const float4 p1 = *reinterpret_cast<const float4 *>(red + (((wp * 2 + 1) * 8 + i) * 16 + r) * 4);
+            const int oy = oy0 + wp * 4 + (i >> 1), ox = ox0 + (i & 1) * 16 + pix_of_row;      // r == frow
+            if (ox < a.W) {                                       // W = 16 (mod 32): the tile's right half is outside
+                const float x = p0.x + p1.x + a.b4[0], y = p0.y + p1.y + a.b4[1];
+                const float z = p0.z + p1.z + a.b4[2], c = p0.w + p1.w + a.b4[3];
+                const float d = sqrtf(x * x + y * y + z * z);
+                const float sc = expm1f(d) / fmaxf(d, 1e-8f);
+                const size_t m = ((size_t)b * a.H + oy) * a.W + ox;
+                a.pts[3 * m + 0] = x * sc; a.pts[3 * m + 1] = y * sc; a.pts[3 * m + 2] = z * sc;
+                a.conf[m] = 1.0f + expf(c);
+            }
         }
     }
 }
@@ -333,36 +385,45 @@ k_conv_tail(const TailArgs ain) {
 
 extern "C" {
 
-// X: NHWC [B, H/2, W/2, 128] when upsample != 0 (the x2 bilinear, align_corners upsampling is done on the fly),
-// else [B, H, W, 128].  H, W multiples of 16.
+// X: NHWC [B, H/2, W/2, CIN] when upsample != 0 (the x2 bilinear, align_corners upsampling is done on the fly),
+// else [B, H, W, CIN].  H, W multiples of 16.  Y == nullptr: the fused tail (CIN = 128, pts / conf out); otherwise
+// conv + bias -> Y NHWC [B,H,W,128] 16-bit (CIN = 128 or 256).
 static int dpt_tail_launch(const void *X, const void *Wc, const float *bias, const void *W4, const float *b4,
                            const void *Wc2, const float *bias2, const void *W42, const float *b42, float *pts,
-                           float *conf, const void *zero16, int B, int H, int W, int upsample, int dtype, void *stream) {
+                           float *conf, void *Y, const void *zero16, int B, int H, int W, int cin, int upsample, int dtype,
+                           void *stream) {
     const int groups = Wc2 ? 2 : 1;
-    M3_REQUIRE(X && Wc && W4 && b4 && pts && conf && zero16 && B > 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0);
-    M3_REQUIRE(groups == 1 || (W42 && b42 && (bias == nullptr) == (bias2 == nullptr)));
+    const bool tail = Y == nullptr;
+    M3_REQUIRE(X && Wc && zero16 && B > 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0);
+    M3_REQUIRE(tail ? (W4 && b4 && pts && conf && cin == 128) : (cin == 128 || cin == 256));
+    M3_REQUIRE(groups == 1 || ((!tail || (W42 && b42)) && (bias == nullptr) == (bias2 == nullptr)));
     M3_REQUIRE((dtype == DT_BF16 || dtype == DT_F16) && (!upsample || (H % 2 == 0 && W % 2 == 0)));
     M3_REQUIRE((int64_t)groups * B * H * W < (1ll << 31));
+    M3_REQUIRE(reinterpret_cast<uintptr_t>(X) % 16 == 0 && reinterpret_cast<uintptr_t>(Wc) % 16 == 0 &&
+               reinterpret_cast<uintptr_t>(Y) % 16 == 0);
     TailArgs a;
     a.Wc2 = (const bf16_t *)Wc2; a.W42 = (const bf16_t *)W42; a.bias2 = bias2; a.b42 = b42;
     a.X = (const bf16_t *)X; a.Wc = (const bf16_t *)Wc; a.bias = bias; a.W4 = (const bf16_t *)W4; a.b4 = b4;
-    a.pts = pts; a.conf = conf; a.zero16 = (const bf16_t *)zero16; a.B = B; a.H = H; a.W = W;
+    a.pts = pts; a.conf = conf; a.Y = (bf16_t *)Y; a.zero16 = (const bf16_t *)zero16; a.B = B; a.H = H; a.W = W;
     a.IH = upsample ? H / 2 : H; a.IW = upsample ? W / 2 : W;
     const dim3 grid((unsigned)((H / TH) * ((W + TW - 1) / TW) * B), groups), blk(kThreads);
     hipStream_t st = (hipStream_t)stream;
-#define M3_TAIL(DTV, UP)                                                                                         \
+#define M3_TAIL(DTV, UP, CI, TL)                                                                                 \
     do {                                                                                                         \
         static M3AttrOnce once;                                                                                  \
         int dev__;                                                                                               \
         if (m3_attr_need(once, &dev__)) {                                                                        \
-            M3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_tail<DTV, UP>),              \
+            M3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_tail<DTV, UP, CI, TL>),      \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes), "m3_dpt_tail/attr"); \
             m3_attr_done(once, dev__);                                                                           \
         }                                                                                                        \
-        hipLaunchKernelGGL((k_conv_tail<DTV, UP>), grid, blk, kLdsBytes, st, a);                                 \
+        hipLaunchKernelGGL((k_conv_tail<DTV, UP, CI, TL>), grid, blk, kLdsBytes, st, a);                         \
     } while (0)
-    if (dtype == DT_F16) { if (upsample) M3_TAIL(DT_F16, true); else M3_TAIL(DT_F16, false); }
-    else { if (upsample) M3_TAIL(DT_BF16, true); else M3_TAIL(DT_BF16, false); }
+#define M3_TAIL_DT(UP, CI, TL) do { if (dtype == DT_F16) M3_TAIL(DT_F16, UP, CI, TL); else M3_TAIL(DT_BF16, UP, CI, TL); } while (0)
+    if (tail) { if (upsample) M3_TAIL_DT(true, 128, true); else M3_TAIL_DT(false, 128, true); }
+    else if (cin == 128) { if (upsample) M3_TAIL_DT(true, 128, false); else M3_TAIL_DT(false, 128, false); }
+    else { if (upsample) M3_TAIL_DT(true, 256, false); else M3_TAIL_DT(false, 256, false); }
+#undef M3_TAIL_DT
 #undef M3_TAIL
     M3_CHECK_LAUNCH("m3_dpt_tail");
     return M3_OK;
@@ -370,17 +431,37 @@ static int dpt_tail_launch(const void *X, const void *Wc, const float *bias, con
 
 int m3_dpt_tail_dt(const void *X, const void *Wc, const float *bias, const void *W4, const float *b4, float *pts,
                    float *conf, const void *zero16, int B, int H, int W, int upsample, int dtype, void *stream) {
-    return dpt_tail_launch(X, Wc, bias, W4, b4, nullptr, nullptr, nullptr, nullptr, pts, conf, zero16, B, H, W, upsample,
-                           dtype, stream);
+    M3_REQUIRE(pts && conf);
+    return dpt_tail_launch(X, Wc, bias, W4, b4, nullptr, nullptr, nullptr, nullptr, pts, conf, nullptr, zero16, B, H, W, 128,
+                           upsample, dtype, stream);
 }
 
 // Both heads in one launch: X [2,B,h,w,128], pts [2,B,H,W,3], conf [2,B,H,W]; head g uses (Wc_g, bias_g, W4_g, b4_g).
 int m3_dpt_tail_grouped2_dt(const void *X, const void *Wc0, const void *Wc1, const float *bias0, const float *bias1,
                             const void *W40, const void *W41, const float *b40, const float *b41, float *pts,
                             float *conf, const void *zero16, int B, int H, int W, int upsample, int dtype, void *stream) {
-    M3_REQUIRE(Wc1 != nullptr);
-    return dpt_tail_launch(X, Wc0, bias0, W40, b40, Wc1, bias1, W41, b41, pts, conf, zero16, B, H, W, upsample, dtype,
-                           stream);
+    M3_REQUIRE(Wc1 != nullptr && pts && conf);
+    return dpt_tail_launch(X, Wc0, bias0, W40, b40, Wc1, bias1, W41, b41, pts, conf, nullptr, zero16, B, H, W, 128, upsample,
+                           dtype, stream);
+}
+
+// Direct 3x3 convolution to 128 output channels with the x2 upsample of its input fused in (head.0 of the DPT head:
+// Cin = 256; Cin = 128 also accepted): X NHWC [B, H/2, W/2, Cin] (upsample) or [B, H, W, Cin], Wc [128][3][3][Cin],
+// Y NHWC [B, H, W, 128] = conv(up(X)) + bias, 16-bit.  H, W multiples of 16 (of 2 as well with the upsample).
+int m3_conv3x3_up_direct_dt(const void *X, const void *Wc, const float *bias, void *Y, const void *zero16, int B, int H,
+                            int W, int Cin, int upsample, int dtype, void *stream) {
+    M3_REQUIRE(Y != nullptr);
+    return dpt_tail_launch(X, Wc, bias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, Y, zero16, B, H,
+                           W, Cin, upsample, dtype, stream);
+}
+
+// ... for both heads in one launch: X [2,B,h,w,Cin], Y [2,B,H,W,128]; head g uses (Wc_g, bias_g).
+int m3_conv3x3_up_direct_grouped2_dt(const void *X, const void *Wc0, const void *Wc1, const float *bias0, const float *bias1,
+                                     void *Y, const void *zero16, int B, int H, int W, int Cin, int upsample, int dtype,
+                                     void *stream) {
+    M3_REQUIRE(Y != nullptr && Wc1 != nullptr);
+    return dpt_tail_launch(X, Wc0, bias0, nullptr, nullptr, Wc1, bias1, nullptr, nullptr, nullptr, nullptr, Y, zero16, B, H, W,
+                           Cin, upsample, dtype, stream);
 }
 
 }  // extern "C"

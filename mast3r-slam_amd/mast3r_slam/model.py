@@ -524,8 +524,13 @@ class Mast3rFull:
         path = self._fusion(p + ".scratch.refinenet4", rn[3])
         path = self._fusion(p + ".scratch.refinenet3", path, rn[2])
         path = self._fusion(p + ".scratch.refinenet2", path, rn[1])
-        path = ops.upsample2x(self._fusion(p + ".scratch.refinenet1", path, rn[0]))
-        h0 = ops.conv3x3(path, P[p + ".head.0.w"], P[p + ".head.0.b"], ops.EPI_BF16)
+        path = self._fusion(p + ".scratch.refinenet1", path, rn[0])
+        if self._direct_head0_ok(path):
+            # refinenet1's trailing x2 upsample + head.0 as ONE direct-convolution launch (the 256-channel full-size map is
+            # neither written nor gathered nine times)
+            h0 = ops.conv3x3_up_direct(path, P[p + ".head.0.w"], P[p + ".head.0.b"], upsample=True)
+        else:
+            h0 = ops.conv3x3(ops.upsample2x(path), P[p + ".head.0.w"], P[p + ".head.0.b"], ops.EPI_BF16)
         ch = P[p + ".head.2.w"].shape[0]
         if ch == 128 and h0.shape[-1] == 128 and P[p + ".head.4.w"].shape == (4, 128):
             # x2 upsample + head.2 conv + ReLU + head.4 1x1 + pointmap post-processing in ONE direct-convolution launch:
@@ -599,8 +604,11 @@ class Mast3rFull:
         path = self._fusion2(d + ".scratch.refinenet2", path, rn[1])
         path = self._fusion2(d + ".scratch.refinenet1", path, rn[0])
         g2, b2, hh, ww, cc = path.shape
-        path = ops.upsample2x(path.view(g2 * b2, hh, ww, cc)).view(g2, b2, 2 * hh, 2 * ww, cc)
-        h0 = ops.conv3x3_grouped2(path, *W(d + ".head.0.w"), *W(d + ".head.0.b"), ops.EPI_BF16)
+        if self._direct_head0_ok(path):
+            h0 = ops.conv3x3_up_direct_grouped2(path, *W(d + ".head.0.w"), *W(d + ".head.0.b"), upsample=True)
+        else:
+            path = ops.upsample2x(path.view(g2 * b2, hh, ww, cc)).view(g2, b2, 2 * hh, 2 * ww, cc)
+            h0 = ops.conv3x3_grouped2(path, *W(d + ".head.0.w"), *W(d + ".head.0.b"), ops.EPI_BF16)
         pts, conf = ops.dpt_tail_grouped2(h0, *W(d + ".head.2.w"), *W(d + ".head.2.b"), *W(d + ".head.4.w"), *W(d + ".head.4.b"),
                                           upsample=True)
         q = ".head_local_features"
@@ -629,6 +637,12 @@ class Mast3rFull:
         if self._grouped_heads_ok():
             return self.heads(taps[0], taps[1], npairs, grid)
         return (self.head("downstream_head1", taps[0], npairs, grid), self.head("downstream_head2", taps[1], npairs, grid))
+
+    def _direct_head0_ok(self, path) -> bool:
+        """The direct head.0 kernel: 256 (or 128) input channels -> 128, output size (twice the input's) a multiple of 16."""
+        w = self.P["downstream_head1.dpt.head.0.w"]
+        return (os.environ.get("M3_DIRECT_HEAD0", "1") != "0" and w.shape[0] == 128 and w.shape[3] in (128, 256)
+                and (2 * path.shape[-3]) % 16 == 0 and (2 * path.shape[-2]) % 16 == 0)
 
     def _grouped_heads_ok(self) -> bool:
         """The 2-group head path needs the public head geometry (128-channel tail, 4 outputs)."""

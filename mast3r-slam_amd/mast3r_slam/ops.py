@@ -242,6 +242,45 @@ def dpt_tail_grouped2(x, w0, w1, b0, b1, w40, w41, b40, b41, upsample: bool = Tr
     return pts, conf
 
 
+def conv3x3_up_direct(x, w, bias, upsample: bool = True):
+    """Direct 3x3 convolution to 128 channels with the x2 bilinear (align_corners) upsample of its input fused in
+    (DPT head.0): x NHWC [B,h,w,Cin] (Cin 256 or 128) -> [B,H,W,128], H = 2h with the upsample.  The upsampled map is
+    never written."""
+    x = _ffi.check(x, H16, "x")
+    b, ih, iw, cin = x.shape
+    w = _ffi.check(w, H16, "w", (128, 3, 3, cin))
+    dt = _same16(x, w)
+    if bias is not None:
+        bias = _ffi.check(bias, torch.float32, "bias", (128,))
+    h, wd = (2 * ih, 2 * iw) if upsample else (ih, iw)
+    out = torch.empty((b, h, wd, 128), dtype=x.dtype, device=x.device)
+    e0 = _prof_begin()
+    _ffi.call("m3_conv3x3_up_direct_dt", _ffi.ptr(x), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(out), _ffi.ptr(zero_page(x.device)),
+              b, h, wd, cin, 1 if upsample else 0, dt, _ffi.stream_ptr())
+    _prof_end(e0, "conv_direct", 2.0 * b * h * wd * 128 * 9 * cin, 2.0 * (b * ih * iw * cin + 128 * 9 * cin + b * h * wd * 128),
+              f"conv3x3_up_direct {b}x{h}x{wd} {cin}->128 upsample={upsample}")
+    return out
+
+
+def conv3x3_up_direct_grouped2(x, w0, w1, b0, b1, upsample: bool = True):
+    """conv3x3_up_direct for both heads in one launch: x [2,B,h,w,Cin] -> [2,B,H,W,128]; head g uses (w_g, b_g)."""
+    x = _ffi.check(x, H16, "x")
+    if x.dim() != 5 or x.shape[0] != 2:
+        raise ValueError(f"x must be [2,B,h,w,Cin], got {tuple(x.shape)}")
+    _, b, ih, iw, cin = x.shape
+    w0 = _ffi.check(w0, H16, "w0", (128, 3, 3, cin))
+    w1 = _ffi.check(w1, H16, "w1", (128, 3, 3, cin))
+    dt = _same16(x, w0, w1)
+    h, wd = (2 * ih, 2 * iw) if upsample else (ih, iw)
+    out = torch.empty((2, b, h, wd, 128), dtype=x.dtype, device=x.device)
+    e0 = _prof_begin()
+    _ffi.call("m3_conv3x3_up_direct_grouped2_dt", _ffi.ptr(x), _ffi.ptr(w0), _ffi.ptr(w1), _ffi.ptr(b0), _ffi.ptr(b1), _ffi.ptr(out),
+              _ffi.ptr(zero_page(x.device)), b, h, wd, cin, 1 if upsample else 0, dt, _ffi.stream_ptr())
+    _prof_end(e0, "conv_direct", 4.0 * b * h * wd * 128 * 9 * cin, 4.0 * (b * ih * iw * cin + 128 * 9 * cin + b * h * wd * 128),
+              f"conv3x3_up_direct x2 {b}x{h}x{wd} {cin}->128 upsample={upsample}")
+    return out
+
+
 def dpt_tail(x: torch.Tensor, w: torch.Tensor, bias, w4: torch.Tensor, b4: torch.Tensor, upsample: bool = True):
     """DPT tail as one direct-convolution launch: [x2 bilinear upsample of x] -> conv3x3 128->128 + ReLU -> 1x1 -> 4
     -> (pts3d [B,H,W,3], conf [B,H,W]) f32.  x NHWC [B,H/2,W/2,128] (upsample) or [B,H,W,128]; 16-bit dtype."""

@@ -101,8 +101,9 @@ def test_best_score_after_weighted_updates_keeps_n_when_the_new_score_loses(dev)
     X, C = _cloud(n, 80)
     f.update_pointmap(torch.from_numpy(X).to(dev), torch.from_numpy(C).to(dev))
     o.update_pointmap(X, C)
-    assert f.N == o.N == 2 and np.array_equal(f.X_canon.cpu().numpy(), o.X_canon)
-    assert np.array_equal(f.get_average_conf().cpu().numpy(), o.get_average_conf())
+    # (the weighted fusion itself is fp32 on both sides but contracts differently: last-bit differences, as in the mode test)
+    assert f.N == o.N == 2 and np.abs(f.X_canon.cpu().numpy() - o.X_canon).max() < 5e-6
+    assert np.allclose(f.get_average_conf().cpu().numpy(), o.get_average_conf(), rtol=1e-6)
     o._score = f._score = 0.0                                           # ... and now anything wins
     f.update_pointmap(torch.from_numpy(X).to(dev), torch.from_numpy(C).to(dev))
     o.update_pointmap(X, C)

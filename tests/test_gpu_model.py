@@ -576,6 +576,39 @@ def test_dpt_tail_direct_convolution(dev, dt, upsample, bhw):
 
 
 @pytest.mark.parametrize("dt", DT16)
+@pytest.mark.parametrize("cin", [256, 128])
+@pytest.mark.parametrize("upsample", [True, False])
+@pytest.mark.parametrize("bhw", [(2, 32, 48), (1, 64, 64), (3, 16, 16), (1, 48, 80)])
+def test_head0_direct_convolution_with_fused_upsample(dev, dt, cin, upsample, bhw):
+    """m3_conv3x3_up_direct_dt (DPT head.0 with refinenet1's x2 upsample fused into the LDS halo staging, four 64-channel
+    slices, LDS-transposed 16-bit output) against the operators it replaces (k_upsample2x -> implicit-GEMM m3_conv3x3:
+    same 16-bit rounding of the upsampled map, fp32 summation order differs) and against a plain torch fp32 chain; the
+    2-group launch equals two single launches bit for bit.  Sizes: multiple tiles, a single tile, W = 16 (mod 32)."""
+    b, h, w = bhw                                                     # OUTPUT size
+    g = torch.Generator(device="cpu").manual_seed(h * 11 + w + cin + int(upsample))
+    ih, iw = (h // 2, w // 2) if upsample else (h, w)
+    x = torch.randn(2, b, ih, iw, cin, generator=g).to(dt)
+    wc = [(torch.randn(128, 3, 3, cin, generator=g) * 0.03).to(dt) for _ in range(2)]
+    bc = [torch.randn(128, generator=g) * 0.1 for _ in range(2)]
+    d = lambda t: t.to(dev)
+    y = ops.conv3x3_up_direct(d(x[0]), d(wc[0]), d(bc[0]), upsample=upsample)
+    assert y.shape == (b, h, w, 128) and y.dtype == dt
+    xu = ops.upsample2x(d(x[0])) if upsample else d(x[0])
+    y_u = ops.conv3x3(xu, d(wc[0]), d(bc[0]), ops.EPI_BF16)
+    assert _rel(y, y_u) < 0.5 * TOL16[dt]                             # one 16-bit rounding of sums that differ in their last fp32 bits
+    xf = x[0].float().permute(0, 3, 1, 2)
+    if upsample:
+        xf = F.interpolate(xf, scale_factor=2, mode="bilinear", align_corners=True)
+    ref = F.conv2d(xf, wc[0].float().permute(0, 3, 1, 2), bc[0], padding=1).permute(0, 2, 3, 1)
+    assert _rel(y, ref) < 2 * TOL16[dt]                               # the interpolated input and the output are rounded once each
+    y_nobias = ops.conv3x3_up_direct(d(x[0]), d(wc[0]), None, upsample=upsample)
+    assert _rel(y_nobias.float() + d(bc[0]), ref) < 2 * TOL16[dt]
+    both = ops.conv3x3_up_direct_grouped2(d(x), d(wc[0]), d(wc[1]), d(bc[0]), d(bc[1]), upsample=upsample)
+    assert torch.equal(both[0], y)
+    assert torch.equal(both[1], ops.conv3x3_up_direct(d(x[1]), d(wc[1]), d(bc[1]), upsample=upsample))
+
+
+@pytest.mark.parametrize("dt", DT16)
 @pytest.mark.parametrize("tq_tk_b_h", [(1024, 1024, 16, 16), (256, 256, 2, 3), (672, 672, 2, 4), (200, 150, 2, 3)])
 def test_attention_prescaled_deferred_max(dev, dt, tq_tk_b_h):
     """m3_attention_prescaled_dt: q carries scale * log2(e) and the reference maximum enters the S^T MFMA as its

@@ -23,8 +23,13 @@
 extern "C" {
 #endif
 
-/* 16-bit storage type of a launch: operands, 16-bit outputs and 16-bit residuals share it */
-enum { M3_DT_BF16 = 0, M3_DT_F16 = 1 };
+/* 16-bit storage type of a launch: operands, 16-bit outputs and 16-bit residuals share it.
+ * M3_DT_F16_PVBF16 is the attention form of the fp16 trunk and is accepted by the RoPE projections
+ * (m3_gemm_rope*_dt, m3_gemm_grouped2*_dt with M3_EPI_BF16_ROPE) and by m3_attention_prescaled_dt only: an fp16 launch
+ * whose v columns (those >= rope_cols) are STORED as bf16, and an attention whose S = Q K^T product runs on fp16
+ * operands while V and the probabilities are bf16 (the operand type of the deferred-maximum loop; q / k keep fp16's
+ * 11-bit mantissa, which is what peaked softmax rows need - DESIGN.md section 4). */
+enum { M3_DT_BF16 = 0, M3_DT_F16 = 1, M3_DT_F16_PVBF16 = 2 };
 
 /* epilogue selectors of m3_gemm_* / m3_conv3x3_* ("BF16" = the launch's 16-bit type) */
 enum {
@@ -34,7 +39,10 @@ enum {
     M3_EPI_F32_ACCUM = 3,  /* C(f32)  = R(f32) + acc + bias   (residual stream; C may alias R) */
     M3_EPI_BF16_RELU = 4,  /* C(bf16) = relu(acc + bias) */
     M3_EPI_BF16_ADD = 5,   /* C(bf16) = R(bf16) + acc + bias  (C may alias R) */
-    M3_EPI_BF16_ROPE = 6   /* C(bf16) = rope2d(acc + bias) on the leading rope_cols columns */
+    M3_EPI_BF16_ROPE = 6,  /* C(bf16) = rope2d(acc + bias) on the leading rope_cols columns */
+    /* flag, OR-ed into the epilogue of m3_conv3x3_dt / m3_conv3x3_grouped2_dt: the convolution reads relu(X) - the
+     * ReLU is applied to the operand fragments in registers, relu(X) is never written (DPT residual unit: relu -> conv1) */
+    M3_EPI_INPUT_RELU = 0x100
 };
 
 /* C[M,N] = epi(A[M,K] . W[N,K]^T + bias): A, W bf16 K-major (torch nn.Linear layout), fp32

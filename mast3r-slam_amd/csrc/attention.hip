@@ -72,9 +72,14 @@ struct AttnArgs {
 //     into range and hide it: round-2 advisor finding), a non-finite l, or a non-finite o at the end.
 #define M3_ATTN_EXP 0
 constexpr float kDefer = 8.0f;
-template <int QT, int DT, int MODE>
+// PVDT: 16-bit type of V in memory and of the probabilities P, i.e. of the O^T = V^T . P^T product.  PVDT = DT except in
+// the mixed mode of the fp16 trunk (DT = fp16, PVDT = bf16, M3_DT_F16_PVBF16): q and k - whose rounding is what an
+// 8-bit mantissa costs on peaked softmax rows (logits of 30-80: DESIGN.md section 4) - keep fp16's 11 bits, while P and V
+// take bf16's exponent range, which is what lets MODE 2 run without tracking the maximum.
+template <int QT, int DT, int MODE, int PVDT = DT>
 __global__ void __launch_bounds__(kThreads, (MODE == 1 && QT == 2) ? 3 : 4)
 k_attn(const AttnArgs a) {
+    static_assert(MODE != 2 || PVDT == DT_BF16, "the deferred-maximum loop needs the fp32 exponent range of bf16 for P");
     constexpr int QR = QT * 64;                                 // query rows per workgroup
     __shared__ __attribute__((aligned(16))) unsigned char lds[kLds];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -130,7 +135,7 @@ k_attn(const AttnArgs a) {
         f32x4 l_acc[QT];                                          // MODE 2: row sums, accumulated by the matrix core
         bf16x8 ones;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ones[j] = (short)(DT == DT_BF16 ? 0x3F80 : 0x3C00);
+        for (int j = 0; j < 8; ++j) ones[j] = (short)(PVDT == DT_BF16 ? 0x3F80 : 0x3C00);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             m_run[qt] = -INFINITY; l_run[qt] = 0.f;
@@ -221,10 +226,10 @@ k_attn(const AttnArgs a) {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     union { unsigned u[4]; bf16x8 v; } pk;
-                    pk.u[0] = pack16<DT>(s[qt][2 * kk][0], s[qt][2 * kk][1]);
-                    pk.u[1] = pack16<DT>(s[qt][2 * kk][2], s[qt][2 * kk][3]);
-                    pk.u[2] = pack16<DT>(s[qt][2 * kk + 1][0], s[qt][2 * kk + 1][1]);
-                    pk.u[3] = pack16<DT>(s[qt][2 * kk + 1][2], s[qt][2 * kk + 1][3]);
+                    pk.u[0] = pack16<PVDT>(s[qt][2 * kk][0], s[qt][2 * kk][1]);
+                    pk.u[1] = pack16<PVDT>(s[qt][2 * kk][2], s[qt][2 * kk][3]);
+                    pk.u[2] = pack16<PVDT>(s[qt][2 * kk + 1][0], s[qt][2 * kk + 1][1]);
+                    pk.u[3] = pack16<PVDT>(s[qt][2 * kk + 1][2], s[qt][2 * kk + 1][3]);
                     pf[qt][kk] = pk.v;
                 }
             };
@@ -335,11 +340,11 @@ k_attn(const AttnArgs a) {
                     }
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt)
-                        o[qt][dt] = mfma16<DT>(vf.v, pf[qt][kk], o[qt][dt]);
+                        o[qt][dt] = mfma16<PVDT>(vf.v, pf[qt][kk], o[qt][dt]);
                 }
                 if constexpr (MD == 2) {
 #pragma unroll
-                    for (int qt = 0; qt < QT; ++qt) l_acc[qt] = mfma16<DT>(ones, pf[qt][kk], l_acc[qt]);
+                    for (int qt = 0; qt < QT; ++qt) l_acc[qt] = mfma16<PVDT>(ones, pf[qt][kk], l_acc[qt]);
                 }
             }
         }
@@ -442,7 +447,8 @@ static int attention_launch(const void *Q, const void *K, const void *V, void *O
                             int nbatch, int heads, int Tq, int Tk, int kv_batch_shift, float scale, int dtype, bool pre,
                             void *stream) {
     M3_REQUIRE(Q && K && V && O && nbatch > 0 && heads > 0 && Tq > 0 && Tk > 0);
-    M3_REQUIRE((dtype == DT_BF16 || dtype == DT_F16) && ((int64_t)Tq / 64 + 1) * heads * nbatch < (1ll << 31));
+    // dtype 2 = M3_DT_F16_PVBF16 (prescaled entry only): q, k, O fp16; V holds bf16, P is bf16
+    M3_REQUIRE((dtype == DT_BF16 || dtype == DT_F16 || (dtype == 2 && pre)) && ((int64_t)Tq / 64 + 1) * heads * nbatch < (1ll << 31));
     M3_REQUIRE(q_row_stride % 8 == 0 && kv_row_stride % 8 == 0 && o_row_stride % 4 == 0);
     M3_REQUIRE(kv_batch_shift >= 0);
     AttnArgs a;
@@ -458,7 +464,8 @@ static int attention_launch(const void *Q, const void *K, const void *V, void *O
     static const bool safe_bf16 = [] { const char *e = getenv("M3_ATTN_SAFE"); return e && atoi(e) != 0; }();
 #define M3_ATTN(QTV, GRID)                                                                                  \
     do {                                                                                                    \
-        if (dtype == DT_F16) { if (pre) hipLaunchKernelGGL((k_attn<QTV, DT_F16, 1>), dim3((unsigned)(GRID)), dim3(kThreads), 0, st, a); \
+        if (dtype == 2) hipLaunchKernelGGL((k_attn<QTV, DT_F16, 2, DT_BF16>), dim3((unsigned)(GRID)), dim3(kThreads), 0, st, a); \
+        else if (dtype == DT_F16) { if (pre) hipLaunchKernelGGL((k_attn<QTV, DT_F16, 1>), dim3((unsigned)(GRID)), dim3(kThreads), 0, st, a); \
                                else hipLaunchKernelGGL((k_attn<QTV, DT_F16, 0>), dim3((unsigned)(GRID)), dim3(kThreads), 0, st, a); } \
         else { if (pre) { if (safe_bf16) hipLaunchKernelGGL((k_attn<QTV, DT_BF16, 1>), dim3((unsigned)(GRID)), dim3(kThreads), 0, st, a); \
                           else hipLaunchKernelGGL((k_attn<QTV, DT_BF16, 2>), dim3((unsigned)(GRID)), dim3(kThreads), 0, st, a); }          \

@@ -137,6 +137,10 @@ k_gemm(const GemmArgs gin) {
                 const int cw = (ks * 4 + fch) ^ ((rw >> 1) & 7);
                 wf[i] = *reinterpret_cast<const bf16x8 *>(Ws + rw * 128 + cw * 16);
             }
+            if (MODE == 1 && g.relu_a) {                    // kernel-uniform (M3_EPI_INPUT_RELU)
+#pragma unroll
+                for (int i = 0; i < NT; ++i) af[i] = relu_frag(af[i]);
+            }
 #pragma unroll
             for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -353,6 +357,9 @@ int m3_gemm_pick_tile(int M, int N, int groups) {
 }
 
 static bool dt_ok(int dtype) { return dtype == DT_BF16 || dtype == DT_F16; }
+// the RoPE projections also take M3_DT_F16_PVBF16 (2): an fp16 launch whose v columns (>= rope_cols) are stored as bf16
+static bool dt_ok_rope(int dtype) { return dt_ok(dtype) || dtype == 2; }
+static void set_dt(GemmArgs &a, int dtype) { a.dt = dtype == 2 ? DT_F16 : dtype; a.v_bf16 = dtype == 2; }
 
 int m3_gemm_dt(const void *A, const void *W, const float *bias, void *C, const void *R, int M, int N, int K,
                int ldc, int epilogue, int dtype, void *stream) {
@@ -375,12 +382,12 @@ int m3_gemm_bf16(const void *A, const void *W, const float *bias, void *C, const
 int m3_gemm_rope_dt(const void *A, const void *W, const float *bias, void *C, int M, int N, int K, int ldc,
                     const float *rope_tok, int tokens_per_image, int rope_cols, int q_cols, float q_scale, int dtype,
                     void *stream) {
-    M3_REQUIRE(A && W && C && rope_tok && M > 0 && N > 0 && K > 0 && tokens_per_image > 0 && dt_ok(dtype));
+    M3_REQUIRE(A && W && C && rope_tok && M > 0 && N > 0 && K > 0 && tokens_per_image > 0 && dt_ok_rope(dtype));
     M3_REQUIRE((reinterpret_cast<size_t>(rope_tok) & 15) == 0 && q_cols >= 0 && q_cols <= rope_cols && q_cols % 64 == 0);
     M3_REQUIRE(K % BK == 0 && N % 64 == 0 && ldc >= N && ldc % 4 == 0 && rope_cols % 64 == 0 && rope_cols <= N);
     GemmArgs a{};
     a.A = (const bf16_t *)A; a.W = (const bf16_t *)W; a.bias = bias; a.C = C;
-    a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.dt = dtype;
+    a.M = M; a.N = N; a.K = K; a.ldc = ldc; set_dt(a, dtype);
     a.rope_tok = rope_tok; a.tokens_per_image = tokens_per_image; a.rope_cols = rope_cols;
     a.q_cols = q_cols; a.q_scale = q_scale;
     const int tile = pick_tile(M, N);
@@ -391,12 +398,12 @@ int m3_gemm_rope_dt(const void *A, const void *W, const float *bias, void *C, in
 int m3_gemm_rope_pos_dt(const void *A, const void *W, const float *bias, void *C, int M, int N, int K, int ldc,
                         const int32_t *pos_yx, int tokens_per_image, float base, int rope_cols, int q_cols, float q_scale,
                         int dtype, void *stream) {
-    M3_REQUIRE(A && W && C && pos_yx && M > 0 && N > 0 && K > 0 && tokens_per_image > 0 && base > 1.0f && dt_ok(dtype));
+    M3_REQUIRE(A && W && C && pos_yx && M > 0 && N > 0 && K > 0 && tokens_per_image > 0 && base > 1.0f && dt_ok_rope(dtype));
     M3_REQUIRE(q_cols >= 0 && q_cols <= rope_cols && q_cols % 64 == 0);
     M3_REQUIRE(K % BK == 0 && N % 64 == 0 && ldc >= N && ldc % 4 == 0 && rope_cols % 64 == 0 && rope_cols <= N);
     GemmArgs a{};
     a.A = (const bf16_t *)A; a.W = (const bf16_t *)W; a.bias = bias; a.C = C;
-    a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.dt = dtype;
+    a.M = M; a.N = N; a.K = K; a.ldc = ldc; set_dt(a, dtype);
     a.rope_pos = pos_yx; a.rope_log2_base = log2f(base); a.tokens_per_image = tokens_per_image; a.rope_cols = rope_cols;
     a.q_cols = q_cols; a.q_scale = q_scale;
     const int tile = pick_tile(M, N);
@@ -415,7 +422,7 @@ int m3_gemm_grouped2_dt(const void *A, const void *W0, const void *W1, const flo
                         void *C, const void *R, int M, int N, int K, int ldc, int64_t a_gstride,
                         int64_t c_gstride, int epilogue, const float *rope_tok,
                         int tokens_per_image, int rope_cols, int q_cols, float q_scale, int dtype, void *stream) {
-    M3_REQUIRE(A && W0 && W1 && C && M > 0 && N > 0 && K > 0 && dt_ok(dtype));
+    M3_REQUIRE(A && W0 && W1 && C && M > 0 && N > 0 && K > 0 && (dt_ok(dtype) || (dtype == 2 && epilogue == EPI_BF16_ROPE)));
     M3_REQUIRE(K % BK == 0 && N % 4 == 0 && ldc >= N && ldc % 4 == 0);
     M3_REQUIRE(!((epilogue == EPI_F32_ACCUM || epilogue == EPI_BF16_ADD) && !R));
     M3_REQUIRE((bias0 == nullptr) == (bias1 == nullptr));
@@ -424,7 +431,7 @@ int m3_gemm_grouped2_dt(const void *A, const void *W0, const void *W1, const flo
                    rope_cols % 64 == 0 && rope_cols <= N && q_cols >= 0 && q_cols <= rope_cols && q_cols % 64 == 0);
     GemmArgs a{};
     a.A = (const bf16_t *)A; a.W = (const bf16_t *)W0; a.W2 = (const bf16_t *)W1; a.bias = bias0; a.bias2 = bias1;
-    a.C = C; a.R = R; a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.dt = dtype;
+    a.C = C; a.R = R; a.M = M; a.N = N; a.K = K; a.ldc = ldc; set_dt(a, dtype);
     a.a_gstride = a_gstride; a.c_gstride = c_gstride; a.groups = 2;
     a.rope_tok = rope_tok; a.tokens_per_image = tokens_per_image; a.rope_cols = rope_cols;
     a.q_cols = q_cols; a.q_scale = q_scale;
@@ -437,12 +444,12 @@ int m3_gemm_grouped2_rope_pos_dt(const void *A, const void *W0, const void *W1, 
                                  void *C, int M, int N, int K, int ldc, int64_t a_gstride, int64_t c_gstride,
                                  const int32_t *pos_yx, int tokens_per_image, float base, int rope_cols, int q_cols,
                                  float q_scale, int dtype, void *stream) {
-    M3_REQUIRE(A && W0 && W1 && C && pos_yx && M > 0 && N > 0 && K > 0 && tokens_per_image > 0 && base > 1.0f && dt_ok(dtype));
+    M3_REQUIRE(A && W0 && W1 && C && pos_yx && M > 0 && N > 0 && K > 0 && tokens_per_image > 0 && base > 1.0f && dt_ok_rope(dtype));
     M3_REQUIRE(K % BK == 0 && N % 64 == 0 && ldc >= N && ldc % 4 == 0 && (bias0 == nullptr) == (bias1 == nullptr));
     M3_REQUIRE(rope_cols % 64 == 0 && rope_cols <= N && q_cols >= 0 && q_cols <= rope_cols && q_cols % 64 == 0);
     GemmArgs a{};
     a.A = (const bf16_t *)A; a.W = (const bf16_t *)W0; a.W2 = (const bf16_t *)W1; a.bias = bias0; a.bias2 = bias1;
-    a.C = C; a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.dt = dtype;
+    a.C = C; a.M = M; a.N = N; a.K = K; a.ldc = ldc; set_dt(a, dtype);
     a.a_gstride = a_gstride; a.c_gstride = c_gstride; a.groups = 2;
     a.rope_pos = pos_yx; a.rope_log2_base = log2f(base); a.tokens_per_image = tokens_per_image; a.rope_cols = rope_cols;
     a.q_cols = q_cols; a.q_scale = q_scale;
@@ -469,10 +476,13 @@ int64_t m3_conv3x3_splitk_bytes(int B, int H, int Wd, int Cin, int Cout, int str
 int m3_conv3x3_dt(const void *X, const void *W, const float *bias, void *Y, const void *R, const void *zero16,
                   int B, int H, int Wd, int Cin, int Cout, int stride, int epilogue, void *splitk_ws,
                   int64_t splitk_ws_bytes, int dtype, void *stream) {
+    const int relu_in = (epilogue & 0x100) ? 1 : 0;           // M3_EPI_INPUT_RELU
+    epilogue &= 0xff;
     M3_REQUIRE(X && W && Y && zero16 && B > 0 && H > 0 && Wd > 0 && Cin > 0 && Cout > 0 && dt_ok(dtype));
     M3_REQUIRE(Cin % BK == 0 && Cout % 4 == 0 && (stride == 1 || stride == 2) && epilogue != EPI_BF16_ROPE);
     M3_REQUIRE(!((epilogue == EPI_F32_ACCUM || epilogue == EPI_BF16_ADD) && !R));
     GemmArgs a{};
+    a.relu_a = relu_in;
     a.A = (const bf16_t *)X; a.W = (const bf16_t *)W; a.bias = bias; a.C = Y; a.R = R;
     a.zero16 = (const bf16_t *)zero16;
     a.H = H; a.Wd = Wd; a.Cin = Cin; a.stride = stride;
@@ -494,11 +504,14 @@ int m3_conv3x3_dt(const void *X, const void *W, const float *bias, void *Y, cons
 int m3_conv3x3_grouped2_dt(const void *X, const void *W0, const void *W1, const float *bias0, const float *bias1,
                            void *Y, const void *R, const void *zero16, int B, int H, int Wd, int Cin, int Cout,
                            int stride, int epilogue, void *splitk_ws, int64_t splitk_ws_bytes, int dtype, void *stream) {
+    const int relu_in = (epilogue & 0x100) ? 1 : 0;           // M3_EPI_INPUT_RELU
+    epilogue &= 0xff;
     M3_REQUIRE(X && W0 && W1 && Y && zero16 && B > 0 && H > 0 && Wd > 0 && Cin > 0 && Cout > 0 && dt_ok(dtype));
     M3_REQUIRE(Cin % BK == 0 && Cout % 4 == 0 && (stride == 1 || stride == 2) && epilogue != EPI_BF16_ROPE);
     M3_REQUIRE(!((epilogue == EPI_F32_ACCUM || epilogue == EPI_BF16_ADD) && !R));
     M3_REQUIRE((bias0 == nullptr) == (bias1 == nullptr));
     GemmArgs a{};
+    a.relu_a = relu_in;
     a.A = (const bf16_t *)X; a.W = (const bf16_t *)W0; a.W2 = (const bf16_t *)W1; a.bias = bias0; a.bias2 = bias1;
     a.C = Y; a.R = R; a.zero16 = (const bf16_t *)zero16;
     a.H = H; a.Wd = Wd; a.Cin = Cin; a.stride = stride;

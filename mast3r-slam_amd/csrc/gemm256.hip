@@ -136,6 +136,10 @@ k_gemm256(const GemmArgs gin) {
         for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8 *>(base + (w_off[j] ^ (ks << 6)));
 #pragma unroll
         for (int i = 0; i < NI; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(base + (a_off[i] ^ (ks << 6)));
+        if (MODE == 1 && g.relu_a) {                         // kernel-uniform: relu(x) -> conv without a relu(x) tensor
+#pragma unroll
+            for (int i = 0; i < NI; ++i) af[i] = relu_frag(af[i]);
+        }
     };
     auto mfma_all = [&]() {
         __builtin_amdgcn_s_setprio(1);

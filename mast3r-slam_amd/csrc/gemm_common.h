@@ -74,6 +74,13 @@ template <int DT> __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f3
     else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
+// ReLU on a fragment of eight 16-bit floats (bf16 or fp16): a negative value has its sign bit set, i.e. is negative as a
+// signed 16-bit integer too, and every non-negative value keeps its bits under max(x, 0)
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+__device__ __forceinline__ bf16x8 relu_frag(bf16x8 v) {
+    return __builtin_elementwise_max(v, (bf16x8)(short)0);
+}
+
 __device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) unsigned *)g,
                                      (__attribute__((address_space(3))) unsigned *)lds_wave_base, 16, 0, 0);
@@ -120,6 +127,11 @@ struct GemmArgs {
     // EPI_RELU_HEAD4: W2 = bf16 [4][N] projection, bias2 = its 4 biases, C = pts f32 [M,3], C2 = conf f32 [M]
     float *C2;
     int dt;                 // DT_BF16 / DT_F16: 16-bit storage type of A, W and of 16-bit C / R
+    int relu_a;             // conv3x3: ReLU applied to the INPUT fragments (max with 0 on the 16-bit lanes, read as signed
+                            //   integers: one v_pk_max_i16 per dword for bf16 and fp16 alike) - the DPT residual unit's
+                            //   relu(x) -> conv1 without materialising relu(x)  (M3_EPI_INPUT_RELU)
+    int v_bf16;             // EPI_BF16_ROPE in a DT_F16 launch: the columns >= rope_cols (v of a q|k|v or k|v projection) are
+                            //   stored as bf16 - the operand type of the fast attention loop's P.V product (M3_DT_F16_PVBF16)
 };
 
 // Per-group view of the arguments (group 1 of a 2-group launch).
@@ -172,7 +184,11 @@ __device__ __forceinline__ void store_tile(const GemmArgs &g, f32x4 v, int m, in
             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
         }
         uint2 o;
-        o.x = pack16<DT>(v[0], v[1]); o.y = pack16<DT>(v[2], v[3]);
+        if (EPI == EPI_BF16_ROPE && DT == DT_F16 && g.v_bf16 && n >= g.rope_cols) {
+            o.x = pack16<DT_BF16>(v[0], v[1]); o.y = pack16<DT_BF16>(v[2], v[3]);
+        } else {
+            o.x = pack16<DT>(v[0], v[1]); o.y = pack16<DT>(v[2], v[3]);
+        }
         *reinterpret_cast<uint2 *>(reinterpret_cast<bf16_t *>(g.C) + off) = o;
     }
 }
@@ -417,7 +433,11 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
                         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
                     }
                     uint2 pk;
-                    pk.x = pack16<DT>(v[0], v[1]); pk.y = pack16<DT>(v[2], v[3]);
+                    if (EPI == EPI_BF16_ROPE && DT == DT_F16 && g.v_bf16 && n_base + (j >> 1) * 32 >= g.rope_cols) {   // wave-uniform
+                        pk.x = pack16<DT_BF16>(v[0], v[1]); pk.y = pack16<DT_BF16>(v[2], v[3]);
+                    } else {
+                        pk.x = pack16<DT>(v[0], v[1]); pk.y = pack16<DT>(v[2], v[3]);
+                    }
                     if constexpr (SWZ)
                         *reinterpret_cast<uint2 *>(wlds + (ii * 16 + r) * RS + (((j * 2 + (gq >> 1)) ^ ((r >> 1) & 7)) << 4) + (((gq ^ r) & 1) << 3)) = pk;
                     else

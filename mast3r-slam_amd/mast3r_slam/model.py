@@ -247,6 +247,10 @@ class Mast3rFull:
         self.precision = precision
         self.tdt = self._PRECISIONS[precision]                                    # trunk operand type
         self.hdt = self._PRECISIONS[head_precision] if head_precision else torch.float16   # heads: fp16 unless asked
+        # fp16 trunk: q / k stay fp16, v and the softmax probabilities are bf16 (M3_DT_F16_PVBF16) - the fast attention loop
+        # needs bf16's exponent range for P, the logits need fp16's mantissa.  M3_ATTN_PV=fp16 keeps
+        # everything fp16 (max-tracking loop, ~20 % slower attention).
+        self.pv_bf16 = self.tdt == torch.float16 and os.environ.get("M3_ATTN_PV", "bf16") != "fp16"
         self.host_weights = weights if weights is not None else init_random_weights(self.cfg, seed)
         self._prepare(self.host_weights)
         self._rope_cache = {}
@@ -370,11 +374,12 @@ class Mast3rFull:
         P = self.P
         c = heads * 64
         # [M,3c], q|k rotated; q additionally carries softmax scale * log2(e) (folded in before the 16-bit rounding)
-        qkv = ops.gemm_rope(xn, P[p + ".qkv.w"], P[p + ".qkv.b"], rtok, 2 * c, q_cols=c, q_scale=ops.QK_PRESCALE)
+        qkv = ops.gemm_rope(xn, P[p + ".qkv.w"], P[p + ".qkv.b"], rtok, 2 * c, q_cols=c, q_scale=ops.QK_PRESCALE,
+                            pv_bf16=self.pv_bf16)
         out = torch.empty((nb * t, c), dtype=xn.dtype, device=xn.device)
         ops.attention(qkv, qkv[:, c:], qkv[:, 2 * c:], out, nbatch=nb, heads=heads, tq=t, tk=t,
                       q_row_stride=3 * c, kv_row_stride=3 * c, o_row_stride=c, q_batch_stride=t * 3 * c,
-                      kv_batch_stride=t * 3 * c, o_batch_stride=t * c, prescaled=True)
+                      kv_batch_stride=t * 3 * c, o_batch_stride=t * c, prescaled=True, pv_bf16=self.pv_bf16)
         return out
 
     # ------------------------------------------------------------------ encoder
@@ -442,15 +447,16 @@ class Mast3rFull:
             # (one pass over x also yields norm1 of the same tokens for the self-attention below)
             xn, yn = ops.layernorm_dual2(x, ((W(i, "norm1.g")[0], W(i, "norm1.b")[0]), (W(i, "norm1.g")[1], W(i, "norm1.b")[1])),
                                          ((W(i, "norm_y.g")[0], W(i, "norm_y.b")[0]), (W(i, "norm_y.g")[1], W(i, "norm_y.b")[1])), dtype=dt)
+            pv = self.pv_bf16
             kv = ops.gemm_grouped2(yn, *W(i, "cross_attn.kv.w"), *W(i, "cross_attn.kv.b"), ops.EPI_BF16_ROPE,
-                                   rope=(rtok, D))                                  # [2,M,2D], k rotated
+                                   rope=(rtok, D), pv_bf16=pv)                      # [2,M,2D], k rotated
             # self-attention
             qkv = ops.gemm_grouped2(xn, *W(i, "attn.qkv.w"), *W(i, "attn.qkv.b"), ops.EPI_BF16_ROPE,
-                                    rope=(rtok, 2 * D, D, ops.QK_PRESCALE)).view(2 * m, 3 * D)
+                                    rope=(rtok, 2 * D, D, ops.QK_PRESCALE), pv_bf16=pv).view(2 * m, 3 * D)
             a = torch.empty((2, m, D), dtype=dt, device=dev)
             ops.attention(qkv, qkv[:, D:], qkv[:, 2 * D:], a, nbatch=2 * npairs, heads=heads, tq=t, tk=t,
                           q_row_stride=3 * D, kv_row_stride=3 * D, o_row_stride=D, q_batch_stride=t * 3 * D,
-                          kv_batch_stride=t * 3 * D, o_batch_stride=t * D, prescaled=True)
+                          kv_batch_stride=t * 3 * D, o_batch_stride=t * D, prescaled=True, pv_bf16=pv)
             ops.gemm_grouped2(a, *W(i, "attn.proj.w"), *W(i, "attn.proj.b"), ops.EPI_F32_ACCUM, out=x, resid=x)
             # cross-attention
             xn = ops.layernorm_grouped2(x, W(i, "norm2.g")[0], W(i, "norm2.b")[0], W(i, "norm2.g")[1], W(i, "norm2.b")[1], dtype=dt)
@@ -460,7 +466,7 @@ class Mast3rFull:
             a = torch.empty((2, m, D), dtype=dt, device=dev)
             ops.attention(q, kvf, kvf[:, D:], a, nbatch=2 * npairs, heads=heads, tq=t, tk=t, q_row_stride=D,
                           kv_row_stride=2 * D, o_row_stride=D, q_batch_stride=t * D, kv_batch_stride=t * 2 * D,
-                          o_batch_stride=t * D, prescaled=True)
+                          o_batch_stride=t * D, prescaled=True, pv_bf16=pv)
             ops.gemm_grouped2(a, *W(i, "cross_attn.proj.w"), *W(i, "cross_attn.proj.b"), ops.EPI_F32_ACCUM, out=x, resid=x)
             # MLP
             xn = ops.layernorm_grouped2(x, W(i, "norm3.g")[0], W(i, "norm3.b")[0], W(i, "norm3.g")[1], W(i, "norm3.b")[1], dtype=dt)
@@ -479,7 +485,7 @@ class Mast3rFull:
     # ------------------------------------------------------------------ heads
     def _rcu(self, x, q):
         P = self.P
-        c1 = ops.conv3x3(ops.relu(x), P[q + ".conv1.w"], P[q + ".conv1.b"], ops.EPI_BF16_RELU)
+        c1 = ops.conv3x3(x, P[q + ".conv1.w"], P[q + ".conv1.b"], ops.EPI_BF16_RELU, relu_input=True)   # conv1(relu(x))
         return ops.conv3x3(c1, P[q + ".conv2.w"], P[q + ".conv2.b"], ops.EPI_BF16_ADD, resid=x)
 
     def _fusion(self, q, x0, x1=None):
@@ -554,7 +560,7 @@ class Mast3rFull:
     def _rcu2(self, x, q):
         P, h1, h2 = self.P, "downstream_head1", "downstream_head2"
         W = lambda s: (P[h1 + q + s], P[h2 + q + s])
-        c1 = ops.conv3x3_grouped2(ops.relu(x), *W(".conv1.w"), *W(".conv1.b"), ops.EPI_BF16_RELU)
+        c1 = ops.conv3x3_grouped2(x, *W(".conv1.w"), *W(".conv1.b"), ops.EPI_BF16_RELU, relu_input=True)   # conv1(relu(x))
         return ops.conv3x3_grouped2(c1, *W(".conv2.w"), *W(".conv2.b"), ops.EPI_BF16_ADD, resid=x)
 
     def _fusion2(self, q, x0, x1=None):

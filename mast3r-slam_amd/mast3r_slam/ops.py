@@ -11,12 +11,22 @@ import torch
 from . import _ffi
 
 EPI_BF16, EPI_BF16_GELU, EPI_F32, EPI_F32_ACCUM, EPI_BF16_RELU, EPI_BF16_ADD, EPI_BF16_ROPE = range(7)
+EPI_INPUT_RELU = 0x100                          # flag (conv3x3*): the convolution reads relu(x) without a relu(x) tensor
 _F32_EPIS = (EPI_F32, EPI_F32_ACCUM)
 
 _zero16 = {}
 
 H16 = (torch.bfloat16, torch.float16)          # the two 16-bit storage types of the network operators
 DT_CODE = {torch.bfloat16: 0, torch.float16: 1}   # M3_DT_BF16 / M3_DT_F16 (include/m3slam_model.h)
+DT_F16_PVBF16 = 2                              # M3_DT_F16_PVBF16: fp16 q / k / o, bf16 v and probabilities (RoPE GEMMs, attention)
+
+
+def _pv_code(dt: int, pv_bf16: bool) -> int:
+    if not pv_bf16:
+        return dt
+    if dt != DT_CODE[torch.float16]:
+        raise TypeError("pv_bf16 (M3_DT_F16_PVBF16) is the attention form of the fp16 trunk: tensors must be torch.float16")
+    return DT_F16_PVBF16
 
 
 def _same16(a, *others):
@@ -120,14 +130,16 @@ def _rope_table(t):
     return t, t.shape[0], False
 
 
-def gemm_rope(a, w, bias, rope_tok, rope_cols: int, q_cols: int = 0, q_scale: float = 1.0, base: float = ROPE_BASE):
+def gemm_rope(a, w, bias, rope_tok, rope_cols: int, q_cols: int = 0, q_scale: float = 1.0, base: float = ROPE_BASE,
+              pv_bf16: bool = False):
     """16-bit out[M,N] = a @ w.T + bias with RoPE-2D applied to the 64-wide heads in columns < rope_cols;
     rope_tok: int32 [tokens_per_image,2] token grid positions (frequencies base^(-i/16)) or the f32
-    [tokens_per_image,2,2,16] table of rope_token_table."""
+    [tokens_per_image,2,2,16] table of rope_token_table.  pv_bf16 (fp16 tensors only): the columns >= rope_cols
+    (v) of the fp16 output buffer hold bf16 values - what attention(..., pv_bf16=True) reads."""
     rope_tok, tokens_per_image, by_pos = _rope_table(rope_tok)
     a = _ffi.check(a, H16, "a")
     w = _ffi.check(w, H16, "w")
-    dt = _same16(a, w)
+    dt = _pv_code(_same16(a, w), pv_bf16)
     m, k = a.shape
     n = w.shape[0]
     out = torch.empty((m, n), dtype=a.dtype, device=a.device)
@@ -142,8 +154,9 @@ def gemm_rope(a, w, bias, rope_tok, rope_cols: int, q_cols: int = 0, q_scale: fl
     return out
 
 
-def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, epi: int = EPI_BF16, stride: int = 1, resid=None, out=None):
-    """x NHWC bf16 [B,H,W,Cin], w bf16 [Cout,3,3,Cin] -> NHWC [B,OH,OW,Cout], padding 1."""
+def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, epi: int = EPI_BF16, stride: int = 1, resid=None, out=None,
+            relu_input: bool = False):
+    """x NHWC bf16 [B,H,W,Cin], w bf16 [Cout,3,3,Cin] -> NHWC [B,OH,OW,Cout], padding 1.  relu_input: conv(relu(x))."""
     x = _ffi.check(x, H16, "x")
     w = _ffi.check(w, H16, "w")
     dt = _same16(x, w)
@@ -164,8 +177,8 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, epi: int = EPI_BF16, st
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes > 0 else None
     e0 = _prof_begin()
     _ffi.call("m3_conv3x3_dt", _ffi.ptr(x), _ffi.ptr(w), _ffi.ptr(bias), _ffi.ptr(out), _ffi.ptr(resid),
-              _ffi.ptr(zero_page(x.device)), b, h, wd, cin, cout, stride, epi, _ffi.ptr(ws), ws_bytes, dt,
-              _ffi.stream_ptr())
+              _ffi.ptr(zero_page(x.device)), b, h, wd, cin, cout, stride, epi | (EPI_INPUT_RELU if relu_input else 0),
+              _ffi.ptr(ws), ws_bytes, dt, _ffi.stream_ptr())
     _prof_end(e0, "conv3x3", 2.0 * b * oh * ow * cout * 9 * cin,
               2.0 * (b * h * wd * cin + cout * 9 * cin) + out.element_size() * b * oh * ow * cout * (1 if resid is None else 2),
               f"conv3x3 {b}x{h}x{wd} {cin}->{cout} s{stride} epi{epi} splitk_ws={ws_bytes}")
@@ -193,7 +206,7 @@ def conv3x3_relu_head4(x: torch.Tensor, w: torch.Tensor, bias, w4: torch.Tensor,
     return pts, conf
 
 
-def conv3x3_grouped2(x, w0, w1, b0, b1, epi: int = EPI_BF16, stride: int = 1, resid=None):
+def conv3x3_grouped2(x, w0, w1, b0, b1, epi: int = EPI_BF16, stride: int = 1, resid=None, relu_input: bool = False):
     """Two same-shape 3x3 convolutions in one launch (the two DPT heads): x NHWC [2,B,H,W,Cin], group g uses
     (w_g [Cout,3,3,Cin], b_g) -> [2,B,OH,OW,Cout]."""
     x = _ffi.check(x, H16, "x")
@@ -213,8 +226,8 @@ def conv3x3_grouped2(x, w0, w1, b0, b1, epi: int = EPI_BF16, stride: int = 1, re
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes > 0 else None
     e0 = _prof_begin()
     _ffi.call("m3_conv3x3_grouped2_dt", _ffi.ptr(x), _ffi.ptr(w0), _ffi.ptr(w1), _ffi.ptr(b0), _ffi.ptr(b1), _ffi.ptr(out),
-              _ffi.ptr(resid), _ffi.ptr(zero_page(x.device)), b, h, wd, cin, cout, stride, epi, _ffi.ptr(ws), ws_bytes, dt,
-              _ffi.stream_ptr())
+              _ffi.ptr(resid), _ffi.ptr(zero_page(x.device)), b, h, wd, cin, cout, stride,
+              epi | (EPI_INPUT_RELU if relu_input else 0), _ffi.ptr(ws), ws_bytes, dt, _ffi.stream_ptr())
     _prof_end(e0, "conv3x3", 4.0 * b * oh * ow * cout * 9 * cin,
               2.0 * (2.0 * (b * h * wd * cin + cout * 9 * cin) + out.element_size() * b * oh * ow * cout * (1 if resid is None else 2)),
               f"conv3x3 x2 {b}x{h}x{wd} {cin}->{cout} s{stride} epi{epi} splitk_ws={ws_bytes}")
@@ -306,14 +319,19 @@ def dpt_tail(x: torch.Tensor, w: torch.Tensor, bias, w4: torch.Tensor, b4: torch
 
 
 def attention(q, k, v, out, *, nbatch, heads, tq, tk, q_row_stride, kv_row_stride, o_row_stride,
-              q_batch_stride, kv_batch_stride, o_batch_stride, kv_batch_shift=0, scale=0.125, prescaled=False):
+              q_batch_stride, kv_batch_stride, o_batch_stride, kv_batch_shift=0, scale=0.125, prescaled=False,
+              pv_bf16=False):
     """Fused MHA (head dim 64).  q/k/v/out are (views into) 16-bit device tensors; the strides are in
     elements, so q, k, v may be column slices of one projection buffer.  prescaled=True: q already carries
-    scale * log2(e) (gemm_rope(..., q_cols, q_scale=QK_PRESCALE)); `scale` is then ignored."""
+    scale * log2(e) (gemm_rope(..., q_cols, q_scale=QK_PRESCALE)); `scale` is then ignored.  pv_bf16=True (prescaled,
+    fp16 tensors): v holds bf16 values (gemm_rope(..., pv_bf16=True)) and the probabilities are bf16 - the fast
+    deferred-maximum loop with fp16 q / k."""
     for name, t in (("q", q), ("k", k), ("v", v), ("out", out)):
         if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype in H16):
             raise TypeError(f"{name}: expected a bf16 / fp16 tensor on the ROCm device")
-    dt = _same16(q, k, v, out)
+    if pv_bf16 and not prescaled:
+        raise ValueError("pv_bf16 needs prescaled=True")
+    dt = _pv_code(_same16(q, k, v, out), pv_bf16)
     e0 = _prof_begin()
     if prescaled:
         _ffi.call("m3_attention_prescaled_dt", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q_row_stride,
@@ -457,16 +475,19 @@ def add(a, b):
     return out
 
 
-def gemm_grouped2(a, w0, w1, b0, b1, epi=EPI_BF16, out=None, resid=None, rope=None):
+def gemm_grouped2(a, w0, w1, b0, b1, epi=EPI_BF16, out=None, resid=None, rope=None, pv_bf16=False):
     """Two same-shape GEMMs in one launch.  a [2,M,K] bf16, weights [N,K] x2 -> out [2,M,N].
-    rope = (positions int32 [T,2] or table f32 [T,2,2,16], rope_cols[, q_cols, q_scale]) with epi=EPI_BF16_ROPE."""
+    rope = (positions int32 [T,2] or table f32 [T,2,2,16], rope_cols[, q_cols, q_scale]) with epi=EPI_BF16_ROPE;
+    pv_bf16 as gemm_rope."""
     a = _ffi.check(a, H16, "a")
     if a.dim() != 3 or a.shape[0] != 2:
         raise ValueError(f"a must be [2,M,K], got {tuple(a.shape)}")
     _, m, k = a.shape
     w0 = _ffi.check(w0, H16, "w0")
     w1 = _ffi.check(w1, H16, "w1", tuple(w0.shape))
-    dt = _same16(a, w0, w1)
+    if pv_bf16 and epi != EPI_BF16_ROPE:
+        raise ValueError("pv_bf16 goes with epi=EPI_BF16_ROPE")
+    dt = _pv_code(_same16(a, w0, w1), pv_bf16)
     n = w0.shape[0]
     odt = torch.float32 if epi in _F32_EPIS else a.dtype
     if out is None:

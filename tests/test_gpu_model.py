@@ -576,6 +576,30 @@ def test_dpt_tail_direct_convolution(dev, dt, upsample, bhw):
 
 
 @pytest.mark.parametrize("dt", DT16)
+@pytest.mark.parametrize("bhw_c", [(16, 128, 128, 256), (2, 64, 64, 256), (2, 16, 16, 256), (1, 50, 72, 64)])
+def test_conv3x3_with_relu_on_its_input_fragments(dev, dt, bhw_c):
+    """M3_EPI_INPUT_RELU (the DPT residual unit's relu(x) -> conv1): the ReLU is applied to the operand fragments in
+    registers (signed 16-bit max with 0), relu(x) is never written.  Must equal conv3x3(relu(x)) bit for bit on every
+    kernel the dispatcher picks: 256-row tiles (16 x 128 x 128), 128-row tiles, split-K (16 x 16 maps) and a ragged size;
+    single and 2-group launches; negative zeros and padding included."""
+    b, h, w, c = bhw_c
+    g = torch.Generator(device="cpu").manual_seed(h + w + c)
+    x = torch.randn(2, b, h, w, c, generator=g).to(dt)
+    x[0, 0, 0, 0, :8] = -0.0
+    wc = [(torch.randn(256, 3, 3, c, generator=g) * 0.03).to(dt).to(dev) for _ in range(2)]
+    bc = [torch.randn(256, generator=g).to(dev) * 0.1 for _ in range(2)]
+    xd = x.to(dev)
+    for epi in (ops.EPI_BF16_RELU, ops.EPI_BF16):
+        want = ops.conv3x3(ops.relu(xd[0]), wc[0], bc[0], epi)
+        got = ops.conv3x3(xd[0], wc[0], bc[0], epi, relu_input=True)
+        assert torch.equal(got, want), epi
+    assert not torch.equal(ops.conv3x3(xd[0], wc[0], bc[0], ops.EPI_BF16), want)       # the flag really changes the input
+    both = ops.conv3x3_grouped2(xd, wc[0], wc[1], bc[0], bc[1], ops.EPI_BF16_RELU, relu_input=True)
+    assert torch.equal(both[0], ops.conv3x3(ops.relu(xd[0]), wc[0], bc[0], ops.EPI_BF16_RELU))
+    assert torch.equal(both[1], ops.conv3x3(ops.relu(xd[1]), wc[1], bc[1], ops.EPI_BF16_RELU))
+
+
+@pytest.mark.parametrize("dt", DT16)
 @pytest.mark.parametrize("cin", [256, 128])
 @pytest.mark.parametrize("upsample", [True, False])
 @pytest.mark.parametrize("bhw", [(2, 32, 48), (1, 64, 64), (3, 16, 16), (1, 48, 80)])
@@ -643,6 +667,80 @@ def test_attention_prescaled_deferred_max(dev, dt, tq_tk_b_h):
         assert _rel(out[0, row], ref[0, row]) < 2 * tol, row
     assert _rel(out[1, 11], ref[1, 11]) < 2 * tol
     assert _rel(out[1, 8:16, 64:128], ref[1, 8:16, 64:128]) < 2 * tol     # its neighbours in the recomputed workgroup
+
+
+@pytest.mark.parametrize("tq_tk_b_h", [(1024, 1024, 4, 16), (672, 672, 2, 4), (200, 150, 2, 3)])
+def test_attention_fp16_qk_with_bf16_pv(dev, tq_tk_b_h):
+    """M3_DT_F16_PVBF16, the attention form of the fp16 trunk: S = Q K^T on fp16 operands (the logits keep 11 mantissa
+    bits), V and the probabilities in bf16 - so the fp16 trunk runs the fast deferred-maximum loop (MODE 2).  Same forced
+    branches as the bf16 test (range keeper, first-tile maximum, exp2 overflow -> recomputation); the float64 reference
+    takes q, k as the fp16 values and v as the bf16 values the kernel reads.  The logit-side accuracy must be fp16's:
+    on rows with one dominating key the result is far closer to the reference than the all-bf16 kernel's."""
+    tq, tk, b, h = tq_tk_b_h
+    g = torch.Generator().manual_seed(tq + h + 1)
+    c = h * 64
+    q = torch.randn(b, tq, c, generator=g) * 3.0                 # logits of +-30: the regime where q / k rounding shows
+    k = torch.randn(b, tk, c, generator=g)
+    v = torch.randn(b, tk, c, generator=g)
+    q[0, 5, :64] = 6.0 * k[0, tk - 3, :64]
+    q[0, 7, :64] = 6.0 * k[0, 2, :64]
+    q[1, 11, 64:128] = 30.0 * k[1, tk - 5, 64:128]
+    qs, kd = (q * ops.QK_PRESCALE).half(), k.half()
+    vb = v.bfloat16()
+    v_as_half = vb.view(torch.float16)                           # bf16 bit patterns inside an fp16 buffer
+    out = torch.full((b, tq, c), 3.0, dtype=torch.float16, device=dev)
+    ops.attention(qs.to(dev), kd.to(dev), v_as_half.to(dev), out, nbatch=b, heads=h, tq=tq, tk=tk, q_row_stride=c,
+                  kv_row_stride=c, o_row_stride=c, q_batch_stride=tq * c, kv_batch_stride=tk * c, o_batch_stride=tq * c,
+                  prescaled=True, pv_bf16=True)
+    qf = qs.double().view(b, tq, h, 64).transpose(1, 2)
+    kf = kd.double().view(b, tk, h, 64).transpose(1, 2)
+    vf = vb.double().view(b, tk, h, 64).transpose(1, 2)
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * math.log(2.0), -1) @ vf).transpose(1, 2).reshape(b, tq, c)
+    assert out.dtype == torch.float16 and torch.isfinite(out).all()
+    assert _rel(out, ref) < 4e-3                                 # P rounded to bf16: 2^-9 per probability, averaged over the row
+    for row in (5, 7):
+        assert _rel(out[0, row], ref[0, row]) < 8e-3, row
+    assert _rel(out[1, 11], ref[1, 11]) < 8e-3
+    # all-bf16 on the SAME inputs: its logits are rounded to 8 bits -> visibly worse against the unrounded float64 result
+    full = (torch.softmax((q * ops.QK_PRESCALE).double().view(b, tq, h, 64).transpose(1, 2)
+                          @ k.double().view(b, tk, h, 64).transpose(1, 2).transpose(-1, -2) * math.log(2.0), -1)
+            @ v.double().view(b, tk, h, 64).transpose(1, 2)).transpose(1, 2).reshape(b, tq, c)
+    out_b = torch.empty((b, tq, c), dtype=torch.bfloat16, device=dev)
+    ops.attention((q * ops.QK_PRESCALE).bfloat16().to(dev), k.bfloat16().to(dev), vb.to(dev), out_b, nbatch=b, heads=h, tq=tq,
+                  tk=tk, q_row_stride=c, kv_row_stride=c, o_row_stride=c, q_batch_stride=tq * c, kv_batch_stride=tk * c,
+                  o_batch_stride=tq * c, prescaled=True)
+    assert _rel(out, full) < 0.5 * _rel(out_b, full)
+    with pytest.raises(TypeError):
+        ops.attention(qs.bfloat16().to(dev), kd.bfloat16().to(dev), vb.to(dev), out_b, nbatch=b, heads=h, tq=tq, tk=tk,
+                      q_row_stride=c, kv_row_stride=c, o_row_stride=c, q_batch_stride=tq * c, kv_batch_stride=tk * c,
+                      o_batch_stride=tq * c, prescaled=True, pv_bf16=True)
+
+
+@pytest.mark.parametrize("m_n_k", [(256, 192, 64), (2048, 3072, 1024), (16384, 2304, 128)])   # 128 / 256x256 / 256x192 tiles
+def test_rope_projection_with_bf16_v_columns(dev, m_n_k):
+    """gemm_rope(..., pv_bf16=True) (M3_DT_F16_PVBF16): the q | k columns are the fp16 launch's bits, the v columns
+    (>= rope_cols) hold the SAME fp32 results rounded to bf16 instead of fp16 - single and 2-group launches."""
+    m, n, k = m_n_k
+    g = torch.Generator().manual_seed(n)
+    gh, gw = 8, 16
+    a = torch.randn(m, k, generator=g).half().to(dev)
+    w = (torch.randn(n, k, generator=g) * 0.05).half().to(dev)
+    bias = torch.randn(n, generator=g).to(dev)
+    gy, gx = torch.meshgrid(torch.arange(gh), torch.arange(gw), indexing="ij")
+    pos = torch.stack([gy.reshape(-1), gx.reshape(-1)], -1).to(torch.int32).to(dev)
+    rc = (n // 3) * 2 // 64 * 64
+    plain = ops.gemm_rope(a, w, bias, pos, rc, q_cols=rc // 2, q_scale=ops.QK_PRESCALE)
+    mixed = ops.gemm_rope(a, w, bias, pos, rc, q_cols=rc // 2, q_scale=ops.QK_PRESCALE, pv_bf16=True)
+    assert torch.equal(mixed[:, :rc], plain[:, :rc])
+    v32 = ops.gemm(a, w, bias, ops.EPI_F32)[:, rc:]
+    assert torch.equal(mixed[:, rc:].contiguous().view(torch.bfloat16), v32.bfloat16())
+    assert torch.equal(plain[:, rc:], v32.half())
+    a2 = torch.stack([a, a.flip(0)])
+    both = ops.gemm_grouped2(a2, w, w, bias, bias, ops.EPI_BF16_ROPE, rope=(pos, rc, rc // 2, ops.QK_PRESCALE), pv_bf16=True)
+    assert torch.equal(both[0], mixed)
+    assert torch.equal(both[1], ops.gemm_rope(a.flip(0).contiguous(), w, bias, pos, rc, q_cols=rc // 2, q_scale=ops.QK_PRESCALE, pv_bf16=True))
+    with pytest.raises(TypeError):
+        ops.gemm_rope(a.bfloat16(), w.bfloat16(), bias, pos, rc, pv_bf16=True)
 
 
 def test_attention_fast_path_output_overflow_with_finite_row_sum(dev):

@@ -8,8 +8,9 @@ Every GEMM / convolution input, q, k (after RoPE), v and the softmax probabiliti
 the stage (what the HIP kernels do: fp32 accumulation, fp32 residual stream, fp32 LayerNorm statistics); the rel-L2
 distance of the outputs to the un-rounded run is printed per mode:
     bf16        bf16 everywhere
-    bf16+f16h   bf16 trunk (encoder + decoders), fp16 heads - the shipped default (precision="bf16")
-    fp16        fp16 everywhere (precision="fp16")
+    bf16+f16h   bf16 trunk (encoder + decoders), fp16 heads (precision="bf16", BASELINE configs[1])
+    fp16        fp16 everywhere (precision="fp16", load_mast3r's default)
+    fp16+bf16pv fp16 everywhere except v and the softmax probabilities (bf16: the fast attention loop's operand type)
 --stages additionally rounds one stage at a time (bf16) to split the error.
 --stats prints what the "trained_like" family is built to show: residual-stream outlier ratio, LayerNorm gain spread,
 largest attention logit per row, largest GELU input.
@@ -67,7 +68,7 @@ class Emul:
         F.conv_transpose2d = lambda x, wt, b=None, **k: o_ct(rnd.get("dpt", ident)(x), wt, b, **k)
 
         def mha(q, k, v, heads):
-            r = cur["attn"]
+            r = cur.get("pv", cur["attn"])
             return o_mha(q, k, r(v), heads)                      # q, k are rounded after RoPE (as the fused epilogue does)
         OM._mha = mha
         OM.rope2d = lambda x, p, c, s: cur["attn"](o_rope(x, p, c, s))
@@ -76,15 +77,19 @@ class Emul:
             if st is not None:
                 st.setdefault("max_logit", []).append(float(x.amax(-1).float().mean()))
                 st.setdefault("max_logit_p99", []).append(float(x.amax(-1).flatten().kthvalue(max(1, int(0.99 * x.amax(-1).numel()))).values))
-            return cur["attn"](o_sm(x, dim=dim))
+            return cur.get("pv", cur["attn"])(o_sm(x, dim=dim))
         torch.softmax = softmax
 
         def sa(x, w, p, heads, pos, cos, sin):
             cur["attn"] = rnd.get("attn_enc" if p.startswith("enc") else "attn_dec", ident)
+            if "pv" in rnd:
+                cur["pv"] = rnd["pv"]                            # v and the probabilities in their own type (q, k keep "attn")
             return o_sa(x, w, p, heads, pos, cos, sin)
 
         def ca(x, y, w, p, heads, px, py, cos, sin):
             cur["attn"] = rnd.get("attn_dec", ident)
+            if "pv" in rnd:
+                cur["pv"] = rnd["pv"]
             return o_ca(x, y, w, p, heads, px, py, cos, sin)
         OM.self_attn, OM.cross_attn = sa, ca
         if st is not None:
@@ -103,6 +108,7 @@ MODES = {
     "bf16": dict(enc=RB, dec=RB, dpt=RB, feat=RB, attn_enc=RB, attn_dec=RB),
     "bf16+f16h": dict(enc=RB, dec=RB, dpt=RH, feat=RH, attn_enc=RB, attn_dec=RB),
     "fp16": dict(enc=RH, dec=RH, dpt=RH, feat=RH, attn_enc=RH, attn_dec=RH),
+    "fp16+bf16pv": dict(enc=RH, dec=RH, dpt=RH, feat=RH, attn_enc=RH, attn_dec=RH, pv=RB),   # q, k fp16; v and P bf16
 }
 
 

@@ -303,13 +303,8 @@ class PairsWorkload:
             # MASt3R sec. 3.3: reciprocal nearest neighbours in descriptor space from a subsampled seed grid (4096 seeds per
             # pair at 512x512), all P pairs per launch; the sparse matches become the tracker's (index, validity) maps:
             # idx[pair, pixel of view 2] = pixel of view 1
-            torch, P, n = self.torch, self.P, self.n
-            pp, p1, p2 = self.matching.fast_reciprocal_nn_device(sc["D11h"], sc["D21h"], subsample=8, max_iter=3)
-            idx = torch.zeros((P, n), dtype=torch.int64, device=p1.device)
-            valid = torch.zeros((P, n, 1), dtype=torch.bool, device=p1.device)
-            idx[pp, p2] = p1
-            valid[pp, p2, 0] = True
-            return idx, valid
+            m = self.matching.fast_reciprocal_nn_maps(sc["D11h"], sc["D21h"], subsample=8, max_iter=3)   # device-only: capturable
+            return m["idx"], m["valid"]
         return self.matching.match(sc["X11"], sc["X21"], sc["D11"], sc["D21"])
 
     def leg_gn(self, idx, valid):
@@ -342,11 +337,8 @@ class PairsWorkload:
                 graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
                 with torch.cuda.graph(graphs[0]):
                     o1, o2 = self.leg_infer()
-                if self.args.matcher == "fast_nn":
-                    graphs[1] = None                                  # the reciprocal filter ends in a data-dependent compaction
-                else:
-                    with torch.cuda.graph(graphs[1]):
-                        idx, valid = self.leg_match()
+                with torch.cuda.graph(graphs[1]):
+                    idx, valid = self.leg_match()
                 with torch.cuda.graph(graphs[2]):
                     gn = self.leg_gn(idx, valid)
                 torch.cuda.synchronize()
@@ -448,7 +440,7 @@ class PairsWorkload:
                                    + "+ 10-iter GN tracking" + ("" if ctx.dist is None else " + RCCL all-gather of results"),
                        "pairs_per_gpu": P, "global_pairs": world * P, "image": [self.h, self.w], "gn_iters": iters, "matcher": args.matcher,
                        "parallelism": f"pair-sharded x{world}",
-                       "launch": (("2 hipGraph replays per step (infer | GN) around the eagerly launched reciprocal-NN match leg" if sparse else "3 hipGraph replays per step (infer | match | GN)") + ("" if ctx.dist is None else " + RCCL all-gather of the previous step overlapped on the communicator stream")) if self.graphs is not None else "eager"},
+                       "launch": ("3 hipGraph replays per step (infer | match | GN)" + ("" if ctx.dist is None else " + RCCL all-gather of the previous step overlapped on the communicator stream")) if self.graphs is not None else "eager"},
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "stage_ms_note": "device time between stream events recorded around the three graph replays of every TIMED step (mean); sum ~ ms_per_step",
             "match_valid_frac": round(match_valid_frac, 4),

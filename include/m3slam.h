@@ -123,6 +123,21 @@ int m3_frnn_pack(const void *Dmap, void *packed, int P, int N, int D, int in_f16
 int m3_frnn_round(const void *packed1, const void *packed2, int32_t *cur, uint8_t *active, int32_t *got1,
                   int32_t *got2, int32_t *xy2_ws, uint64_t *keys_ws, int P, int S, int N1, int N2, int in_f16,
                   void *stream);
+/* The same round restricted to the seeds that are still active (rounds >= 2): act_ws int32 [P * (S + 1)] scratch receives
+ * the ascending list of active seed slots per pair and their count; search workgroups past a pair's count exit at once.
+ * Same results as m3_frnn_round. */
+int m3_frnn_round_active(const void *packed1, const void *packed2, int32_t *cur, uint8_t *active, int32_t *got1,
+                         int32_t *got2, int32_t *xy2_ws, uint64_t *keys_ws, int32_t *act_ws, int P, int S, int N1,
+                         int N2, int in_f16, void *stream);
+/* The reciprocal pairs of `rounds` rounds (got1 / got2 int32 [rounds,P,S]) as fixed-shape device outputs - no sort, no
+ * host synchronisation (the matcher can be captured into a hipGraph): map1 int32 [P,N1] = view-1 pixel -> its partner
+ * in view 2 (-1 = none); optionally the tracker's maps idx2 int64 [P,N2] / valid2 uint8 [P,N2] (view-2 pixel -> view-1
+ * pixel; both or neither); pairs int32 [P,S,2] = the distinct (p1, p2) of every image pair sorted by p1, count int32 [P]
+ * (rows >= count[pair] are -1; a seed converges at most once, so S bounds the number of pairs); chunk_ws int32
+ * [P * m3_frnn_chunks(N1)] scratch. */
+int m3_frnn_chunks(int N1);
+int m3_frnn_collect(const int32_t *got1, const int32_t *got2, int rounds, int P, int S, int N1, int N2, int32_t *map1,
+                    int64_t *idx2, uint8_t *valid2, int32_t *pairs, int32_t *count, int32_t *chunk_ws, void *stream);
 
 /* ------------------------------------------------------------------ tracking */
 

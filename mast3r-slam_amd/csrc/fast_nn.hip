@@ -205,11 +205,17 @@ template <int PASSES>
 __global__ void __launch_bounds__(kThreads, PASSES == 1 ? 4 : 2)       // fp16 descriptors: 4 waves per SIMD (<= 128 registers)
 k_nn_mfma(const unsigned short *__restrict__ Qhi, const unsigned short *__restrict__ Qlo, const int32_t *__restrict__ qidx,
           const unsigned short *__restrict__ Dhi, const unsigned short *__restrict__ Dlo,
-          unsigned long long *__restrict__ keys, int S, int NQ, int N, int per_split) {
+          unsigned long long *__restrict__ keys, int S_all, int NQ, int N, int per_split,
+          const int32_t *__restrict__ qlist, const int32_t *__restrict__ qcount) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][kRows * 64];   // [stage][hi|lo][64 rows x 64 B]
     const int b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, g = lane >> 4;
-    const size_t qb = (size_t)b * NQ, db = (size_t)b * N, kb = (size_t)b * S;
+    const size_t qb = (size_t)b * NQ, db = (size_t)b * N, kb = (size_t)b * S_all;
+    // active-set form (rounds >= 2 of the reciprocal matcher): only the first qcount[b] entries of qlist[b] are queries -
+    // the seed slots that have not converged yet, in ascending order; a workgroup past the end has nothing to do
+    // (workgroup-uniform exit in front of every barrier).  keys / qidx stay indexed by the seed SLOT.
+    const int S = qcount ? qcount[b] : S_all;
+    if ((int)(blockIdx.x * kQPB) >= S) return;
     // query fragments (MFMA B operand): lane -> query col, k = 8 g .. 8 g + 7
     f16x8 qh[kQT], ql[PASSES == 3 ? kQT : 1];
     const int q0 = blockIdx.x * kQPB + wave * kQPW;
@@ -217,7 +223,8 @@ k_nn_mfma(const unsigned short *__restrict__ Qhi, const unsigned short *__restri
     for (int t = 0; t < kQT; ++t) {
         int q = q0 + t * 16 + col;
         q = q < S ? q : S - 1;
-        int qr = qidx ? qidx[kb + q] : q;
+        const int slot = qlist ? qlist[kb + q] : q;
+        int qr = qidx ? qidx[kb + slot] : slot;
         qr = qr < 0 ? 0 : (qr >= NQ ? NQ - 1 : qr);
         qh[t] = *reinterpret_cast<const f16x8 *>(Qhi + (qb + qr) * 32 + g * 8);
         if (PASSES == 3) ql[t] = *reinterpret_cast<const f16x8 *>(Qlo + (qb + qr) * 32 + g * 8);
@@ -275,7 +282,7 @@ k_nn_mfma(const unsigned short *__restrict__ Qhi, const unsigned short *__restri
         if (g == 0 && q < S) {
             const unsigned long long key = ((unsigned long long)ordered_bits(best[t]) << 32) |
                                            (unsigned long long)(0xffffffffu - (unsigned)bestn[t]);
-            atomicMax(keys + kb + q, key);
+            atomicMax(keys + kb + (qlist ? qlist[kb + q] : q), key);
         }
     }
 }
@@ -286,8 +293,92 @@ __global__ void __launch_bounds__(kThreads)
 k_frnn_mid(unsigned long long *__restrict__ keys, int32_t *__restrict__ xy2, long long total) {
     const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
     if (i >= total) return;
-    xy2[i] = (int32_t)(0xffffffffu - (unsigned)(keys[i] & 0xffffffffull));
+    xy2[i] = (int32_t)(0xffffffffu - (unsigned)(keys[i] & 0xffffffffull));   // (inactive slots: key 0 -> a value nobody reads)
     keys[i] = 0ull;
+}
+// compact: the still-active seed slots of every pair, ascending, + their number - the query list of the next round's
+// searches.  One workgroup per pair walks its S flags in order (ballot + prefix counts): deterministic.
+__global__ void __launch_bounds__(kThreads)
+k_frnn_compact(const uint8_t *__restrict__ active, int32_t *__restrict__ list, int32_t *__restrict__ count, int S) {
+    __shared__ int base, wsum[kThreads / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int s0 = 0; s0 < S; s0 += kThreads) {
+        const int sl = s0 + tid;
+        const bool a = sl < S && active[(size_t)b * S + sl] != 0;
+        const unsigned long long m = __ballot(a);
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (a) list[(size_t)b * S + off + __popcll(m & ((1ull << lane) - 1ull))] = sl;
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < kThreads / 64; ++w) t += wsum[w]; base += t; }
+        __syncthreads();
+    }
+    if (tid == 0) count[b] = base;
+}
+// collect: every reciprocal pair of every round (got1 / got2 [rounds][P][S], -1 = none) into dense maps - map1[pair][p1]
+// = p2 (int32, -1 = none) and, for the tracker, idx2[pair][p2] = p1 / valid2[pair][p2] = 1.  A reciprocal pair is mutual,
+// so p1 <-> p2 is one-to-one per image pair and seeds that found the same pair write the same values.
+__global__ void __launch_bounds__(kThreads)
+k_frnn_scatter(const int32_t *__restrict__ got1, const int32_t *__restrict__ got2, int32_t *__restrict__ map1,
+               long long *__restrict__ idx2, uint8_t *__restrict__ valid2, int P, int S, int N1, int N2, long long total) {
+    const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= total) return;
+    const int p1 = got1[i], p2 = got2[i];
+    if (p1 < 0 || p1 >= N1 || p2 < 0 || p2 >= N2) return;
+    const int b = (int)((i / S) % P);
+    map1[(size_t)b * N1 + p1] = p2;
+    if (idx2) { idx2[(size_t)b * N2 + p2] = p1; valid2[(size_t)b * N2 + p2] = 1; }
+}
+// the distinct pairs as a list sorted by (pair, p1): ordered compaction of map1 in two launches (per-chunk counts, then
+// offsets = sum of the counts in front + an in-chunk prefix) - what torch.unique (a sort and a host synchronisation) did
+constexpr int kChunk = kThreads * 16;
+__global__ void __launch_bounds__(kThreads)
+k_frnn_count(const int32_t *__restrict__ map1, int32_t *__restrict__ chunk_cnt, int N1, int nchunk) {
+    __shared__ int wsum[kThreads / 64];
+    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    const int32_t *m = map1 + (size_t)b * N1;
+    int n = 0;
+    for (int k = 0; k < 16; ++k) { const int i = c * kChunk + tid * 16 + k; n += (i < N1 && m[i] >= 0) ? 1 : 0; }
+    for (int sh = 32; sh >= 1; sh >>= 1) n += __shfl_xor(n, sh, 64);
+    if ((tid & 63) == 0) wsum[tid >> 6] = n;
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int w = 0; w < kThreads / 64; ++w) t += wsum[w]; chunk_cnt[b * nchunk + c] = t; }
+}
+__global__ void __launch_bounds__(kThreads)
+k_frnn_emit(const int32_t *__restrict__ map1, const int32_t *__restrict__ chunk_cnt, int32_t *__restrict__ pairs,
+            int32_t *__restrict__ count, int N1, int nchunk, int cap) {
+    __shared__ int pre[kThreads];
+    __shared__ int off0;
+    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    const int32_t *m = map1 + (size_t)b * N1;
+    if (tid == 0) {
+        int o = 0, tot = 0;
+        for (int k = 0; k < nchunk; ++k) { const int v = chunk_cnt[b * nchunk + k]; if (k < c) o += v; tot += v; }
+        off0 = o;
+        if (c == 0) count[b] = tot < cap ? tot : cap;
+    }
+    int n = 0;
+    for (int k = 0; k < 16; ++k) { const int i = c * kChunk + tid * 16 + k; n += (i < N1 && m[i] >= 0) ? 1 : 0; }
+    pre[tid] = n;
+    __syncthreads();
+    for (int d = 1; d < kThreads; d <<= 1) {                       // inclusive scan of the 256 per-thread counts
+        const int v = tid >= d ? pre[tid - d] : 0;
+        __syncthreads();
+        pre[tid] += v;
+        __syncthreads();
+    }
+    int o = off0 + pre[tid] - n;
+    for (int k = 0; k < 16; ++k) {
+        const int i = c * kChunk + tid * 16 + k;
+        if (i < N1 && m[i] >= 0) {
+            if (o < cap) { pairs[((size_t)b * cap + o) * 2] = i; pairs[((size_t)b * cap + o) * 2 + 1] = m[i]; }
+            ++o;
+        }
+    }
 }
 // end: keys of the backward search -> back; a seed that returned to where it started is a reciprocal pair (recorded in
 // row `round` of got1 / got2, -1 elsewhere) and leaves the active set, the others continue from where they landed
@@ -373,8 +464,10 @@ int m3_nn_search_mfma(const void *Q, const void *DB, int32_t *idx_out, float *sc
     splits = m3_cdiv(N, per_split);
     const dim3 grid(qblocks, splits, B);
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(keys_ws);
-    if (in_f16) hipLaunchKernelGGL(k_nn_mfma<1>, grid, blk, 0, st, qhi, qlo, (const int32_t *)nullptr, dhi, dlo, keys, S, S, N, per_split);
-    else hipLaunchKernelGGL(k_nn_mfma<3>, grid, blk, 0, st, qhi, qlo, (const int32_t *)nullptr, dhi, dlo, keys, S, S, N, per_split);
+    if (in_f16) hipLaunchKernelGGL(k_nn_mfma<1>, grid, blk, 0, st, qhi, qlo, (const int32_t *)nullptr, dhi, dlo, keys, S, S, N, per_split,
+                                   (const int32_t *)nullptr, (const int32_t *)nullptr);
+    else hipLaunchKernelGGL(k_nn_mfma<3>, grid, blk, 0, st, qhi, qlo, (const int32_t *)nullptr, dhi, dlo, keys, S, S, N, per_split,
+                            (const int32_t *)nullptr, (const int32_t *)nullptr);
     M3_CHECK_LAUNCH("m3_nn_search_mfma");
     const long long total = (long long)B * S;
     hipLaunchKernelGGL(k_nn_unpack, dim3((unsigned)m3_cdiv(total, (long long)kThreads)), dim3(kThreads), 0, st,
@@ -407,7 +500,7 @@ int m3_frnn_pack(const void *Dmap, void *packed, int P, int N, int D, int in_f16
 }
 
 static int frnn_search(const void *qpacked, int NQ, const int32_t *qidx, const void *dpacked, int N, unsigned long long *keys,
-                       int P, int S, int in_f16, hipStream_t st) {
+                       int P, int S, int in_f16, hipStream_t st, const int32_t *qlist = nullptr, const int32_t *qcount = nullptr) {
     const unsigned short *qhi = (const unsigned short *)qpacked, *qlo = in_f16 ? nullptr : qhi + (size_t)P * NQ * 32;
     const unsigned short *dhi = (const unsigned short *)dpacked, *dlo = in_f16 ? nullptr : dhi + (size_t)P * N * 32;
     const int qblocks = m3_cdiv(S, kQPB);
@@ -418,8 +511,8 @@ static int frnn_search(const void *qpacked, int NQ, const int32_t *qidx, const v
     per_split = m3_cdiv(per_split, kRows) * kRows;
     splits = m3_cdiv(N, per_split);
     const dim3 grid(qblocks, splits, P), blk(kThreads);
-    if (in_f16) hipLaunchKernelGGL(k_nn_mfma<1>, grid, blk, 0, st, qhi, qlo, qidx, dhi, dlo, keys, S, NQ, N, per_split);
-    else hipLaunchKernelGGL(k_nn_mfma<3>, grid, blk, 0, st, qhi, qlo, qidx, dhi, dlo, keys, S, NQ, N, per_split);
+    if (in_f16) hipLaunchKernelGGL(k_nn_mfma<1>, grid, blk, 0, st, qhi, qlo, qidx, dhi, dlo, keys, S, NQ, N, per_split, qlist, qcount);
+    else hipLaunchKernelGGL(k_nn_mfma<3>, grid, blk, 0, st, qhi, qlo, qidx, dhi, dlo, keys, S, NQ, N, per_split, qlist, qcount);
     return M3_OK;
 }
 
@@ -440,6 +533,59 @@ int m3_frnn_round(const void *packed1, const void *packed2, int32_t *cur, uint8_
     frnn_search(packed2, N2, xy2_ws, packed1, N1, keys, P, S, in_f16, st);            // and back
     hipLaunchKernelGGL(k_frnn_end, eg, eb, 0, st, keys, (const int32_t *)xy2_ws, cur, active, got1, got2, total);
     M3_CHECK_LAUNCH("m3_frnn_round");
+    return M3_OK;
+}
+
+// m3_frnn_round restricted to the seeds that are still active: act_ws int32 [P * (S + 1)] scratch receives the ascending
+// list of active seed slots of every pair ([P][S]) and their count ([P]); the two searches then run on those queries only
+// (workgroups past a pair's count exit at once).  After the first round most seeds of a well-textured pair have found
+// their mutual nearest neighbour, so rounds >= 2 cost a fraction of a full round.  Same results as m3_frnn_round.
+int m3_frnn_round_active(const void *packed1, const void *packed2, int32_t *cur, uint8_t *active, int32_t *got1,
+                         int32_t *got2, int32_t *xy2_ws, uint64_t *keys_ws, int32_t *act_ws, int P, int S, int N1, int N2,
+                         int in_f16, void *stream) {
+    M3_REQUIRE(packed1 && packed2 && cur && active && got1 && got2 && xy2_ws && keys_ws && act_ws);
+    M3_REQUIRE(P > 0 && P <= 65535 && S > 0 && N1 > 0 && N2 > 0);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(keys_ws);
+    int32_t *list = act_ws, *count = act_ws + (size_t)P * S;
+    const long long total = (long long)P * S;
+    const dim3 eb(kThreads), eg((unsigned)m3_cdiv(total, (long long)kThreads));
+    hipLaunchKernelGGL(k_frnn_compact, dim3(P), eb, 0, st, (const uint8_t *)active, list, count, S);
+    frnn_search(packed1, N1, cur, packed2, N2, keys, P, S, in_f16, st, list, count);
+    hipLaunchKernelGGL(k_frnn_mid, eg, eb, 0, st, keys, xy2_ws, total);
+    frnn_search(packed2, N2, xy2_ws, packed1, N1, keys, P, S, in_f16, st, list, count);
+    hipLaunchKernelGGL(k_frnn_end, eg, eb, 0, st, keys, (const int32_t *)xy2_ws, cur, active, got1, got2, total);
+    M3_CHECK_LAUNCH("m3_frnn_round_active");
+    return M3_OK;
+}
+
+// The reciprocal pairs of `rounds` rounds (got1 / got2 int32 [rounds,P,S]) as FIXED-SHAPE device outputs - no sort, no
+// host synchronisation, so the whole matcher can be captured into a hipGraph:
+//   map1  int32 [P,N1]   view-1 pixel -> its reciprocal partner in view 2, -1 = none            (always written)
+//   idx2  int64 [P,N2], valid2 uint8 [P,N2]   the tracker's maps: view-2 pixel -> view-1 pixel  (optional: both or none)
+//   pairs int32 [P,S,2], count int32 [P]   the distinct (p1, p2) of every image pair sorted by p1, rows >= count[pair] = -1
+//                                          (a seed converges at most once: S bounds the number of pairs)
+//   chunk_ws int32 [P * m3_frnn_chunks(N1)] scratch.
+int m3_frnn_chunks(int N1) { return N1 > 0 ? (N1 + kChunk - 1) / kChunk : 0; }
+int m3_frnn_collect(const int32_t *got1, const int32_t *got2, int rounds, int P, int S, int N1, int N2, int32_t *map1,
+                    int64_t *idx2, uint8_t *valid2, int32_t *pairs, int32_t *count, int32_t *chunk_ws, void *stream) {
+    M3_REQUIRE(got1 && got2 && map1 && pairs && count && chunk_ws && rounds > 0 && P > 0 && P <= 65535 && S > 0 && N1 > 0 && N2 > 0);
+    M3_REQUIRE((idx2 == nullptr) == (valid2 == nullptr));
+    hipStream_t st = (hipStream_t)stream;
+    M3_CHECK_HIP(hipMemsetAsync(map1, 0xff, (size_t)P * N1 * 4, st), "m3_frnn_collect/memset");
+    M3_CHECK_HIP(hipMemsetAsync(pairs, 0xff, (size_t)P * S * 8, st), "m3_frnn_collect/memset");
+    if (idx2) {
+        M3_CHECK_HIP(hipMemsetAsync(idx2, 0, (size_t)P * N2 * 8, st), "m3_frnn_collect/memset");
+        M3_CHECK_HIP(hipMemsetAsync(valid2, 0, (size_t)P * N2, st), "m3_frnn_collect/memset");
+    }
+    const long long total = (long long)rounds * P * S;
+    hipLaunchKernelGGL(k_frnn_scatter, dim3((unsigned)m3_cdiv(total, (long long)kThreads)), dim3(kThreads), 0, st, got1, got2, map1,
+                       (long long *)idx2, valid2, P, S, N1, N2, total);
+    const int nchunk = m3_frnn_chunks(N1);
+    hipLaunchKernelGGL(k_frnn_count, dim3(nchunk, P), dim3(kThreads), 0, st, (const int32_t *)map1, chunk_ws, N1, nchunk);
+    hipLaunchKernelGGL(k_frnn_emit, dim3(nchunk, P), dim3(kThreads), 0, st, (const int32_t *)map1, (const int32_t *)chunk_ws, pairs,
+                       count, N1, nchunk, S);
+    M3_CHECK_LAUNCH("m3_frnn_collect");
     return M3_OK;
 }
 

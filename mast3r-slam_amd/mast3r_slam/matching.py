@@ -142,22 +142,22 @@ def nn_search(Q: torch.Tensor, DB: torch.Tensor, return_score: bool = False, met
     return (idx, score) if return_score else idx
 
 
-def fast_reciprocal_nn_device(D1: torch.Tensor, D2: torch.Tensor, subsample: int = 8, max_iter: int = 10):
-    """fast_reciprocal_nn with the whole loop on the device, for ONE pair (D1, D2 [H,W,D]) or a BATCH of P pairs
-    ([P,H,W,D] each) in the same launches: every descriptor map is packed to K-padded fp16 once (m3_frnn_pack) and serves
-    as the database of one search direction and the query source of the other; a round is ONE C-ABI call (m3_frnn_round:
-    forward search, backward search, convergence bookkeeping - four launches for all pairs, no torch glue, no host
-    synchronisation).  Every round runs on the full seed set (converged seeds are masked, a seed that moved continues
-    from where it landed); ONE synchronisation at the end (the final `unique`).  Same result set as the
-    shrinking-active-set version (fast_reciprocal_nn) for the same max_iter.  fp32 or fp16 descriptors.
-    Returns (idx1, idx2) int64 [M] for one pair; (pair, idx1, idx2) int64 [M] (sorted by pair, idx1) for a batch."""
-    batched = D1.dim() == 4
-    if D1.dim() not in (3, 4) or D2.dim() != D1.dim() or D1.shape[-1] != D2.shape[-1] or (batched and D1.shape[0] != D2.shape[0]):
-        raise ValueError("D1, D2 must be [H,W,D] or [P,H,W,D] with the same D (and P)")
+def fast_reciprocal_nn_maps(D1: torch.Tensor, D2: torch.Tensor, subsample: int = 8, max_iter: int = 10, tracker_maps: bool = True):
+    """Fast reciprocal NN for a batch of P pairs (D1, D2 [P,H,W,D], fp32 or fp16) with EVERYTHING on the device and every
+    output of a fixed shape - no host synchronisation, no data-dependent allocation - so the call can be captured into a
+    hipGraph.  Each descriptor map is packed to K-padded fp16 once (m3_frnn_pack) and serves as the database of one
+    search direction and the query source of the other; round 0 runs on all seeds (m3_frnn_round), later rounds only on
+    the seeds that have not converged yet (m3_frnn_round_active: a device-side ordered compaction feeds the searches);
+    m3_frnn_collect turns the rounds' reciprocal pairs into
+        map1   int32 [P,N1]    view-1 pixel -> its reciprocal partner in view 2 (-1 = none)
+        idx    int64 [P,N2], valid bool [P,N2,1]   the tracker's maps (view-2 pixel -> view-1 pixel)   (tracker_maps)
+        pairs  int32 [P,S,2], count int32 [P]      the distinct (p1, p2) per pair, sorted by p1; rows >= count are -1."""
+    if D1.dim() != 4 or D2.dim() != 4 or D1.shape[-1] != D2.shape[-1] or D1.shape[0] != D2.shape[0]:
+        raise ValueError("D1, D2 must be [P,H,W,D] with the same P and D")
     if D1.dtype != D2.dtype:
         raise TypeError(f"D1 and D2 must have the same dtype, got {D1.dtype} / {D2.dtype}")
-    A = _ffi.check(D1 if batched else D1[None], (torch.float32, torch.float16), "D1")
-    B = _ffi.check(D2 if batched else D2[None], A.dtype, "D2")
+    A = _ffi.check(D1, (torch.float32, torch.float16), "D1")
+    B = _ffi.check(D2, A.dtype, "D2")
     P, h1, w1, d = A.shape
     n1, n2 = h1 * w1, B.shape[1] * B.shape[2]
     dev = A.device
@@ -165,9 +165,8 @@ def fast_reciprocal_nn_device(D1: torch.Tensor, D2: torch.Tensor, subsample: int
     xs = torch.arange(subsample // 2, w1, subsample, device=dev)
     seeds = (ys[:, None] * w1 + xs[None, :]).reshape(-1).to(torch.int32)
     s = seeds.numel()
-    e = torch.empty(0, dtype=torch.int64, device=dev)
     if s == 0 or max_iter <= 0:
-        return (e, e, e) if batched else (e, e)
+        raise ValueError("fast_reciprocal_nn_maps needs at least one seed and one round")
     L = _ffi.lib()
     f16 = 1 if A.dtype == torch.float16 else 0
     st = _ffi.stream_ptr()
@@ -181,14 +180,50 @@ def fast_reciprocal_nn_device(D1: torch.Tensor, D2: torch.Tensor, subsample: int
     got2 = torch.empty((max_iter, P, s), dtype=torch.int32, device=dev)
     xy2 = torch.empty((P, s), dtype=torch.int32, device=dev)
     keys = torch.zeros((P, s), dtype=torch.int64, device=dev)
+    act_ws = torch.empty(P * (s + 1), dtype=torch.int32, device=dev)
     for r in range(max_iter):
-        _ffi.call("m3_frnn_round", _ffi.ptr(pk1), _ffi.ptr(pk2), _ffi.ptr(cur), _ffi.ptr(active), _ffi.ptr(got1[r]),
-                  _ffi.ptr(got2[r]), _ffi.ptr(xy2), _ffi.ptr(keys), P, s, n1, n2, f16, st)
-    pid = torch.arange(P, device=dev, dtype=torch.int64)[None, :, None].expand(max_iter, P, s)
-    keep = (got1 >= 0).reshape(-1)
-    trip = torch.stack([pid.reshape(-1)[keep], got1.reshape(-1)[keep].long(), got2.reshape(-1)[keep].long()], 1)
-    trip = torch.unique(trip, dim=0)                                      # the one host synchronisation
-    return (trip[:, 0], trip[:, 1], trip[:, 2]) if batched else (trip[:, 1], trip[:, 2])
+        if r == 0:
+            _ffi.call("m3_frnn_round", _ffi.ptr(pk1), _ffi.ptr(pk2), _ffi.ptr(cur), _ffi.ptr(active), _ffi.ptr(got1[r]),
+                      _ffi.ptr(got2[r]), _ffi.ptr(xy2), _ffi.ptr(keys), P, s, n1, n2, f16, st)
+        else:
+            _ffi.call("m3_frnn_round_active", _ffi.ptr(pk1), _ffi.ptr(pk2), _ffi.ptr(cur), _ffi.ptr(active), _ffi.ptr(got1[r]),
+                      _ffi.ptr(got2[r]), _ffi.ptr(xy2), _ffi.ptr(keys), _ffi.ptr(act_ws), P, s, n1, n2, f16, st)
+    map1 = torch.empty((P, n1), dtype=torch.int32, device=dev)
+    idx = torch.empty((P, n2), dtype=torch.int64, device=dev) if tracker_maps else None
+    valid = torch.empty((P, n2), dtype=torch.uint8, device=dev) if tracker_maps else None
+    pairs = torch.empty((P, s, 2), dtype=torch.int32, device=dev)
+    count = torch.empty((P,), dtype=torch.int32, device=dev)
+    chunk_ws = torch.empty(P * int(L.m3_frnn_chunks(n1)), dtype=torch.int32, device=dev)
+    _ffi.call("m3_frnn_collect", _ffi.ptr(got1), _ffi.ptr(got2), max_iter, P, s, n1, n2, _ffi.ptr(map1), _ffi.ptr(idx),
+              _ffi.ptr(valid), _ffi.ptr(pairs), _ffi.ptr(count), _ffi.ptr(chunk_ws), st)
+    out = dict(map1=map1, pairs=pairs, count=count, seeds=s)
+    if tracker_maps:
+        out["idx"], out["valid"] = idx, valid.view(torch.bool)[:, :, None]
+    return out
+
+
+def fast_reciprocal_nn_device(D1: torch.Tensor, D2: torch.Tensor, subsample: int = 8, max_iter: int = 10):
+    """fast_reciprocal_nn with the whole loop on the device, for ONE pair (D1, D2 [H,W,D]) or a BATCH of P pairs
+    ([P,H,W,D] each) in the same launches (fast_reciprocal_nn_maps).  Same result set as the shrinking-active-set version
+    (fast_reciprocal_nn) for the same max_iter.  fp32 or fp16 descriptors.  ONE host synchronisation, at the end: the pair
+    counts, to cut the fixed-capacity device list to size.
+    Returns (idx1, idx2) int64 [M] for one pair; (pair, idx1, idx2) int64 [M] (sorted by pair, idx1) for a batch."""
+    batched = D1.dim() == 4
+    if D1.dim() not in (3, 4) or D2.dim() != D1.dim() or D1.shape[-1] != D2.shape[-1] or (batched and D1.shape[0] != D2.shape[0]):
+        raise ValueError("D1, D2 must be [H,W,D] or [P,H,W,D] with the same D (and P)")
+    if D1.dtype != D2.dtype:
+        raise TypeError(f"D1 and D2 must have the same dtype, got {D1.dtype} / {D2.dtype}")
+    A, B = (D1, D2) if batched else (D1[None], D2[None])
+    dev = A.device
+    e = torch.empty(0, dtype=torch.int64, device=dev)
+    if max_iter <= 0 or A.shape[1] <= subsample // 2 or A.shape[2] <= subsample // 2:
+        return (e, e, e) if batched else (e, e)
+    m = fast_reciprocal_nn_maps(A, B, subsample, max_iter, tracker_maps=False)
+    counts = m["count"].cpu().tolist()                                    # the one host synchronisation
+    rows = [m["pairs"][p, :c].long() for p, c in enumerate(counts)]
+    pid = torch.cat([torch.full((c,), p, dtype=torch.int64, device=dev) for p, c in enumerate(counts)]) if counts else e
+    trip = torch.cat(rows) if rows else torch.empty((0, 2), dtype=torch.int64, device=dev)
+    return (pid, trip[:, 0], trip[:, 1]) if batched else (trip[:, 0], trip[:, 1])
 
 
 def fast_reciprocal_nn(D1: torch.Tensor, D2: torch.Tensor, subsample: int = 8, max_iter: int = 10):

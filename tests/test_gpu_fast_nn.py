@@ -104,3 +104,61 @@ def test_fast_reciprocal_nn_batched_equals_per_pair(dev):
             assert torch.equal(i1[m], s1) and torch.equal(i2[m], s2) and s1.numel() > 100
     with pytest.raises(ValueError):
         matching.fast_reciprocal_nn_device(D1, D2[:2])
+
+
+def test_fast_reciprocal_nn_maps_fixed_shapes_graph_capture_and_active_rounds(dev):
+    """fast_reciprocal_nn_maps: the whole matcher on the device with fixed-shape outputs (no torch.unique, no host
+    synchronisation) - (1) its sorted pair list equals the set a sort-based reference builds from full rounds
+    (m3_frnn_round on every seed in every round: the active-set rounds must not change a result), (2) the tracker maps
+    are the same pairs seen from view 2, (3) it can be captured into a hipGraph and replayed on new inputs."""
+    from mast3r_slam import _ffi
+    scs = [synthetic.geometric_pair(64, 96, seed=30 + k, batch=1) for k in range(3)]
+    D1 = torch.from_numpy(np.stack([s["D21"][0] for s in scs])).to(dev).half()
+    D2 = torch.from_numpy(np.stack([s["D11"][0] for s in scs])).to(dev).half()
+    P, h, w, d = D1.shape
+    n = h * w
+    rounds, sub = 5, 4
+    m = matching.fast_reciprocal_nn_maps(D1, D2, subsample=sub, max_iter=rounds)
+    counts = m["count"].cpu().tolist()
+    s = m["seeds"]
+    assert m["pairs"].shape == (P, s, 2) and m["idx"].shape == (P, n) and m["valid"].shape == (P, n, 1)
+    # reference: full rounds through the C ABI + a host-side sort / unique
+    L = _ffi.lib()
+    st = _ffi.stream_ptr()
+    pk1 = torch.empty(int(L.m3_frnn_pack_bytes(P, n, 1)), dtype=torch.uint8, device=dev)
+    pk2 = torch.empty_like(pk1)
+    _ffi.call("m3_frnn_pack", _ffi.ptr(D1), _ffi.ptr(pk1), P, n, d, 1, st)
+    _ffi.call("m3_frnn_pack", _ffi.ptr(D2), _ffi.ptr(pk2), P, n, d, 1, st)
+    ys, xs = torch.arange(sub // 2, h, sub, device=dev), torch.arange(sub // 2, w, sub, device=dev)
+    cur = (ys[:, None] * w + xs[None, :]).reshape(-1).to(torch.int32)[None].repeat(P, 1).contiguous()
+    active = torch.ones((P, s), dtype=torch.uint8, device=dev)
+    got1 = torch.empty((rounds, P, s), dtype=torch.int32, device=dev); got2 = torch.empty_like(got1)
+    xy2 = torch.empty((P, s), dtype=torch.int32, device=dev); keys = torch.zeros((P, s), dtype=torch.int64, device=dev)
+    for r in range(rounds):
+        _ffi.call("m3_frnn_round", _ffi.ptr(pk1), _ffi.ptr(pk2), _ffi.ptr(cur), _ffi.ptr(active), _ffi.ptr(got1[r]), _ffi.ptr(got2[r]),
+                  _ffi.ptr(xy2), _ffi.ptr(keys), P, s, n, n, 1, st)
+    later = int((got1[1:] >= 0).sum())
+    assert later > 0                                                 # some seeds do converge after round 0: the active rounds matter
+    for p in range(P):
+        keep = got1[:, p].reshape(-1) >= 0
+        ref = torch.unique(torch.stack([got1[:, p].reshape(-1)[keep], got2[:, p].reshape(-1)[keep]], 1), dim=0)
+        assert counts[p] == ref.shape[0] and counts[p] > 100
+        assert torch.equal(m["pairs"][p, :counts[p]], ref)           # sorted by p1, as torch.unique sorts
+        assert bool((m["pairs"][p, counts[p]:] == -1).all())
+        v = m["valid"][p, :, 0]
+        assert int(v.sum()) == counts[p]
+        assert torch.equal(m["idx"][p][ref[:, 1].long()], ref[:, 0].long())
+        assert torch.equal(m["map1"][p][ref[:, 0].long()], ref[:, 1]) and int((m["map1"][p] >= 0).sum()) == counts[p]
+    # hipGraph capture: static inputs, replay on other data
+    a, b = D1.clone(), D2.clone()
+    for _ in range(2):
+        matching.fast_reciprocal_nn_maps(a, b, subsample=sub, max_iter=rounds)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = matching.fast_reciprocal_nn_maps(a, b, subsample=sub, max_iter=rounds)
+    a.copy_(D1.flip(0)); b.copy_(D2.flip(0))
+    g.replay()
+    torch.cuda.synchronize()
+    assert out["count"].cpu().tolist() == counts[::-1]
+    assert torch.equal(out["pairs"], m["pairs"].flip(0)) and torch.equal(out["idx"], m["idx"].flip(0))

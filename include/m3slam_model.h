@@ -162,6 +162,17 @@ int m3_conv3x3_up_direct_grouped2_dt(const void *X, const void *W0, const void *
                                      const float *bias1, void *Y, const void *zero16, int B, int H, int Wd, int Cin,
                                      int upsample, int dtype, void *stream);
 
+/* The direct convolution as a general 3x3 / pad 1 / stride 1 operator for the wide DPT maps (the residual units of the
+ * fusion blocks, 256 -> 256 channels at 128 x 128 / 64 x 64): X NHWC [(2,)B,H,W,Cin], W_g [Cout,3,3,Cin], Y (and R) NHWC
+ * [(2,)B,H,W,Cout], Cin, Cout in {128, 256}, H, W multiples of 16; epilogue M3_EPI_BF16 | M3_EPI_BF16_RELU |
+ * M3_EPI_BF16_ADD, optionally | M3_EPI_INPUT_RELU.  W1 == NULL: a single group.  Returns THE SAME BITS as
+ * m3_conv3x3_dt / m3_conv3x3_grouped2_dt on the same operands (both walk K as (64-channel slice, tap, k-step) and apply
+ * the epilogue in the same order): the caller picks by problem size - the direct form pays once the grid
+ * (H/16 * ceil(W/32) * B * Cout/128 * groups workgroups) fills the chip. */
+int m3_conv3x3_direct_grouped2_dt(const void *X, const void *W0, const void *W1, const float *bias0, const float *bias1,
+                                  void *Y, const void *R, const void *zero16, int B, int H, int Wd, int Cin, int Cout,
+                                  int epilogue, int dtype, void *stream);
+
 /* Fused multi-head attention, head dim 64: O = softmax(scale * Q K^T) V, bf16 in/out, fp32
  * softmax.  Q/K/V/O are addressed as base + batch*batch_stride + token*row_stride + head*64
  * (element units), so q, k, v may live interleaved in one [tokens, 3C] projection buffer.

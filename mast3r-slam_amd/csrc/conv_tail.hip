@@ -47,7 +47,10 @@ struct TailArgs {
     const bf16_t *W4;       // [4][128]
     const float *b4;        // [4]
     float *pts, *conf;      // [B,H,W,3], [B,H,W]                      (TAIL)
-    bf16_t *Y;              // NHWC [B,H,W,128] 16-bit: conv + bias     (!TAIL)
+    bf16_t *Y;              // NHWC [B,H,W,cout] 16-bit: epi(conv + bias)   (!TAIL); a workgroup writes channels
+                            //   [128 z, 128 z + 128), z = blockIdx.z (cout = 128 or 256)
+    const bf16_t *R;        // EP_ADD: residual, laid out as Y
+    int cout, relu_in;      // relu_in: the convolution reads relu(X) (fragments clamped in registers)
     const bf16_t *zero16;
     int B, H, W, IH, IW;
     // second head (blockIdx.y = 1): its own weights; X / pts / conf advance by one head's extent
@@ -55,9 +58,14 @@ struct TailArgs {
     const float *bias2, *b42;
 };
 
-template <int DT, bool UPS, int CIN, bool TAIL>
+// EP: what happens to the 128 output channels of a workgroup
+enum { EP_PLAIN = 0 /* Y = conv + bias */, EP_TAIL = 1 /* relu -> head.4 -> pointmap */, EP_RELU = 2 /* Y = relu(conv + bias) */,
+       EP_ADD = 3 /* Y = R + conv + bias, one rounding */ };
+
+template <int DT, bool UPS, int CIN, int EP>
 __global__ void __launch_bounds__(kThreads, 2)
 k_conv_tail(const TailArgs ain) {
+    constexpr bool TAIL = EP == EP_TAIL;
     static_assert(CIN % 64 == 0 && (TAIL ? CIN == 128 : true), "64-channel steps; the fused tail is the 128-channel head.2");
     constexpr int NQ = CIN / 64;                            // 64-channel input slices ("halves" of the 128-channel tail)
     TailArgs a = ain;
@@ -68,8 +76,16 @@ k_conv_tail(const TailArgs ain) {
             a.pts = ain.pts + (size_t)ain.B * ain.H * ain.W * 3;
             a.conf = ain.conf + (size_t)ain.B * ain.H * ain.W;
         } else {
-            a.Y = ain.Y + (size_t)ain.B * ain.H * ain.W * 128;
+            a.Y = ain.Y + (size_t)ain.B * ain.H * ain.W * ain.cout;
+            if (EP == EP_ADD) a.R = ain.R + (size_t)ain.B * ain.H * ain.W * ain.cout;
         }
+    }
+    if (!TAIL) {                                            // output-channel half of this workgroup: weight rows, bias, Y / R columns
+        const int z = blockIdx.z;
+        a.Wc += (size_t)z * 128 * 9 * CIN;
+        if (a.bias) a.bias += z * 128;
+        a.Y += z * 128;
+        if (EP == EP_ADD) a.R += z * 128;
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char *halo = lds, *wst = lds + kHaloBytes, *patch = lds + kHaloBytes + 2 * kWStage;
@@ -203,6 +219,10 @@ k_conv_tail(const TailArgs ain) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             af[i] = *reinterpret_cast<const bf16x8 *>(rowp + (i >> 1) * (HW * 128) + ((i & 1) ? c1 : c0));
+        if (!TAIL && a.relu_in) {                           // kernel-uniform: conv(relu(x)) without a relu(x) tensor
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[i] = relu_frag(af[i]);
+        }
     };
     auto mfma_all = [&]() {
         __builtin_amdgcn_s_setprio(1);
@@ -282,10 +302,68 @@ k_conv_tail(const TailArgs ain) {
         run_half(q);                                          // ends behind a barrier: every read of this halo slice is done
     }
 
-    if constexpr (!TAIL) {
-        // ---- epilogue (head.0): acc + bias -> 16 bits, transposed through the dead halo (8 KiB per wave) so that the 64 channels
-        // a wave owns leave as full 128-byte pieces of a pixel's 256-byte row (the scratch layout and its swizzle are
-        // epilogue_rows' 16-bit form, gemm_common.h: 8-byte writes / 16-byte reads, every bank once)
+    if constexpr (EP == EP_ADD) {
+        // ---- epilogue (residual unit's conv2): Y = R + (acc + bias), ONE rounding - the sub-tile goes through the dead halo
+        // in fp32 (two 16-pixel tiles per pass: 32 rows x 272 B per wave), is read back 8 channels per lane (8 lanes = the
+        // 128 contiguous bytes of a pixel's 64-channel half), meets the residual there and leaves as full 128-byte pieces
+        const int r = lane & 15, gq = lane >> 4;
+        constexpr int RS = 272;                              // 64 fp32 + 16 bytes of padding: conflict-free writes
+        unsigned char *wl = halo + wave * (32 * RS);
+        float4 bj[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            bj[j] = a.bias ? *reinterpret_cast<const float4 *>(a.bias + wc * 64 + j * 16 + gq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        auto pix = [&](int pass, int rl, int &oy, int &ox) {
+            const int i = pass * 2 + (rl >> 4);
+            oy = oy0 + wp * 4 + (i >> 1);
+            ox = ox0 + (i & 1) * 16 + (int)((0x3D9F2A40E6C851B7ULL >> (4 * (rl & 15))) & 15);
+        };
+        uint4 q[2][4];                                       // residual pieces of a pass, loaded one pass ahead of their use
+        auto load_resid = [&](int pass, uint4 (&dst)[4]) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int c = it * 64 + lane, rl = c >> 3, ch = c & 7;
+                int oy, ox;
+                pix(pass, rl, oy, ox);
+                ox = ox < a.W ? ox : a.W - 1;
+                dst[it] = *reinterpret_cast<const uint4 *>(a.R + (((size_t)b * a.H + oy) * a.W + ox) * a.cout + wc * 64 + ch * 8);
+            }
+        };
+        load_resid(0, q[0]);
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            if (pass + 1 < 4) load_resid(pass + 1, q[(pass + 1) & 1]);
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = acc[pass * 2 + ii][j];
+                    *reinterpret_cast<float4 *>(wl + (ii * 16 + r) * RS + ((j * 4 + gq) << 4)) =
+                        make_float4(v[0] + bj[j].x, v[1] + bj[j].y, v[2] + bj[j].z, v[3] + bj[j].w);
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int c = it * 64 + lane, rl = c >> 3, ch = c & 7;
+                const float4 f0 = *reinterpret_cast<const float4 *>(wl + rl * RS + ch * 32);
+                const float4 f1 = *reinterpret_cast<const float4 *>(wl + rl * RS + ch * 32 + 16);
+                const uint4 u = q[pass & 1][it];
+                uint4 o;
+                o.x = pack16<DT>(f0.x + lo16<DT>(u.x), f0.y + hi16<DT>(u.x));
+                o.y = pack16<DT>(f0.z + lo16<DT>(u.y), f0.w + hi16<DT>(u.y));
+                o.z = pack16<DT>(f1.x + lo16<DT>(u.z), f1.y + hi16<DT>(u.z));
+                o.w = pack16<DT>(f1.z + lo16<DT>(u.w), f1.w + hi16<DT>(u.w));
+                int oy, ox;
+                pix(pass, rl, oy, ox);
+                if (ox < a.W)
+                    *reinterpret_cast<uint4 *>(a.Y + (((size_t)b * a.H + oy) * a.W + ox) * a.cout + wc * 64 + ch * 8) = o;
+            }
+            asm volatile("" ::: "memory");
+        }
+    } else if constexpr (!TAIL) {
+        // ---- epilogue (head.0, residual unit's conv1): [relu](acc + bias) -> 16 bits, transposed through the dead halo (8 KiB
+        // per wave) so that the 64 channels a wave owns leave as full 128-byte pieces of a pixel's row (the scratch layout and
+        // its swizzle are epilogue_rows' 16-bit form, gemm_common.h: 8-byte writes / 16-byte reads, every bank once)
         const int r = lane & 15, gq = lane >> 4;
         unsigned char *wl = halo + wave * 8192;
         float4 bj[4];
@@ -298,9 +376,14 @@ k_conv_tail(const TailArgs ain) {
             for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f32x4 v = acc[pass * 4 + ii][j];
+                    f32x4 v = acc[pass * 4 + ii][j];
+                    v[0] += bj[j].x; v[1] += bj[j].y; v[2] += bj[j].z; v[3] += bj[j].w;
+                    if (EP == EP_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    }
                     uint2 pk;
-                    pk.x = pack16<DT>(v[0] + bj[j].x, v[1] + bj[j].y); pk.y = pack16<DT>(v[2] + bj[j].z, v[3] + bj[j].w);
+                    pk.x = pack16<DT>(v[0], v[1]); pk.y = pack16<DT>(v[2], v[3]);
                     *reinterpret_cast<uint2 *>(wl + (ii * 16 + r) * 128 + (((j * 2 + (gq >> 1)) ^ ((r >> 1) & 7)) << 4) + (((gq ^ r) & 1) << 3)) = pk;
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -313,7 +396,7 @@ k_conv_tail(const TailArgs ain) {
                 const int oy = oy0 + wp * 4 + (i >> 1);
                 const int ox = ox0 + (i & 1) * 16 + (int)((0x3D9F2A40E6C851B7ULL >> (4 * (rl & 15))) & 15);
                 if (ox < a.W)
-                    *reinterpret_cast<uint4 *>(a.Y + (((size_t)b * a.H + oy) * a.W + ox) * 128 + wc * 64 + ch * 8) = v;
+                    *reinterpret_cast<uint4 *>(a.Y + (((size_t)b * a.H + oy) * a.W + ox) * a.cout + wc * 64 + ch * 8) = v;
             }
             asm volatile("" ::: "memory");
         }
@@ -386,43 +469,48 @@ k_conv_tail(const TailArgs ain) {
 extern "C" {
 
 // X: NHWC [B, H/2, W/2, CIN] when upsample != 0 (the x2 bilinear, align_corners upsampling is done on the fly),
-// else [B, H, W, CIN].  H, W multiples of 16.  Y == nullptr: the fused tail (CIN = 128, pts / conf out); otherwise
-// conv + bias -> Y NHWC [B,H,W,128] 16-bit (CIN = 128 or 256).
+// else [B, H, W, CIN].  H, W multiples of 16.  ep = EP_TAIL: the fused tail (CIN = 128, pts / conf out); otherwise
+// epi(conv + bias) -> Y NHWC [B,H,W,cout] 16-bit (CIN, cout in {128, 256}; R = residual for EP_ADD).
 static int dpt_tail_launch(const void *X, const void *Wc, const float *bias, const void *W4, const float *b4,
                            const void *Wc2, const float *bias2, const void *W42, const float *b42, float *pts,
-                           float *conf, void *Y, const void *zero16, int B, int H, int W, int cin, int upsample, int dtype,
-                           void *stream) {
+                           float *conf, void *Y, const void *R, const void *zero16, int B, int H, int W, int cin, int cout,
+                           int ep, int relu_in, int upsample, int dtype, void *stream) {
     const int groups = Wc2 ? 2 : 1;
-    const bool tail = Y == nullptr;
+    const bool tail = ep == EP_TAIL;
     M3_REQUIRE(X && Wc && zero16 && B > 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0);
-    M3_REQUIRE(tail ? (W4 && b4 && pts && conf && cin == 128) : (cin == 128 || cin == 256));
+    M3_REQUIRE(tail ? (W4 && b4 && pts && conf && cin == 128 && !Y)
+                    : (Y && (cin == 128 || cin == 256) && (cout == 128 || cout == 256) && (ep == EP_PLAIN || ep == EP_RELU || ep == EP_ADD)));
+    M3_REQUIRE((ep == EP_ADD) == (R != nullptr) && (!upsample || ep == EP_PLAIN || tail));
     M3_REQUIRE(groups == 1 || ((!tail || (W42 && b42)) && (bias == nullptr) == (bias2 == nullptr)));
     M3_REQUIRE((dtype == DT_BF16 || dtype == DT_F16) && (!upsample || (H % 2 == 0 && W % 2 == 0)));
     M3_REQUIRE((int64_t)groups * B * H * W < (1ll << 31));
     M3_REQUIRE(reinterpret_cast<uintptr_t>(X) % 16 == 0 && reinterpret_cast<uintptr_t>(Wc) % 16 == 0 &&
-               reinterpret_cast<uintptr_t>(Y) % 16 == 0);
+               reinterpret_cast<uintptr_t>(Y) % 16 == 0 && reinterpret_cast<uintptr_t>(R) % 16 == 0);
     TailArgs a;
     a.Wc2 = (const bf16_t *)Wc2; a.W42 = (const bf16_t *)W42; a.bias2 = bias2; a.b42 = b42;
     a.X = (const bf16_t *)X; a.Wc = (const bf16_t *)Wc; a.bias = bias; a.W4 = (const bf16_t *)W4; a.b4 = b4;
-    a.pts = pts; a.conf = conf; a.Y = (bf16_t *)Y; a.zero16 = (const bf16_t *)zero16; a.B = B; a.H = H; a.W = W;
+    a.pts = pts; a.conf = conf; a.Y = (bf16_t *)Y; a.R = (const bf16_t *)R; a.cout = tail ? 128 : cout; a.relu_in = relu_in;
+    a.zero16 = (const bf16_t *)zero16; a.B = B; a.H = H; a.W = W;
     a.IH = upsample ? H / 2 : H; a.IW = upsample ? W / 2 : W;
-    const dim3 grid((unsigned)((H / TH) * ((W + TW - 1) / TW) * B), groups), blk(kThreads);
+    const dim3 grid((unsigned)((H / TH) * ((W + TW - 1) / TW) * B), groups, tail ? 1 : cout / 128), blk(kThreads);
     hipStream_t st = (hipStream_t)stream;
-#define M3_TAIL(DTV, UP, CI, TL)                                                                                 \
+#define M3_TAIL(DTV, UP, CI, EPV)                                                                                \
     do {                                                                                                         \
         static M3AttrOnce once;                                                                                  \
         int dev__;                                                                                               \
         if (m3_attr_need(once, &dev__)) {                                                                        \
-            M3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_tail<DTV, UP, CI, TL>),      \
+            M3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_tail<DTV, UP, CI, EPV>),     \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes), "m3_dpt_tail/attr"); \
             m3_attr_done(once, dev__);                                                                           \
         }                                                                                                        \
-        hipLaunchKernelGGL((k_conv_tail<DTV, UP, CI, TL>), grid, blk, kLdsBytes, st, a);                         \
+        hipLaunchKernelGGL((k_conv_tail<DTV, UP, CI, EPV>), grid, blk, kLdsBytes, st, a);                        \
     } while (0)
-#define M3_TAIL_DT(UP, CI, TL) do { if (dtype == DT_F16) M3_TAIL(DT_F16, UP, CI, TL); else M3_TAIL(DT_BF16, UP, CI, TL); } while (0)
-    if (tail) { if (upsample) M3_TAIL_DT(true, 128, true); else M3_TAIL_DT(false, 128, true); }
-    else if (cin == 128) { if (upsample) M3_TAIL_DT(true, 128, false); else M3_TAIL_DT(false, 128, false); }
-    else { if (upsample) M3_TAIL_DT(true, 256, false); else M3_TAIL_DT(false, 256, false); }
+#define M3_TAIL_DT(UP, CI, EPV) do { if (dtype == DT_F16) M3_TAIL(DT_F16, UP, CI, EPV); else M3_TAIL(DT_BF16, UP, CI, EPV); } while (0)
+    if (tail) { if (upsample) M3_TAIL_DT(true, 128, EP_TAIL); else M3_TAIL_DT(false, 128, EP_TAIL); }
+    else if (ep == EP_PLAIN && cin == 128) { if (upsample) M3_TAIL_DT(true, 128, EP_PLAIN); else M3_TAIL_DT(false, 128, EP_PLAIN); }
+    else if (ep == EP_PLAIN) { if (upsample) M3_TAIL_DT(true, 256, EP_PLAIN); else M3_TAIL_DT(false, 256, EP_PLAIN); }
+    else if (ep == EP_RELU) { if (cin == 128) M3_TAIL_DT(false, 128, EP_RELU); else M3_TAIL_DT(false, 256, EP_RELU); }
+    else { if (cin == 128) M3_TAIL_DT(false, 128, EP_ADD); else M3_TAIL_DT(false, 256, EP_ADD); }
 #undef M3_TAIL_DT
 #undef M3_TAIL
     M3_CHECK_LAUNCH("m3_dpt_tail");
@@ -432,8 +520,8 @@ static int dpt_tail_launch(const void *X, const void *Wc, const float *bias, con
 int m3_dpt_tail_dt(const void *X, const void *Wc, const float *bias, const void *W4, const float *b4, float *pts,
                    float *conf, const void *zero16, int B, int H, int W, int upsample, int dtype, void *stream) {
     M3_REQUIRE(pts && conf);
-    return dpt_tail_launch(X, Wc, bias, W4, b4, nullptr, nullptr, nullptr, nullptr, pts, conf, nullptr, zero16, B, H, W, 128,
-                           upsample, dtype, stream);
+    return dpt_tail_launch(X, Wc, bias, W4, b4, nullptr, nullptr, nullptr, nullptr, pts, conf, nullptr, nullptr, zero16, B, H, W,
+                           128, 128, EP_TAIL, 0, upsample, dtype, stream);
 }
 
 // Both heads in one launch: X [2,B,h,w,128], pts [2,B,H,W,3], conf [2,B,H,W]; head g uses (Wc_g, bias_g, W4_g, b4_g).
@@ -441,8 +529,8 @@ int m3_dpt_tail_grouped2_dt(const void *X, const void *Wc0, const void *Wc1, con
                             const void *W40, const void *W41, const float *b40, const float *b41, float *pts,
                             float *conf, const void *zero16, int B, int H, int W, int upsample, int dtype, void *stream) {
     M3_REQUIRE(Wc1 != nullptr && pts && conf);
-    return dpt_tail_launch(X, Wc0, bias0, W40, b40, Wc1, bias1, W41, b41, pts, conf, nullptr, zero16, B, H, W, 128, upsample,
-                           dtype, stream);
+    return dpt_tail_launch(X, Wc0, bias0, W40, b40, Wc1, bias1, W41, b41, pts, conf, nullptr, nullptr, zero16, B, H, W, 128, 128,
+                           EP_TAIL, 0, upsample, dtype, stream);
 }
 
 // Direct 3x3 convolution to 128 output channels with the x2 upsample of its input fused in (head.0 of the DPT head:
@@ -451,8 +539,8 @@ int m3_dpt_tail_grouped2_dt(const void *X, const void *Wc0, const void *Wc1, con
 int m3_conv3x3_up_direct_dt(const void *X, const void *Wc, const float *bias, void *Y, const void *zero16, int B, int H,
                             int W, int Cin, int upsample, int dtype, void *stream) {
     M3_REQUIRE(Y != nullptr);
-    return dpt_tail_launch(X, Wc, bias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, Y, zero16, B, H,
-                           W, Cin, upsample, dtype, stream);
+    return dpt_tail_launch(X, Wc, bias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, Y, nullptr, zero16,
+                           B, H, W, Cin, 128, EP_PLAIN, 0, upsample, dtype, stream);
 }
 
 // ... for both heads in one launch: X [2,B,h,w,Cin], Y [2,B,H,W,128]; head g uses (Wc_g, bias_g).
@@ -460,8 +548,24 @@ int m3_conv3x3_up_direct_grouped2_dt(const void *X, const void *Wc0, const void 
                                      void *Y, const void *zero16, int B, int H, int W, int Cin, int upsample, int dtype,
                                      void *stream) {
     M3_REQUIRE(Y != nullptr && Wc1 != nullptr);
-    return dpt_tail_launch(X, Wc0, bias0, nullptr, nullptr, Wc1, bias1, nullptr, nullptr, nullptr, nullptr, Y, zero16, B, H, W,
-                           Cin, upsample, dtype, stream);
+    return dpt_tail_launch(X, Wc0, bias0, nullptr, nullptr, Wc1, bias1, nullptr, nullptr, nullptr, nullptr, Y, nullptr, zero16, B,
+                           H, W, Cin, 128, EP_PLAIN, 0, upsample, dtype, stream);
+}
+
+// The same direct convolution as a general 3x3 / padding 1 / stride 1 operator for the wide DPT maps (the residual units
+// of the fusion blocks: 256 -> 256 at 128 x 128 and 64 x 64): Cin, Cout in {128, 256}; epilogue M3_EPI_BF16 | _RELU | _ADD
+// (R = residual, laid out as Y), optionally OR-ed with M3_EPI_INPUT_RELU.  SAME BITS as m3_conv3x3_dt on the same
+// operands: both walk K as (64-channel slice, tap, k-step) and apply the epilogue in the same order, so a caller may pick
+// either by problem size.  H, W multiples of 16.  W1 == NULL: one group.
+int m3_conv3x3_direct_grouped2_dt(const void *X, const void *W0, const void *W1, const float *bias0, const float *bias1,
+                                  void *Y, const void *R, const void *zero16, int B, int H, int W, int Cin, int Cout,
+                                  int epilogue, int dtype, void *stream) {
+    const int relu_in = (epilogue & 0x100) ? 1 : 0;
+    const int e = epilogue & 0xff;
+    M3_REQUIRE(Y != nullptr && (e == M3_EPI_BF16 || e == M3_EPI_BF16_RELU || e == M3_EPI_BF16_ADD));
+    const int ep = e == M3_EPI_BF16 ? EP_PLAIN : (e == M3_EPI_BF16_RELU ? EP_RELU : EP_ADD);
+    return dpt_tail_launch(X, W0, bias0, nullptr, nullptr, W1, bias1, nullptr, nullptr, nullptr, nullptr, Y, R, zero16, B, H, W,
+                           Cin, Cout, ep, relu_in, 0, dtype, stream);
 }
 
 }  // extern "C"

@@ -82,9 +82,9 @@ k_gemm(const GemmArgs gin) {
         kt += kt0;
         unsigned char *base = lds + buf * kStageBytes;
         int ky = 0, kx = 0, c0 = 0;
-        if (MODE == 1) {
-            const int k0 = kt * BK, tap = k0 / g.Cin;
-            c0 = k0 - tap * g.Cin;
+        if (MODE == 1) {                                     // K-tile kt = (64-channel slice q, tap): see conv_k_offset
+            const int q = kt / 9, tap = kt - q * 9;
+            c0 = q * BK;
             ky = tap / 3; kx = tap - ky * 3;
         }
 #pragma unroll
@@ -99,9 +99,10 @@ k_gemm(const GemmArgs gin) {
             }
             glds16(src, base + i * 4096 + wave * 1024);
         }
+        const size_t koff = MODE == 1 ? conv_k_offset(kt, g.Cin) : (size_t)kt * BK;
 #pragma unroll
         for (int i = 0; i < NT; ++i)
-            glds16(w_src[i] + (size_t)kt * BK, base + BM * BK * 2 + i * 4096 + wave * 1024);
+            glds16(w_src[i] + koff, base + BM * BK * 2 + i * 4096 + wave * 1024);
     };
 
     f32x4 acc[NT][NT];

@@ -83,9 +83,9 @@ k_gemm256(const GemmArgs gin) {
     auto stage_a = [&](int kt, int buf) {
         unsigned char *base = lds + buf * kStageBytes;
         int ky = 0, kx = 0, c0 = 0;
-        if (MODE == 1) {
-            const int k0 = kt * BK, tap = k0 / g.Cin;
-            c0 = k0 - tap * g.Cin;
+        if (MODE == 1) {                                     // K-tile kt = (64-channel slice q, tap): see conv_k_offset
+            const int q = kt / 9, tap = kt - q * 9;
+            c0 = q * BK;
             ky = tap / 3; kx = tap - ky * 3;
         }
 #pragma unroll
@@ -103,9 +103,10 @@ k_gemm256(const GemmArgs gin) {
     };
     auto stage_w = [&](int kt, int buf) {
         unsigned char *base = lds + buf * kStageBytes;
+        const size_t koff = MODE == 1 ? conv_k_offset(kt, g.Cin) : (size_t)kt * BK;
 #pragma unroll
         for (int i = 0; i < WISS; ++i)
-            glds16(w_src[i] + (size_t)kt * BK, base + BM * BK * 2 + i * 8192 + wave * 1024);
+            glds16(w_src[i] + koff, base + BM * BK * 2 + i * 8192 + wave * 1024);
     };
     auto stage = [&](int kt, int buf) { stage_a(kt, buf); stage_w(kt, buf); };
 

@@ -459,6 +459,14 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
     }
 }
 
+// Implicit-GEMM convolution: K-tile kt covers input channels [64 q, 64 q + 64) of tap `tap` with (q, tap) = (kt / 9, kt % 9)
+// - slice-major, the order in which the direct convolution (conv_tail.hip) walks K, so both forms add the same products
+// in the same order and return the same bits.  Offset of that K-tile in a weight row [3][3][Cin]:
+__device__ __forceinline__ size_t conv_k_offset(int kt, int Cin) {
+    const int q = kt / 9, tap = kt - q * 9;
+    return (size_t)tap * Cin + q * BK;
+}
+
 // XCD-aware bijective tile remap: consecutive tiles (sharing an A panel) land on one XCD's L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;

@@ -6,6 +6,8 @@ allocated by the caller-facing wrapper (torch caching allocator) and passed as r
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _ffi
@@ -155,8 +157,10 @@ def gemm_rope(a, w, bias, rope_tok, rope_cols: int, q_cols: int = 0, q_scale: fl
 
 
 def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, epi: int = EPI_BF16, stride: int = 1, resid=None, out=None,
-            relu_input: bool = False):
-    """x NHWC bf16 [B,H,W,Cin], w bf16 [Cout,3,3,Cin] -> NHWC [B,OH,OW,Cout], padding 1.  relu_input: conv(relu(x))."""
+            relu_input: bool = False, direct=None):
+    """x NHWC bf16 [B,H,W,Cin], w bf16 [Cout,3,3,Cin] -> NHWC [B,OH,OW,Cout], padding 1.  relu_input: conv(relu(x)).
+    direct: None = the direct-convolution kernel when its grid fills the chip (conv3x3_direct_ok), True / False force
+    one form - both return the same bits."""
     x = _ffi.check(x, H16, "x")
     w = _ffi.check(w, H16, "w")
     dt = _same16(x, w)
@@ -166,12 +170,14 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, epi: int = EPI_BF16, st
         raise ValueError(f"weight must be [Cout,3,3,{cin}], got {tuple(w.shape)}")
     oh, ow = (h + 2 - 3) // stride + 1, (wd + 2 - 3) // stride + 1
     odt = torch.float32 if epi in _F32_EPIS else x.dtype
-    if out is None:
-        out = torch.empty((b, oh, ow, cout), dtype=odt, device=x.device)
     if bias is not None:
         bias = _ffi.check(bias, torch.float32, "bias", (cout,))
     if resid is not None:
         resid = _ffi.check(resid, odt, "resid", (b, oh, ow, cout))
+    if out is None and direct is not False and epi in (EPI_BF16, EPI_BF16_RELU, EPI_BF16_ADD) and (direct or conv3x3_direct_ok(x, cout, stride)):
+        return _conv3x3_direct(x, w, None, bias, None, epi, resid, relu_input)      # same bits as the implicit-GEMM form
+    if out is None:
+        out = torch.empty((b, oh, ow, cout), dtype=odt, device=x.device)
     ws_bytes = int(_ffi.lib().m3_conv3x3_splitk_bytes(b, h, wd, cin, cout, stride))
     # fp32 partial planes of the split-K path, from torch's caching allocator: stream-ordered, capture-safe
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes > 0 else None
@@ -206,7 +212,7 @@ def conv3x3_relu_head4(x: torch.Tensor, w: torch.Tensor, bias, w4: torch.Tensor,
     return pts, conf
 
 
-def conv3x3_grouped2(x, w0, w1, b0, b1, epi: int = EPI_BF16, stride: int = 1, resid=None, relu_input: bool = False):
+def conv3x3_grouped2(x, w0, w1, b0, b1, epi: int = EPI_BF16, stride: int = 1, resid=None, relu_input: bool = False, direct=None):
     """Two same-shape 3x3 convolutions in one launch (the two DPT heads): x NHWC [2,B,H,W,Cin], group g uses
     (w_g [Cout,3,3,Cin], b_g) -> [2,B,OH,OW,Cout]."""
     x = _ffi.check(x, H16, "x")
@@ -219,9 +225,11 @@ def conv3x3_grouped2(x, w0, w1, b0, b1, epi: int = EPI_BF16, stride: int = 1, re
     cout = w0.shape[0]
     oh, ow = (h + 2 - 3) // stride + 1, (wd + 2 - 3) // stride + 1
     odt = torch.float32 if epi in _F32_EPIS else x.dtype
-    out = torch.empty((2, b, oh, ow, cout), dtype=odt, device=x.device)
     if resid is not None:
         resid = _ffi.check(resid, odt, "resid", (2, b, oh, ow, cout))
+    if direct is not False and epi in (EPI_BF16, EPI_BF16_RELU, EPI_BF16_ADD) and (direct or conv3x3_direct_ok(x, cout, stride)):
+        return _conv3x3_direct(x, w0, w1, b0, b1, epi, resid, relu_input)
+    out = torch.empty((2, b, oh, ow, cout), dtype=odt, device=x.device)
     ws_bytes = 2 * int(_ffi.lib().m3_conv3x3_splitk_bytes(b, h, wd, cin, cout, stride))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes > 0 else None
     e0 = _prof_begin()
@@ -231,6 +239,35 @@ def conv3x3_grouped2(x, w0, w1, b0, b1, epi: int = EPI_BF16, stride: int = 1, re
     _prof_end(e0, "conv3x3", 4.0 * b * oh * ow * cout * 9 * cin,
               2.0 * (2.0 * (b * h * wd * cin + cout * 9 * cin) + out.element_size() * b * oh * ow * cout * (1 if resid is None else 2)),
               f"conv3x3 x2 {b}x{h}x{wd} {cin}->{cout} s{stride} epi{epi} splitk_ws={ws_bytes}")
+    return out
+
+
+DIRECT_CONV_MIN_WGS = 256      # direct convolution once its grid fills the chip (one workgroup per CU); same bits either way
+
+
+def conv3x3_direct_ok(x, cout: int, stride: int = 1) -> bool:
+    """Whether conv3x3 / conv3x3_grouped2 on x (NHWC [B,H,W,Cin] or [2,B,H,W,Cin]) takes the direct-convolution kernel."""
+    g = 2 if x.dim() == 5 else 1
+    b, h, w, cin = x.shape[-4:]
+    if stride != 1 or cin not in (128, 256) or cout not in (128, 256) or h % 16 or w % 16 or os.environ.get("M3_DIRECT_CONV", "1") == "0":
+        return False
+    return (h // 16) * ((w + 31) // 32) * b * (cout // 128) * g >= DIRECT_CONV_MIN_WGS
+
+
+def _conv3x3_direct(x, w0, w1, b0, b1, epi, resid, relu_input):
+    grouped = x.dim() == 5
+    b, h, wd, cin = x.shape[-4:]
+    cout = w0.shape[0]
+    dt = _same16(x, w0, w1)
+    out = torch.empty(tuple(x.shape[:-1]) + (cout,), dtype=x.dtype, device=x.device)
+    e0 = _prof_begin()
+    _ffi.call("m3_conv3x3_direct_grouped2_dt", _ffi.ptr(x), _ffi.ptr(w0), _ffi.ptr(w1), _ffi.ptr(b0), _ffi.ptr(b1), _ffi.ptr(out),
+              _ffi.ptr(resid), _ffi.ptr(zero_page(x.device)), b, h, wd, cin, cout, epi | (EPI_INPUT_RELU if relu_input else 0), dt,
+              _ffi.stream_ptr())
+    g = 2 if grouped else 1
+    _prof_end(e0, "conv_direct", 2.0 * g * b * h * wd * cout * 9 * cin,
+              g * (2.0 * (b * h * wd * cin + cout * 9 * cin) + 2.0 * b * h * wd * cout * (1 if resid is None else 2)),
+              f"conv3x3 direct{' x2' if grouped else ''} {b}x{h}x{wd} {cin}->{cout} epi{epi}")
     return out
 
 

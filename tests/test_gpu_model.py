@@ -600,6 +600,37 @@ def test_conv3x3_with_relu_on_its_input_fragments(dev, dt, bhw_c):
 
 
 @pytest.mark.parametrize("dt", DT16)
+@pytest.mark.parametrize("bhw_ci_co", [(2, 128, 128, 256, 256), (3, 64, 64, 256, 256), (1, 48, 80, 128, 256), (2, 16, 32, 256, 128)])
+def test_direct_convolution_returns_the_bits_of_the_implicit_gemm(dev, dt, bhw_ci_co):
+    """m3_conv3x3_direct_grouped2_dt (the DPT residual units at 128 x 128 / 64 x 64 as a direct convolution: LDS halo,
+    64-channel slices, output channels split over blockIdx.z) against m3_conv3x3_dt on the same operands: BIT-identical for
+    every epilogue (plain, ReLU, residual add with one rounding), with and without ReLU on the input, single and 2-group -
+    both forms walk K as (channel slice, tap, k-step).  The dispatcher may therefore choose by problem size without
+    breaking "a pair gives the same bits alone or in a batch"."""
+    b, h, w, ci, co = bhw_ci_co
+    g = torch.Generator(device="cpu").manual_seed(h + w + ci + co)
+    x = torch.randn(2, b, h, w, ci, generator=g).to(dt).to(dev)
+    wc = [(torch.randn(co, 3, 3, ci, generator=g) * 0.03).to(dt).to(dev) for _ in range(2)]
+    bc = [(torch.randn(co, generator=g) * 0.1).to(dev) for _ in range(2)]
+    res = torch.randn(2, b, h, w, co, generator=g).to(dt).to(dev)
+    for epi, r in ((ops.EPI_BF16, None), (ops.EPI_BF16_RELU, None), (ops.EPI_BF16_ADD, res)):
+        for relu_in in (False, True):
+            one = lambda v, direct: ops.conv3x3(x[v], wc[v], bc[v], epi, resid=None if r is None else r[v], relu_input=relu_in, direct=direct)
+            d0, i0 = one(0, True), one(0, False)
+            assert torch.equal(d0, i0), (epi, relu_in, _rel(d0, i0))
+            both = ops.conv3x3_grouped2(x, wc[0], wc[1], bc[0], bc[1], epi, resid=r, relu_input=relu_in, direct=True)
+            assert torch.equal(both[0], d0) and torch.equal(both[1], one(1, False)), (epi, relu_in)
+    nb = ops.conv3x3(x[0], wc[0], None, ops.EPI_BF16, direct=True)                           # no bias
+    assert torch.equal(nb, ops.conv3x3(x[0], wc[0], None, ops.EPI_BF16, direct=False))
+    xf = torch.relu(x[0].float()).permute(0, 3, 1, 2)
+    ref = (F.conv2d(xf, wc[0].float().permute(0, 3, 1, 2), bc[0], padding=1).permute(0, 2, 3, 1) + res[0].float())
+    got = ops.conv3x3(x[0], wc[0], bc[0], ops.EPI_BF16_ADD, resid=res[0], relu_input=True, direct=True)
+    assert _rel(got, ref) < TOL16[dt]
+    assert ops.conv3x3_direct_ok(torch.empty(16, 128, 128, 256), 256) and not ops.conv3x3_direct_ok(torch.empty(1, 128, 128, 256), 256)
+    assert not ops.conv3x3_direct_ok(torch.empty(16, 128, 128, 192), 256)
+
+
+@pytest.mark.parametrize("dt", DT16)
 @pytest.mark.parametrize("cin", [256, 128])
 @pytest.mark.parametrize("upsample", [True, False])
 @pytest.mark.parametrize("bhw", [(2, 32, 48), (1, 64, 64), (3, 16, 16), (1, 48, 80)])

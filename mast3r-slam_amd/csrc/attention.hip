@@ -70,7 +70,9 @@ struct AttnArgs {
 //     workgroup recompute its block with the MODE 1 loop.  The test is sticky and conservative: l > 2^100 at a range
 //     check or at the end (then o = sum p v may already be inf although l = sum p is finite - l alone would come back
 //     into range and hide it: round-2 advisor finding), a non-finite l, or a non-finite o at the end.
-#define M3_ATTN_EXP 0
+#ifndef M3_ATTN_EXP
+#define M3_ATTN_EXP 0       // experiments (timing-only builds, wrong results): 4 = no exp2 (p = s), 5 = no exp2 and constant P (no packing)
+#endif
 constexpr float kDefer = 8.0f;
 // PVDT: 16-bit type of V in memory and of the probabilities P, i.e. of the O^T = V^T . P^T product.  PVDT = DT except in
 // the mixed mode of the fp16 trunk (DT = fp16, PVDT = bf16, M3_DT_F16_PVBF16): q and k - whose rounding is what an
@@ -247,11 +249,16 @@ k_attn(const AttnArgs a) {
 #pragma unroll
                     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) s[qt][kt][r] = __builtin_amdgcn_exp2f(s[qt][kt][r]);
+                        for (int r = 0; r < 4; ++r) s[qt][kt][r] = (M3_ATTN_EXP >= 4) ? s[qt][kt][r] : __builtin_amdgcn_exp2f(s[qt][kt][r]);
 #if M3_ATTN_EXP == 1
                     for (int kt = 0; kt < 4; ++kt) for (int r = 0; r < 4; ++r) l_run[qt] += s[qt][kt][r];
 #endif
+#if M3_ATTN_EXP == 5
+                    pf[qt][0] = ones; pf[qt][1] = ones;
+                    asm volatile("" :: "v"(s[qt][0]), "v"(s[qt][1]), "v"(s[qt][2]), "v"(s[qt][3]));
+#else
                     pack_p(qt);
+#endif
                 }
             } else if constexpr (MD == 1) {
 #pragma unroll

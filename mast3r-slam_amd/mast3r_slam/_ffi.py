@@ -12,7 +12,8 @@ import re
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libm3slam_hip.so")
+# M3SLAM_LIB: another build of the same library (experiments: ablation builds of one kernel file linked with the shipped objects)
+LIB_PATH = os.environ.get("M3SLAM_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libm3slam_hip.so")
 HEADERS = [os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", h)
            for h in ("m3slam.h", "m3slam_model.h")]
 

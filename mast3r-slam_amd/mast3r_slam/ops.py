@@ -251,6 +251,8 @@ def conv3x3_direct_ok(x, cout: int, stride: int = 1) -> bool:
     b, h, w, cin = x.shape[-4:]
     if stride != 1 or cin not in (128, 256) or cout not in (128, 256) or h % 16 or w % 16 or os.environ.get("M3_DIRECT_CONV", "1") == "0":
         return False
+    if int(_ffi.lib().m3_conv3x3_splitk_bytes(1, h, w, cin, cout, 1)) > 0:
+        return False        # a geometry the implicit-GEMM form runs as split-K (partial planes: another summation order)
     return (h // 16) * ((w + 31) // 32) * b * (cout // 128) * g >= DIRECT_CONV_MIN_WGS
 
 

@@ -215,10 +215,23 @@ k_nn_mfma(const unsigned short *__restrict__ Qhi, const unsigned short *__restri
     // the seed slots that have not converged yet, in ascending order; a workgroup past the end has nothing to do
     // (workgroup-uniform exit in front of every barrier).  keys / qidx stay indexed by the seed SLOT.
     const int S = qcount ? qcount[b] : S_all;
-    if ((int)(blockIdx.x * kQPB) >= S) return;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (qcount) {
+        // The grid was sized for S_all queries (gridDim.x query blocks x gridDim.y database splits = one round of the
+        // chip).  With only nb = ceil(S / 512) query blocks left, the same workgroups are re-dealt as nb query blocks x
+        // (slots / nb) database splits: every CU still works, each on a shorter database range - the round's time shrinks
+        // with the active set instead of staying one full-length workgroup long.  (The per-split winners merge by atomicMax
+        // whatever the number of splits.)
+        if (S <= 0) return;
+        const int nb = (S + kQPB - 1) / kQPB, slots = (int)(gridDim.x * gridDim.y);
+        const int w = by * (int)gridDim.x + bx, nsplit = slots / nb;
+        bx = w % nb; by = w / nb;
+        if (by >= nsplit) return;
+        per_split = (((N + nsplit - 1) / nsplit) + kRows - 1) / kRows * kRows;
+    }
     // query fragments (MFMA B operand): lane -> query col, k = 8 g .. 8 g + 7
     f16x8 qh[kQT], ql[PASSES == 3 ? kQT : 1];
-    const int q0 = blockIdx.x * kQPB + wave * kQPW;
+    const int q0 = bx * kQPB + wave * kQPW;
 #pragma unroll
     for (int t = 0; t < kQT; ++t) {
         int q = q0 + t * 16 + col;
@@ -229,7 +242,7 @@ k_nn_mfma(const unsigned short *__restrict__ Qhi, const unsigned short *__restri
         qh[t] = *reinterpret_cast<const f16x8 *>(Qhi + (qb + qr) * 32 + g * 8);
         if (PASSES == 3) ql[t] = *reinterpret_cast<const f16x8 *>(Qlo + (qb + qr) * 32 + g * 8);
     }
-    const int n0 = blockIdx.y * per_split, n1 = min(n0 + per_split, N);
+    const int n0 = by * per_split, n1 = min(n0 + per_split, N);
     float best[kQT];
     int bestn[kQT];
 #pragma unroll

@@ -556,6 +556,33 @@ class PairsWorkload:
                                          "status": [int(x) for x in info_c[:, 3].tolist()][:2]}
 
         self._backend_block(result, args)
+        if args.precision == "bf16" and args.model == "full":
+            # the loader's default precision (fp16 trunk: fp16 q / k / GEMM operands, bf16 P.V - load_mast3r's and the reference's
+            # default; it is the mode that holds 1e-3 on trained-like weight statistics) through the same
+            # graphed inference leg, for the record beside the bf16 trunk BASELINE configs[1] names
+            from mast3r_slam import model as model_mod
+            net16 = model_mod.Mast3rFull(weights=self.net.host_weights, device=self.ctx.dev, precision="fp16")
+            for _ in range(2):
+                net16.reconstruct_batch(self.im1, self.im2)
+            torch.cuda.synchronize()
+            run16 = lambda: net16.reconstruct_batch(self.im1, self.im2)
+            if self.graphs is not None:
+                g16 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g16):
+                    keep16 = net16.reconstruct_batch(self.im1, self.im2)      # noqa: F841 - the graph's static outputs
+                run16 = g16.replay
+            run16(); torch.cuda.synchronize()
+            e0, e1 = ev(), ev()
+            e0.record()
+            for _ in range(5):
+                run16()
+            e1.record(); torch.cuda.synchronize()
+            ms16 = e0.elapsed_time(e1) / 5
+            result["fp16_trunk"] = {"infer_ms": round(ms16, 3), "bf16_trunk_infer_ms": result["stage_ms"]["infer"],
+                                    "ms_per_step_with_this_infer_leg": round(ms16 + result["stage_ms"]["match"] + result["stage_ms"]["gn"], 3),
+                                    "note": "precision='fp16' (load_mast3r's default): fp16 GEMM / q / k operands, bf16 softmax probabilities and v "
+                                            "(M3_DT_F16_PVBF16), fp16 heads; same graph-replayed inference leg on the same images"}
+            del net16
 
         if P != 1:
             # BASELINE configs[1]: one pair per step (latency regime), same pipeline, graph-replayed

@@ -582,6 +582,108 @@ k_track_gather(const float *__restrict__ Xf_canon, const float *__restrict__ Cf_
     if (threadIdx.x < 2 && cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], cnt[threadIdx.x]);
 }
 
+// Tiled form for spatially coherent matches (the tracker's regime: neighbouring keyframe pixels match neighbouring frame
+// pixels).  A workgroup owns 1024 consecutive keyframe points; when the frame indices they point at span at most kGatherCap
+// points, that contiguous range of Xf_canon / Cf / Qff is staged in LDS with coalesced 16-byte loads and the three
+// data-dependent gathers per point read LDS instead of issuing 12 scattered global loads per lane (one 32-byte sector per
+// 4-12 useful bytes: the round-3 kernel moved 1.52 x its algorithmic bytes and sat at 0.27-0.30 of the HBM roof).
+// Workgroups whose matches are scattered take the global-gather path.  Same values, same arithmetic: same bits.
+constexpr int kGatherCap = 3072;                      // staged frame points: 20 B each = 60 KiB of LDS
+__global__ void __launch_bounds__(kThreads)
+k_track_gather_lds(const float *__restrict__ Xf_canon, const float *__restrict__ Cf_avg,
+                   const float *__restrict__ Ck_avg, const float *__restrict__ Qff, const float *__restrict__ Qkf,
+                   const int64_t *__restrict__ idx, const uint8_t *__restrict__ valid_match,
+                   float *__restrict__ Xf_g, float *__restrict__ Qk, uint8_t *__restrict__ valid_opt,
+                   uint8_t *__restrict__ valid_kf, int32_t *__restrict__ counts, int N, float C_conf, float Q_conf) {
+    extern __shared__ __attribute__((aligned(16))) float gl[];
+    float *Xs = gl, *Cs = gl + 3 * kGatherCap, *Qs = Cs + kGatherCap;
+    __shared__ int rng[2], cnt[2];
+    {
+        const size_t pb = blockIdx.y;
+        Xf_canon += pb * N * 3; Cf_avg += pb * N; Ck_avg += pb * N; Qff += pb * N; Qkf += pb * N; idx += pb * N;
+        valid_match += pb * N; Xf_g += pb * N * 3; Qk += pb * N; valid_opt += pb * N; valid_kf += pb * N; counts += 2 * pb;
+    }
+    const int tid = threadIdx.x, g4 = blockIdx.x * kThreads + tid;
+    const bool live = g4 < N / 4;
+    if (tid == 0) { rng[0] = INT_MAX; rng[1] = INT_MIN; cnt[0] = 0; cnt[1] = 0; }
+    int id[4] = {0, 0, 0, 0};
+    float4 qk4 = make_float4(0.f, 0.f, 0.f, 0.f), ck4 = qk4;
+    unsigned vm4 = 0;
+    if (live) {
+        const longlong2 i01 = reinterpret_cast<const longlong2 *>(idx)[2 * g4], i23 = reinterpret_cast<const longlong2 *>(idx)[2 * g4 + 1];
+        qk4 = reinterpret_cast<const float4 *>(Qkf)[g4]; ck4 = reinterpret_cast<const float4 *>(Ck_avg)[g4];
+        vm4 = reinterpret_cast<const unsigned *>(valid_match)[g4];
+        const long long raw[4] = {i01.x, i01.y, i23.x, i23.y};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                        // the index normalisation of gather_point
+            long long v = raw[k];
+            if (v < 0) v += N;
+            id[k] = (int)(v < 0 ? 0 : (v >= N ? N - 1 : v));
+        }
+    }
+    int lo = live ? min(min(id[0], id[1]), min(id[2], id[3])) : INT_MAX;
+    int hi = live ? max(max(id[0], id[1]), max(id[2], id[3])) : INT_MIN;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_xor(lo, off, 64)); hi = max(hi, __shfl_xor(hi, off, 64)); }
+    __syncthreads();
+    if ((tid & 63) == 0) { atomicMin(&rng[0], lo); atomicMax(&rng[1], hi); }
+    __syncthreads();
+    const int base = rng[0] & ~3, span = rng[1] - base + 1;   // base: a multiple of 4 points = 16-byte aligned in all three arrays
+    const bool staged = rng[0] <= rng[1] && span <= kGatherCap;   // workgroup-uniform
+    if (staged) {
+        const int n4 = (span + 3) / 4;                          // groups of 4 points; the tail group may reach past N - 1:
+        const int last4 = (N - base) / 4;                       //   whole groups that exist (N % 4 == 0, base % 4 == 0)
+        for (int i = tid; i < n4; i += kThreads) {
+            const int j = i < last4 ? i : last4 - 1;
+            reinterpret_cast<float4 *>(Cs)[i] = reinterpret_cast<const float4 *>(Cf_avg + base)[j];
+            reinterpret_cast<float4 *>(Qs)[i] = reinterpret_cast<const float4 *>(Qff + base)[j];
+        }
+        for (int i = tid; i < 3 * n4; i += kThreads) {
+            const int j = i < 3 * last4 ? i : 3 * last4 - 1;
+            reinterpret_cast<float4 *>(Xs)[i] = reinterpret_cast<const float4 *>(Xf_canon + (size_t)base * 3)[j];
+        }
+    }
+    __syncthreads();
+    int vo = 0, vk = 0;
+    if (live) {
+        Gathered r[4];
+        const float qkf[4] = {qk4.x, qk4.y, qk4.z, qk4.w}, ck[4] = {ck4.x, ck4.y, ck4.z, ck4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int vm = (int)((vm4 >> (8 * k)) & 0xffu);
+            float x, y, z, qf, cf;
+            if (staged) {
+                const int o = id[k] - base;
+                x = Xs[3 * o]; y = Xs[3 * o + 1]; z = Xs[3 * o + 2]; qf = Qs[o]; cf = Cs[o];
+            } else {
+                x = Xf_canon[3 * (size_t)id[k]]; y = Xf_canon[3 * (size_t)id[k] + 1]; z = Xf_canon[3 * (size_t)id[k] + 2];
+                qf = Qff[id[k]]; cf = Cf_avg[id[k]];
+            }
+            r[k].x = x; r[k].y = y; r[k].z = z;
+            r[k].q = sqrtf(qf * qkf[k]);
+            r[k].vk = (vm != 0) && (r[k].q > Q_conf);
+            r[k].vo = r[k].vk && (cf > C_conf) && (ck[k] > C_conf);
+        }
+        float4 *xo = reinterpret_cast<float4 *>(Xf_g) + 3 * (size_t)g4;
+        xo[0] = make_float4(r[0].x, r[0].y, r[0].z, r[1].x);
+        xo[1] = make_float4(r[1].y, r[1].z, r[2].x, r[2].y);
+        xo[2] = make_float4(r[2].z, r[3].x, r[3].y, r[3].z);
+        reinterpret_cast<float4 *>(Qk)[g4] = make_float4(r[0].q, r[1].q, r[2].q, r[3].q);
+        reinterpret_cast<unsigned *>(valid_opt)[g4] = (unsigned)r[0].vo | ((unsigned)r[1].vo << 8) | ((unsigned)r[2].vo << 16) | ((unsigned)r[3].vo << 24);
+        reinterpret_cast<unsigned *>(valid_kf)[g4] = (unsigned)r[0].vk | ((unsigned)r[1].vk << 8) | ((unsigned)r[2].vk << 16) | ((unsigned)r[3].vk << 24);
+        vo = r[0].vo + r[1].vo + r[2].vo + r[3].vo;
+        vk = r[0].vk + r[1].vk + r[2].vk + r[3].vk;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { vo += __shfl_down(vo, off, 64); vk += __shfl_down(vk, off, 64); }
+    if ((tid & 63) == 0) {
+        if (vo) atomicAdd(&cnt[0], vo);
+        if (vk) atomicAdd(&cnt[1], vk);
+    }
+    __syncthreads();
+    if (tid < 2 && cnt[tid]) atomicAdd(&counts[tid], cnt[tid]);
+}
+
 __global__ void __launch_bounds__(kThreads)
 k_sim3_act(const float *__restrict__ Tp, const float *__restrict__ X, float *__restrict__ out, int N) {
     const int n = blockIdx.x * kThreads + threadIdx.x;
@@ -607,7 +709,20 @@ int m3_track_gather_batch(const float *Xf_canon, const float *Cf_avg, const floa
     M3_CHECK_HIP(hipMemsetAsync(counts, 0, 2 * P * sizeof(int32_t), st), "m3_track_gather/memset");
     const uintptr_t al = (uintptr_t)idx | (uintptr_t)Qkf | (uintptr_t)Ck_avg | (uintptr_t)Xf_g | (uintptr_t)Qk;
     const uintptr_t al4 = (uintptr_t)valid_match | (uintptr_t)valid_opt | (uintptr_t)valid_kf;
-    if (N % 4 == 0 && (al & 15) == 0 && (al4 & 3) == 0)       // per-problem strides are then multiples of 16 / 4 bytes too
+    const uintptr_t alg = (uintptr_t)Xf_canon | (uintptr_t)Cf_avg | (uintptr_t)Qff;       // staged arrays: 16-byte loads from a 4-point base
+    static const bool tiled = [] { const char *e = getenv("M3_GATHER_LDS"); return !(e && atoi(e) == 0); }();
+    if (tiled && N % 4 == 0 && N >= 4 && ((al | alg) & 15) == 0 && (al4 & 3) == 0) {
+        constexpr int kLds = kGatherCap * 20;
+        static M3AttrOnce once;
+        int dev__;
+        if (m3_attr_need(once, &dev__)) {
+            M3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_track_gather_lds),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, kLds), "m3_track_gather/attr");
+            m3_attr_done(once, dev__);
+        }
+        hipLaunchKernelGGL(k_track_gather_lds, dim3(m3_cdiv(N / 4, kThreads), P), dim3(kThreads), kLds, st, Xf_canon, Cf_avg,
+                           Ck_avg, Qff, Qkf, idx, valid_match, Xf_g, Qk, valid_opt, valid_kf, counts, N, C_conf, Q_conf);
+    } else if (N % 4 == 0 && (al & 15) == 0 && (al4 & 3) == 0)       // per-problem strides are then multiples of 16 / 4 bytes too
         hipLaunchKernelGGL(k_track_gather<true>, dim3(m3_cdiv(N / 4, kThreads), P), dim3(kThreads), 0, st, Xf_canon, Cf_avg,
                            Ck_avg, Qff, Qkf, idx, valid_match, Xf_g, Qk, valid_opt, valid_kf, counts, N, C_conf, Q_conf);
     else

@@ -160,6 +160,31 @@ def test_track_gather_and_sim3_act(dev, n):
     assert np.abs(out - S.sim3_act_mlx(T.astype(np.float64), Xc.astype(np.float64))).max() < 1e-5
 
 
+def test_track_gather_tiled_path_on_coherent_matches(dev):
+    """k_track_gather_lds: workgroups whose 1024 keyframe points match a compact range of frame points gather from an LDS
+    copy of that range, the others (scattered indices, ranges beyond the cap, negative indices, the ragged last
+    workgroup) from global memory - every output exact against numpy either way, counts included."""
+    rng = np.random.default_rng(21)
+    n = 512 * 40 + 1024 * 3 + 512                                       # not a multiple of the 1024-point workgroup
+    Xc = rng.normal(size=(2, n, 3)).astype(np.float32)
+    Cf = rng.uniform(-0.5, 3, (2, n)).astype(np.float32); Ck = rng.uniform(-0.5, 3, (2, n)).astype(np.float32)
+    Qff = rng.uniform(0.5, 4, (2, n)).astype(np.float32); Qkf = rng.uniform(0.5, 4, (2, n)).astype(np.float32)
+    idx = np.arange(n)[None].repeat(2, 0) + rng.integers(-700, 700, size=(2, n))     # coherent: within +-700 of the identity
+    idx = np.clip(idx, 0, n - 1)
+    idx[0, 4096:6144] = rng.integers(0, n, 2048)                         # two workgroups of scattered matches
+    idx[1, 9000:9010] = np.arange(10) - 5 - 3                            # negative indices (wrap by + n, as the kernel does)
+    vm = rng.uniform(size=(2, n)) < 0.8
+    Xf, Qk, vo, vk, cnt = tracker.track_gather(*[_t(a, dev) for a in (Xc, Cf, Ck, Qff, Qkf, idx.astype(np.int64), vm)], 0.0, 1.5)
+    for b in range(2):
+        ii = np.where(idx[b] < 0, idx[b] + n, idx[b])
+        Qk_o = np.sqrt(Qff[b][ii] * Qkf[b])
+        vo_o, vk_o = ot.validity(vm[b], Cf[b][ii], Ck[b], Qk_o, 0.0, 1.5)
+        assert np.array_equal(Xf[b].cpu().numpy(), Xc[b][ii])
+        assert np.array_equal(Qk[b].cpu().numpy(), Qk_o)
+        assert np.array_equal(vo[b].cpu().numpy().astype(bool), vo_o) and np.array_equal(vk[b].cpu().numpy().astype(bool), vk_o)
+        assert cnt[b].cpu().tolist() == [int(vo_o.sum()), int(vk_o.sum())]
+
+
 def test_batched_solve_equals_loop_of_single_solves(dev):
     """P problems in one launch sequence == P separate calls, bit for bit (pairs are independent units)."""
     prs = [_problem(32, 48, 20 + i) for i in range(3)]

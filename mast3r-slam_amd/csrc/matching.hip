@@ -326,7 +326,12 @@ constexpr int kRefineLdsBytes = 64 * 1024;
 // that chain's latency was the kernel's time), no per-candidate bounds branches (out-of-image candidates read a clamped
 // address and are masked at selection), no index multiply per candidate.  Each score is still the same sequential
 // fp32 sum and the selection still walks the candidates in raster order with a strict '>': identical bits.
-template <int D, typename TD, int R>
+// DMA (round 4, fp32 descriptors only - half ones are widened on the way in): the candidate region goes global -> LDS by
+// LDS-DMA (global_load_lds, 16 bytes per lane, no register round trip, every piece of the workgroup in flight at once and
+// ONE wait) instead of load -> wait -> ds_write through VGPRs.  The LDS image is unchanged (7 sixteen-byte slots per
+// pixel, the seventh is padding): a wave-instruction fills 64 consecutive slots, slot s = (pixel s / 7, chunk s % 7), the
+// padding slots re-read chunk 5.  Same image, same inner loop: same bits.
+template <int D, typename TD, int R, bool DMA = false>
 __global__ void __launch_bounds__(kThreads, 2)
 k_refine_lds(const TD *__restrict__ D11, const TD *__restrict__ D21, const int32_t *__restrict__ p_in,
              int32_t *__restrict__ p_out, int H, int W, int N, int radius) {
@@ -378,6 +383,19 @@ k_refine_lds(const TD *__restrict__ D11, const TD *__restrict__ D21, const int32
         // variant, which stages half the pieces, was 50-65 us faster for that reason alone).
         const int per_row = rw * CH, total = rh * per_row;
         constexpr int U = 4;                                   // (8 in flight measured the same)
+        if constexpr (DMA) {
+            static_assert(DescIO<TD>::kVec == 4, "LDS-DMA staging copies bytes: fp32 descriptors only");
+            const int slots = rw * rh * PS4, nslots = (slots + 63) & ~63;      // <= 4096 = the 64 KiB of the tile
+            for (int i0 = threadIdx.x; i0 < nslots; i0 += kThreads) {
+                const int sl = i0 < slots ? i0 : slots - 1;
+                const int pix = sl / PS4, k = sl - pix * PS4;
+                const int ry = pix / rw, rx = pix - ry * rw;
+                const TD *src = img + ((size_t)(y0 + ry) * W + x0 + rx) * D + (k < CH ? k : CH - 1) * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) unsigned *)src,
+                                                 (__attribute__((address_space(3))) unsigned *)(tile + (i0 - lane)), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else
         for (int i0 = threadIdx.x; i0 < total; i0 += kThreads * U) {
             float v[U][V];
             int dofs[U];
@@ -638,6 +656,14 @@ int refine_launch(const TD *D11, const TD *D21, const int32_t *p_in, int32_t *p_
 #define M3_REFINE(DD) hipLaunchKernelGGL((k_refine<DD, TD>), grid, blk, 0, st, D11, D21, p_in, p_out, H, W, N, radius, dmax, chained, tiled)
     const bool single_pass = !chained || dmax == 1;
     if (aligned && D == 24 && tiled && single_pass && radius <= 4) {
+        static const bool dma = [] { const char *e = getenv("M3_REFINE_DMA"); return !(e && atoi(e) == 0); }();
+        if constexpr (DescIO<TD>::kVec == 4) {
+            if (dma && radius == 3) {
+                hipLaunchKernelGGL((k_refine_lds<24, TD, 3, true>), grid, blk, kRefineLdsBytes, st, D11, D21, p_in, p_out, H, W, N, radius);
+                M3_CHECK_LAUNCH("m3_refine_matches");
+                return M3_OK;
+            }
+        }
         if (radius == 3) hipLaunchKernelGGL((k_refine_lds<24, TD, 3>), grid, blk, kRefineLdsBytes, st, D11, D21, p_in, p_out, H, W, N, radius);
         else hipLaunchKernelGGL((k_refine_lds<24, TD, 0>), grid, blk, kRefineLdsBytes, st, D11, D21, p_in, p_out, H, W, N, radius);
     } else if (aligned && D == 24) M3_REFINE(24);

@@ -28,7 +28,7 @@ namespace {
 constexpr int BM = 128, BN = 128;                         // default tile; T = 64 gives 64x64 tiles (latency regime)
 constexpr int kThreads = 256;
 
-template <int MODE /*0 dense, 1 conv3x3*/, int EPI, int T, int DT>
+template <int MODE /*0 dense, 1 conv3x3*/, int EPI, int T, int DT, bool SLICED = false>
 __global__ void __launch_bounds__(kThreads)
 k_gemm(const GemmArgs gin) {
     constexpr int BM = T, BN = T;
@@ -114,6 +114,17 @@ k_gemm(const GemmArgs gin) {
     // fragment read offsets: lane -> row (lane&15), k-chunk (lane>>4) (+4 for the second k-step)
     const int frow = lane & 15, fch = lane >> 4;
 
+    // Sliced accumulation (convolutions on 128 x 128 tiles only): when the split-K rule (pick_splits: a function of the
+    // per-image geometry) asks for S slices but the BATCH already fills the chip with output tiles, one workgroup walks all S
+    // slices itself and adds the slice sums in the finishing kernel's order - tot = ((p0 + p1) + p2) + ... - so the result
+    // is bit-identical to S partial planes + k_splitk_finish without writing and re-reading the planes.
+    // (its own instantiation: the second accumulator set costs 64 registers and the 2-waves-per-SIMD occupancy of the plain one)
+    constexpr bool CAN_SLICE = SLICED;
+    static_assert(!SLICED || (MODE == 1 && T == 128), "sliced accumulation: convolutions on 128 x 128 tiles");
+    f32x4 tot[CAN_SLICE ? NT : 1][CAN_SLICE ? NT : 1];
+    const int slices = CAN_SLICE ? g.slices : 1;
+    int slice = 0, slice_end = slices > 1 ? (int)((long long)nk * 1 / slices) : nk;
+
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
@@ -149,6 +160,27 @@ k_gemm(const GemmArgs gin) {
                     acc[i][j] = mfma16<DT>(wf[j], af[i], acc[i][j]);
         }
         lds_barrier();                          // all waves done reading `buf` (reads RETURNED) before it is restaged
+        if constexpr (CAN_SLICE) {
+            if (slices > 1 && kt + 1 == slice_end) {             // workgroup-uniform: a slice is complete
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        tot[i][j] = slice == 0 ? acc[i][j] : tot[i][j] + acc[i][j];
+                        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                ++slice;
+                slice_end = (int)((long long)nk * (slice + 1) / slices);
+            }
+        }
+    }
+    if constexpr (CAN_SLICE) {
+        if (slices > 1) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = tot[i][j];
+        }
     }
 
     if constexpr (EPI == EPI_RELU_HEAD4) {
@@ -226,6 +258,16 @@ int launch_dt(const GemmArgs &a, int epi, hipStream_t st) {
     const int tiles = m3_cdiv(a.M, T) * m3_cdiv(a.N, T);
     dim3 grid(tiles, a.groups > 1 ? a.groups : 1, a.splits > 1 ? a.splits : 1), blk(kThreads);
 #define M3_L(E) case E: hipLaunchKernelGGL((k_gemm<MODE, E, T, DT>), grid, blk, kLdsBytes, st, a); break
+    if (a.slices > 1) {
+        if constexpr (MODE == 1 && T == 128) {
+            switch (epi) {
+                case EPI_BF16: hipLaunchKernelGGL((k_gemm<1, EPI_BF16, 128, DT, true>), grid, blk, kLdsBytes, st, a); break;
+                case EPI_BF16_RELU: hipLaunchKernelGGL((k_gemm<1, EPI_BF16_RELU, 128, DT, true>), grid, blk, kLdsBytes, st, a); break;
+                case EPI_BF16_ADD: hipLaunchKernelGGL((k_gemm<1, EPI_BF16_ADD, 128, DT, true>), grid, blk, kLdsBytes, st, a); break;
+                default: return M3_ERR_INVALID_ARG;
+            }
+        } else return M3_ERR_INVALID_ARG;
+    } else
     if (epi == EPI_RELU_HEAD4) {
         if constexpr (MODE == 1 && T == 128) hipLaunchKernelGGL((k_gemm<1, EPI_RELU_HEAD4, 128, DT>), grid, blk, kLdsBytes, st, a);
         else return M3_ERR_INVALID_ARG;
@@ -316,6 +358,16 @@ k_splitk_finish(const GemmArgs gin, const float *__restrict__ part, int S) {
 
 template <int MODE>
 int run_split(const GemmArgs &a, int S, int epi, void *ws, hipStream_t st) {
+    if (MODE == 1 && (epi == EPI_BF16 || epi == EPI_BF16_RELU || epi == EPI_BF16_ADD)) {
+        // enough output tiles to give every CU a workgroup: one pass, the S slice sums added in the finishing order (same bits)
+        const long tiles = (long)m3_cdiv(a.M, BM) * m3_cdiv(a.N, BN) * (a.groups > 1 ? a.groups : 1);
+        static const bool sliced_ok = [] { const char *e = getenv("M3_CONV_SLICED"); return !(e && atoi(e) == 0); }();
+        if (sliced_ok && tiles >= 256) {
+            GemmArgs q = a;
+            q.slices = S; q.splits = 1;
+            return launch<MODE>(q, epi, st);
+        }
+    }
     GemmArgs p = a;
     p.C = ws; p.ldc = a.N; p.bias = nullptr; p.bias2 = nullptr; p.R = nullptr; p.splits = S;
     p.c_gstride = (long long)S * a.M * a.N;                     // group 1's planes follow group 0's S planes

@@ -124,6 +124,8 @@ struct GemmArgs {
     int groups;
     // split-K (128x128 kernel, EPI_F32 only): blockIdx.z = split, C = fp32 partials [splits][M][ldc]
     int splits;
+    int slices;             // > 1 (conv, 128 x 128 kernel): ONE workgroup walks all K slices of the split-K rule and adds the slice
+                            //   sums in the finishing kernel's order (same bits as `splits` partial planes + k_splitk_finish)
     // EPI_RELU_HEAD4: W2 = bf16 [4][N] projection, bias2 = its 4 biases, C = pts f32 [M,3], C2 = conf f32 [M]
     float *C2;
     int dt;                 // DT_BF16 / DT_F16: 16-bit storage type of A, W and of 16-bit C / R

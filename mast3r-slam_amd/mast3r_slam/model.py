@@ -383,16 +383,25 @@ class Mast3rFull:
         return out
 
     # ------------------------------------------------------------------ encoder
-    def encode_tokens(self, imgs_u8: torch.Tensor):
+    def encode_tokens(self, imgs_u8: torch.Tensor, imgs2_u8: Optional[torch.Tensor] = None):
         """uint8 [B,H,W,3] -> (enc_norm tokens, trunk 16-bit type, [B*T,1024], (gh,gw)).  Any H, W that are
-        multiples of 16 (resize_img emits e.g. 512x336 -> 672 tokens, 512x288 -> 576)."""
+        multiples of 16 (resize_img emits e.g. 512x336 -> 672 tokens, 512x288 -> 576).  imgs2_u8 (same shape): a second
+        image batch encoded behind the first in the same token matrix ([2B*T,1024]) - both are patchified straight into
+        their halves, no concatenated image tensor."""
         P, c = self.P, self.cfg
         b, h, w, _ = imgs_u8.shape
         gh, gw = h // 16, w // 16
         t = gh * gw
         dt = self.tdt
         rtok = self._rope(gh, gw)
-        x = ops.gemm(ops.patchify16(imgs_u8, dt), P["patch.w"], P["patch.b"], ops.EPI_F32)   # fp32 residual stream
+        if imgs2_u8 is None:
+            patches = ops.patchify16(imgs_u8, dt)
+        else:
+            patches = torch.empty((2 * b * t, 768), dtype=dt, device=imgs_u8.device)
+            ops.patchify16(imgs_u8, dt, out=patches[:b * t])
+            ops.patchify16(imgs2_u8, dt, out=patches[b * t:])
+            b = 2 * b
+        x = ops.gemm(patches, P["patch.w"], P["patch.b"], ops.EPI_F32)                        # fp32 residual stream
         for i in range(c["enc_depth"]):
             p = f"enc_blocks.{i}"
             xn = ops.layernorm(x, P[p + ".norm1.g"], P[p + ".norm1.b"], dtype=dt)
@@ -633,7 +642,7 @@ class Mast3rFull:
         if imgs1.shape != imgs2.shape:
             raise ValueError("both views must have the same shape")
         npairs = imgs1.shape[0]
-        tok, grid = self.encode_tokens(torch.cat([imgs1, imgs2], 0))
+        tok, grid = self.encode_tokens(imgs1, imgs2)
         m = npairs * grid[0] * grid[1]
         return self.decode_heads(tok[:m], tok[m:], npairs, grid)
 

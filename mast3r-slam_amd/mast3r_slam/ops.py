@@ -401,12 +401,18 @@ def layernorm(x, gamma, beta, eps=1e-6, out=None, dtype=torch.bfloat16):
     return out
 
 
-def patchify16(img_u8, dtype=torch.bfloat16):
+def patchify16(img_u8, dtype=torch.bfloat16, out=None):
+    """uint8 [B,H,W,3] -> patch rows [B*T,768] (16-bit); `out`: write into this [B*T,768] slice of a larger token matrix
+    (two image batches patchified into the halves of ONE matrix need no concatenated image tensor)."""
     img_u8 = _ffi.check(img_u8, torch.uint8, "img")
     if img_u8.data_ptr() % 8:                      # a uint8 view with an odd storage offset: the kernel reads 8-byte pieces
         img_u8 = img_u8.clone()                    # (the C entry point rejects a misaligned pointer with a status)
     b, h, w, _ = img_u8.shape
-    out = torch.empty((b * (h // 16) * (w // 16), 768), dtype=dtype, device=img_u8.device)
+    rows = b * (h // 16) * (w // 16)
+    if out is None:
+        out = torch.empty((rows, 768), dtype=dtype, device=img_u8.device)
+    elif out.dtype != dtype or tuple(out.shape) != (rows, 768) or not out.is_contiguous():
+        raise ValueError("bad `out`")
     _ffi.call("m3_patchify16_dt", _ffi.ptr(img_u8), _ffi.ptr(out), b, h, w, DT_CODE[dtype], _ffi.stream_ptr())
     return out
 

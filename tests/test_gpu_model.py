@@ -120,6 +120,30 @@ def test_conv_splitk_is_batch_invariant(dev):
     assert torch.equal(one[0], out[1])
 
 
+@pytest.mark.parametrize("dt", DT16)
+def test_conv_sliced_single_pass_equals_splitk_planes(dev, dt):
+    """32 x 32 maps with K = 9 * 256 are a split-K geometry (4 slices per image, by the per-image rule).  A batch that
+    already gives every CU an output tile (2 x 8 maps: 256 tiles) runs them as ONE pass in which a workgroup walks the 4
+    slices itself and adds the slice sums in the finishing kernel's order; a single image still writes partial planes and
+    runs k_splitk_finish.  Both must return the same bits for every image, for the plain, ReLU (+ input ReLU) and
+    residual-add epilogues - the invariant "a pair gives the same bits alone or in a batch" on the small DPT maps."""
+    from mast3r_slam import _ffi
+    assert int(_ffi.lib().m3_conv3x3_splitk_bytes(1, 32, 32, 256, 256, 1)) == 4 * 1024 * 256 * 4
+    g = torch.Generator(device="cpu").manual_seed(77)
+    x = torch.randn(2, 8, 32, 32, 256, generator=g).to(dt).to(dev)
+    wc = [(torch.randn(256, 3, 3, 256, generator=g) * 0.03).to(dt).to(dev) for _ in range(2)]
+    bc = [(torch.randn(256, generator=g) * 0.1).to(dev) for _ in range(2)]
+    res = torch.randn(2, 8, 32, 32, 256, generator=g).to(dt).to(dev)
+    for epi, r, relu_in in ((ops.EPI_BF16, None, False), (ops.EPI_BF16_RELU, None, True), (ops.EPI_BF16_ADD, res, False)):
+        both = ops.conv3x3_grouped2(x, wc[0], wc[1], bc[0], bc[1], epi, resid=r, relu_input=relu_in)       # 256 tiles: one sliced pass
+        for v in range(2):
+            for b in (0, 5):
+                one = ops.conv3x3(x[v, b:b + 1], wc[v], bc[v], epi, resid=None if r is None else r[v, b:b + 1], relu_input=relu_in)
+                assert torch.equal(both[v, b], one[0]), (epi, v, b, _rel(both[v, b], one[0]))
+    ref = F.conv2d(x[0].float().permute(0, 3, 1, 2), wc[0].float().permute(0, 3, 1, 2), bc[0], padding=1).permute(0, 2, 3, 1)
+    assert _rel(ops.conv3x3_grouped2(x, wc[0], wc[1], bc[0], bc[1], ops.EPI_BF16)[0], ref) < TOL16[dt]
+
+
 def test_gemm_layout_identity_asymmetric(dev):
     """A = I with an asymmetric W catches a transposed C write (guide: 'A=I-check with ASYMMETRIC B')."""
     eye = torch.eye(128, device=dev).bfloat16()

@@ -71,6 +71,9 @@ struct AttnArgs {
 //     workgroup recompute its block with the MODE 1 loop.  The test is sticky and conservative: l > 2^100 at a range
 //     check or at the end (then o = sum p v may already be inf although l = sum p is finite - l alone would come back
 //     into range and hide it: round-2 advisor finding), a non-finite l, or a non-finite o at the end.
+#ifndef M3_ATTN_ABL
+#define M3_ATTN_ABL 0       // experiments (timing-only, wrong results), bit mask on top of M3_ATTN_EXP: 1 = K fragments read once (no
+#endif                      // per-tile ds_read_b128), 2 = V^T fragments read once, 4 = only tile 0 is staged (no global -> LDS traffic)
 #ifndef M3_ATTN_EXP
 #define M3_ATTN_EXP 0       // experiments (timing-only builds, wrong results): 4 = no exp2 (p = s), 5 = no exp2 and constant P (no packing)
 #endif
@@ -153,8 +156,8 @@ k_attn(const AttnArgs a) {
             // where tile t+1 is staged right behind it, with the whole of tile t's arithmetic to land.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             m3gemm::lds_barrier();
-            if (t + 1 < nt) stage(t + 1, buf ^ 1);
-            const unsigned char *Ks = lds + buf * 2 * kTileBytes, *Vs = Ks + kTileBytes;
+            if (t + 1 < nt && !(M3_ATTN_ABL & 4)) stage(t + 1, buf ^ 1);
+            const unsigned char *Ks = lds + ((M3_ATTN_ABL & 4) ? 0 : buf) * 2 * kTileBytes, *Vs = Ks + kTileBytes;
 
             if constexpr (MD == 2) {
                 // range keeper for the row sums of the tiles so far (tested here, a tile late, so that the test does
@@ -194,7 +197,9 @@ k_attn(const AttnArgs a) {
                 for (int kt = 0; kt < 4; ++kt) {
                     const int r = kt * 16 + lq;
                     const int c = (ks * 4 + g) ^ ((r >> 1) & 7);
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + r * 128 + c * 16);
+                    bf16x8 kf;
+                    if ((M3_ATTN_ABL & 1) && t > 0) { kf = qf[0][ks]; asm volatile("" : "+v"(kf)); }
+                    else kf = *reinterpret_cast<const bf16x8 *>(Ks + r * 128 + c * 16);
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt)
                         s[qt][kt] = mfma16<DT>(kf, qf[qt][ks], s[qt][kt]);
@@ -337,6 +342,8 @@ k_attn(const AttnArgs a) {
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     union { bf16x4 h[2]; bf16x8 v; } vf;
+                    if ((M3_ATTN_ABL & 2) && t > 0) { vf.v = qf[0][kk]; asm volatile("" : "+v"(vf.v)); }
+                    else
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
                         const int row = (2 * kk + half) * 16 + g * 4 + tq;

@@ -120,6 +120,28 @@ def test_benchmarked_configuration_eight_pairs_through_the_graph(dev, full_weigh
     assert not torch.equal(o1["pts3d"][0], o1["pts3d"][1])                             # the pairs really differ
 
 
+@pytest.mark.parametrize("prec,P,shape", [("fp16", 3, (384, 512)), ("bf16", 2, (336, 512))])
+def test_batch_versus_alone_at_other_precisions_sizes_and_pair_counts(dev, full_weights, prec, P, shape):
+    """The same "alone == in a batch" statement where the DISPATCH differs from the benchmarked case: the loader's default
+    precision (fp16 operands with bf16 P.V attention, k_attn<.., DT_F16, 2, DT_BF16>), BASELINE configs[0]'s 512x384
+    (768 tokens: 6 key tiles, 192-row tails) and a 672-token size resize_img emits, odd pair counts (3 pairs = 6 images:
+    the direct convolutions switch on for some maps and not for others, the dense launches fall between the 128 and
+    the 256 tiles).  Full depth, graph replay of P pairs against every pair alone, bit for bit."""
+    h, w = shape
+    im1 = np.stack([synthetic.textured_image(h, w, 20 + 2 * p) for p in range(P)])
+    im2 = np.stack([synthetic.textured_image(h, w, 21 + 2 * p) for p in range(P)])
+    net = M.Mast3rFull(weights=full_weights, device=dev, precision=prec)
+    o1, o2 = net.graphed(P, h, w)(im1, im2)
+    o1, o2 = ({k: v.clone() for k, v in o.items()} for o in (o1, o2))
+    for p in range(P):
+        e1, e2 = net.reconstruct_batch(im1[p:p + 1], im2[p:p + 1])
+        for k in ("pts3d", "conf", "desc", "desc_conf"):
+            assert torch.isfinite(o1[k][p]).all() and torch.isfinite(o2[k][p]).all(), (p, k)
+            assert torch.equal(o1[k][p], e1[k][0]), (prec, p, k, "view 1", _rel(o1[k][p], e1[k][0]))
+            assert torch.equal(o2[k][p], e2[k][0]), (prec, p, k, "view 2", _rel(o2[k][p], e2[k][0]))
+    assert not torch.equal(o1["pts3d"][0], o1["pts3d"][1])
+
+
 # Trained-like statistics (model.init_random_weights(family="trained_like")): rel-L2 bounds at FULL depth, 512x512.
 # CPU emulation of operand rounding (tools/emul_precision.py --family trained_like --res 512 512): pts3d view 1 / view 2
 #   bf16 trunk + fp16 heads 1.28e-3 / 2.34e-3 (encoder GEMM operands 9e-4 / 1.7e-3, encoder q|k|v|P 9e-4 / 1.6e-3: an

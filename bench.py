@@ -502,18 +502,25 @@ class PairsWorkload:
         # fp16 descriptors, 3 rounds; not part of the timed step.  MFMA roofline per search launch: 2 S N D flops
         # (D = 24; the kernel multiplies K padded to 32) over the device time of the k_nn_mfma launch.
         d1, d2 = sc["D21"].half(), sc["D11"].half()
-        for _ in range(2):
-            matching.fast_reciprocal_nn_maps(d1, d2, subsample=8, max_iter=3)
-        e0, e1 = ev(), ev()
-        e0.record()
-        for _ in range(3):
-            mp = matching.fast_reciprocal_nn_maps(d1, d2, subsample=8, max_iter=3)
-        e1.record(); torch.cuda.synchronize()
-        ms_all = e0.elapsed_time(e1) / 3
+
+        def time_frnn(prune):
+            for _ in range(2):
+                matching.fast_reciprocal_nn_maps(d1, d2, subsample=8, max_iter=3, prune=prune)
+            e0, e1 = ev(), ev()
+            e0.record()
+            for _ in range(3):
+                out = matching.fast_reciprocal_nn_maps(d1, d2, subsample=8, max_iter=3, prune=prune)
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / 3, out
+        ms_all, mp = time_frnn(True)                  # the default: exact block-bound search (m3_frnn_round_pruned)
+        ms_brute, mb = time_frnn(False)               # every seed against every pixel (m3_frnn_round / _active)
+        same = all(bool(torch.equal(mp[k], mb[k])) for k in ("map1", "pairs", "count", "idx", "valid"))
         # the rounds alone, HIP events around the C-ABI calls: round 0 runs every seed (two full searches), rounds 1, 2 only
-        # the seeds that have not converged (m3_frnn_round_active)
-        _ffi.PROFILE, _ffi.PROFILE_NAMES = {}, ("m3_frnn_round", "m3_frnn_round_active")
-        matching.fast_reciprocal_nn_maps(d1, d2, subsample=8, max_iter=3)
+        # the seeds that have not converged
+        names = ("m3_frnn_round", "m3_frnn_round_active", "m3_frnn_round_pruned")
+        _ffi.PROFILE, _ffi.PROFILE_NAMES = {}, names
+        matching.fast_reciprocal_nn_maps(d1, d2, subsample=8, max_iter=3, prune=False)
+        matching.fast_reciprocal_nn_maps(d1, d2, subsample=8, max_iter=3, prune=True)
         torch.cuda.synchronize()
         prof_r, _ffi.PROFILE = _ffi.PROFILE, None
         us_of = lambda name: [a_.elapsed_time(b_) * 1e3 for a_, b_ in prof_r.get(name, [])]
@@ -522,14 +529,20 @@ class PairsWorkload:
         fl_search = 2.0 * P * seeds * (self.h * self.w) * 24
         result["fast_nn_matcher"] = {"ms_per_pair": round(ms_all / P, 3), "ms_all_pairs": round(ms_all, 3), "pairs": P,
                                      "reciprocal_pairs": int(mp["count"].sum()), "seeds_per_pair": seeds,
-                                     "round_us": us_round, "active_round_us": [round(u, 1) for u in us_of("m3_frnn_round_active")],
-                                     "roofline": {"bound": "mfma", "kernel": "k_nn_mfma<1> (two full searches + bookkeeping: m3_frnn_round, round 0)",
+                                     "pruned_round_us": [round(u, 1) for u in us_of("m3_frnn_round_pruned")],
+                                     "brute_force": {"ms_all_pairs": round(ms_brute, 3), "same_outputs_bit_for_bit": same,
+                                                     "round_us": us_round,
+                                                     "active_round_us": [round(u, 1) for u in us_of("m3_frnn_round_active")]},
+                                     "roofline": {"bound": "mfma", "kernel": "k_nn_mfma<1> (brute force: two full searches + bookkeeping, m3_frnn_round, round 0)",
                                                   "achieved": 2 * fl_search / us_round / 1e6, "peak": MFMA_BF16_PEAK_TFLOPS,
                                                   "unit": "TFLOP/s", "frac": 2 * fl_search / us_round / 1e6 / MFMA_BF16_PEAK_TFLOPS,
                                                   "flops_note": "2 S N D with D = 24 (K is padded to 32 on the matrix core: x 4/3 issued)"},
                                      "note": f"fast_reciprocal_nn_maps on {P} pairs at once (hipGraph-capturable: fixed-shape device outputs, no "
-                                             f"host synchronisation): m3_frnn_pack x 2 + m3_frnn_round + 2 x m3_frnn_round_active + m3_frnn_collect, "
-                                             f"fp16 descriptors, {seeds} seeds x {self.h * self.w} pixels per full search"}
+                                             f"host synchronisation): m3_frnn_pack x 2 + m3_frnn_blockstats x 2 + 3 x m3_frnn_round_pruned + "
+                                             f"m3_frnn_collect, fp16 descriptors, {seeds} seeds x {self.h * self.w} pixels per search.  The "
+                                             f"default search is EXACT with block bounds (8 x 8 pixel tiles: centroid + radius, Cauchy-Schwarz): "
+                                             f"same index and score as the brute-force search, which stays the device-side fallback and whose "
+                                             f"MFMA rate the roofline block quotes"}
 
         # calibrated tracking solve (tracker.py:326-406; pixel + log-depth residuals through a pinhole K): same streams as
         # the ray-distance solve (Xf 12 + Xk 12 + Qk 4 + valid 1 B per point and iteration), all P problems per launch

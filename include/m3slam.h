@@ -129,6 +129,25 @@ int m3_frnn_round(const void *packed1, const void *packed2, int32_t *cur, uint8_
 int m3_frnn_round_active(const void *packed1, const void *packed2, int32_t *cur, uint8_t *active, int32_t *got1,
                          int32_t *got2, int32_t *xy2_ws, uint64_t *keys_ws, int32_t *act_ws, int P, int S, int N1,
                          int N2, int in_f16, void *stream);
+/* The same rounds with an EXACT pruned search (round 4).  The maps are H x W pixels in raster order (N = H * W).  Per
+ * packed map, once per call, m3_frnn_blockstats writes for every 8 x 8 pixel tile a reference point (its centroid, fp16),
+ * its radius and a norm bound (stats: m3_frnn_stats_bytes(P, H, W) bytes, 16-byte aligned).  A search then scores the
+ * queries against the tile centroids on the matrix core (1/64 of the full search), drops every (16-query tile, block)
+ * whose Cauchy-Schwarz bound <q, c> + |q| r lies below a lower bound of the query's final maximum, and scores the
+ * surviving blocks with the MFMA sequence of the brute-force kernel - index and score equal m3_frnn_round's bit for bit
+ * (a block holding the maximum or a tie always survives; ties go to the lowest pixel index).  When more than a quarter
+ * of the pairs survive (descriptor maps without spatial coherence) the brute-force kernel runs instead; both test one
+ * device counter, no host decision.  act_ws as in m3_frnn_round_active, or NULL for a round on every seed; seed_order
+ * int32 [S] or NULL: the order in which the active slots are listed (with act_ws) - the searches work on groups of
+ * consecutive entries, so an order that walks the seed grid in small patches prunes more; no result depends on it.
+ * prune_ws: m3_frnn_prune_ws_bytes(...) bytes, 16-byte aligned.  Finite descriptors are assumed. */
+int64_t m3_frnn_stats_bytes(int P, int H, int W);
+int m3_frnn_blockstats(const void *packed, void *stats, int P, int H, int W, int in_f16, void *stream);
+int64_t m3_frnn_prune_ws_bytes(int P, int S, int H1, int W1, int H2, int W2);
+int m3_frnn_round_pruned(const void *packed1, const void *packed2, const void *stats1, const void *stats2, int32_t *cur,
+                         uint8_t *active, int32_t *got1, int32_t *got2, int32_t *xy2_ws, uint64_t *keys_ws,
+                         int32_t *act_ws, const int32_t *seed_order, void *prune_ws, int P, int S, int H1, int W1, int H2,
+                         int W2, int in_f16, void *stream);
 /* The reciprocal pairs of `rounds` rounds (got1 / got2 int32 [rounds,P,S]) as fixed-shape device outputs - no sort, no
  * host synchronisation (the matcher can be captured into a hipGraph): map1 int32 [P,N1] = view-1 pixel -> its partner
  * in view 2 (-1 = none); optionally the tracker's maps idx2 int64 [P,N2] / valid2 uint8 [P,N2] (view-2 pixel -> view-1

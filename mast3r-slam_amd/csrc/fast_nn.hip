@@ -123,6 +123,13 @@ k_nn_pack(const void *__restrict__ X, unsigned short *__restrict__ hi, unsigned 
     if (lo) reinterpret_cast<uint4 *>(lo)[i] = L.q;
 }
 
+// ---- exact search with block bounds: shared definitions (kernels further down) ----
+constexpr float kSlack = 1.52587890625e-05f;   // 2^-16: covers the fp32 rounding of the bound and of the scores it is compared with
+// more than a quarter of all (query tile, block) pairs survived: the brute-force kernel is the faster one
+__device__ __forceinline__ bool prune_overflow(int total, int S, int NB) {
+    return (long long)total * 4 > (long long)((S + 15) / 16) * NB;
+}
+
 constexpr int kQT = 8;                      // query tiles (16 queries each) per wave
 constexpr int kQPW = kQT * 16;              // queries per wave
 constexpr int kQPB = kQPW * (kThreads / 64);   // queries per workgroup: 512
@@ -206,9 +213,12 @@ __global__ void __launch_bounds__(kThreads, PASSES == 1 ? 4 : 2)       // fp16 d
 k_nn_mfma(const unsigned short *__restrict__ Qhi, const unsigned short *__restrict__ Qlo, const int32_t *__restrict__ qidx,
           const unsigned short *__restrict__ Dhi, const unsigned short *__restrict__ Dlo,
           unsigned long long *__restrict__ keys, int S_all, int NQ, int N, int per_split,
-          const int32_t *__restrict__ qlist, const int32_t *__restrict__ qcount) {
+          const int32_t *__restrict__ qlist, const int32_t *__restrict__ qcount,
+          const int32_t *__restrict__ gate_total, int gate_nb) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][kRows * 64];   // [stage][hi|lo][64 rows x 64 B]
     const int b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // fallback of the block-bound search (k_frnn_eval below): runs only when the bounds pruned too little
+    if (gate_total && !prune_overflow(gate_total[b], qcount ? qcount[b] : S_all, gate_nb)) return;
     const int col = lane & 15, g = lane >> 4;
     const size_t qb = (size_t)b * NQ, db = (size_t)b * N, kb = (size_t)b * S_all;
     // active-set form (rounds >= 2 of the reciprocal matcher): only the first qcount[b] entries of qlist[b] are queries -
@@ -300,6 +310,375 @@ k_nn_mfma(const unsigned short *__restrict__ Qhi, const unsigned short *__restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Round 4: the SAME arg-max with most of the database never touched.  The brute-force search above scores every seed
+// against every pixel of the other view (4096 x 262 144 x 2 directions per pair and round); a descriptor map is smooth,
+// so whole patches of pixels can be excluded by a bound.  Per map, once per matcher call (k_frnn_blockstats): for every
+// block = 8 x 8 pixel tile (a first version used 64 consecutive pixels of an image row: radius 0.63 on the synthetic
+// scene's unit descriptors, a quarter of all blocks survived; a square tile is four times more compact) a reference point
+// c (the centroid, rounded to fp16 so that it is an exact MFMA operand), the radius r = max ||x - c|| and ||c|| + r.
+// Blocks are numbered by * ceil(W / 8) + bx; block-local row 8 ry + rx is pixel (8 by + ry, 8 bx + rx); the packed map
+// itself stays in raster order (a packed row is 64 bytes: the tile's rows are gathered by address).
+// For a query q and ANY row x of the block (Cauchy-Schwarz)
+//        <q, x> = <q, c> + <q, x - c>  <=  <q, c> + ||q|| r.
+// Per search:
+//   1. k_nn_mfma on the CENTROIDS (N / 64 rows) picks a promising block per query; k_frnn_seed_lb scores its 64 rows ->
+//      a lower bound m(q) of the final maximum (minus a slack for the rounding differences to the MFMA scores);
+//   2. k_frnn_survivors: <q, c> for all (query, block) pairs on the matrix core (1/64 of the full search), one bit per
+//      (16-query tile, block): set unless  <q, c> + ||q|| (r + slack)  <  m(q)  for all 16 queries;
+//   3. k_frnn_eval scores the surviving blocks with the SAME MFMA sequence as nn_step (bit-identical scores) and keeps
+//      (score, lowest PIXEL index) - tiles are not visited in raster order, so ties compare indices explicitly - then the
+//      same 64-bit key merge; a block that holds the maximum, or a tie with it, always survives (its bound is >= its
+//      best score >= m), so index AND score equal the brute-force result bit for bit;
+//   4. if more than a quarter of the pairs survived (descriptors without spatial coherence, e.g. a random-weight
+//      network), k_frnn_eval stands down and k_nn_mfma runs instead (both test the same device counter).
+// Finite descriptors are assumed (this file is built with -fno-honor-nans, as the brute-force kernel always was).
+__device__ __forceinline__ void load_row32(const unsigned short *__restrict__ hi, const unsigned short *__restrict__ lo, size_t row,
+                                           float (&x)[32]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        union { uint4 q; _Float16 h[8]; } H, L;
+        H.q = reinterpret_cast<const uint4 *>(hi + row * 32)[c];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[c * 8 + k] = (float)H.h[k];
+        if (lo) {
+            L.q = reinterpret_cast<const uint4 *>(lo + row * 32)[c];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[c * 8 + k] += (float)L.h[k];
+        }
+    }
+}
+
+// cen [P][NBp][32] fp16, rad / bn [P][NBp] fp32; NBp = blocks rounded up to a multiple of 64 (padding: rad = -inf).
+// One wave per tile: lane = (tile row ry = lane >> 3, dimension quad dq = lane & 7) owns the 8 pixels of its row x 4
+// dimensions (8-byte loads; the 8 lanes of a row cover the pixels' 64-byte packed rows), so the centroid needs 3 shuffle
+// steps per dimension quad and the squared distances 3 per pixel (a first version - lane = pixel, 32 wave reductions - took
+// 78 us per 8 maps, more than the searches it serves).
+__global__ void __launch_bounds__(kThreads)
+k_frnn_blockstats(const unsigned short *__restrict__ hi, const unsigned short *__restrict__ lo, unsigned short *__restrict__ cen,
+                  float *__restrict__ rad, float *__restrict__ bn, int H, int W, int NB, int NBp) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, blk = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (blk >= NBp) return;
+    const size_t sb = (size_t)b * NBp + blk;
+    if (blk >= NB) {
+        if (lane < 4) reinterpret_cast<uint4 *>(cen + sb * 32)[lane] = make_uint4(0u, 0u, 0u, 0u);
+        if (lane == 0) { rad[sb] = -INFINITY; bn[sb] = 0.f; }
+        return;
+    }
+    const int BW = (W + 7) >> 3, by = blk / BW, bx = blk - by * BW;
+    const int ry = lane >> 3, dq = lane & 7;
+    const int y = by * 8 + ry, ch = H - by * 8 < 8 ? H - by * 8 : 8, cw = W - bx * 8 < 8 ? W - bx * 8 : 8;
+    const bool rowok = y < H;
+    float v[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bool ok = rowok && i < cw;
+        const size_t row = (size_t)b * H * W + (ok ? (size_t)y * W + bx * 8 + i : (size_t)by * 8 * W + bx * 8);
+        union { uint2 q; _Float16 h[4]; } A;
+        A.q = *reinterpret_cast<const uint2 *>(hi + row * 32 + dq * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[i][k] = (float)A.h[k];
+        if (lo) {
+            A.q = *reinterpret_cast<const uint2 *>(lo + row * 32 + dq * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[i][k] += (float)A.h[k];
+        }
+        if (!ok) { v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f; }
+    }
+    const float inv = 1.0f / (float)(ch * cw);
+    float cf[4], c2 = 0.f;
+    union { unsigned short h[4]; uint2 q; } C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float sum = ((v[0][k] + v[1][k]) + (v[2][k] + v[3][k])) + ((v[4][k] + v[5][k]) + (v[6][k] + v[7][k]));
+#pragma unroll
+        for (int sh = 8; sh <= 32; sh <<= 1) sum += __shfl_xor(sum, sh, 64);        // over the 8 tile rows
+        const _Float16 c16 = (_Float16)(sum * inv);
+        C.h[k] = __builtin_bit_cast(unsigned short, c16);
+        cf[k] = (float)c16;
+        c2 = fmaf(cf[k], cf[k], c2);
+    }
+    float dmax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float d2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float e = v[i][k] - cf[k]; d2 = fmaf(e, e, d2); }
+#pragma unroll
+        for (int sh = 1; sh <= 4; sh <<= 1) d2 += __shfl_xor(d2, sh, 64);           // over the 8 dimension quads
+        dmax = (rowok && i < cw) ? fmaxf(dmax, d2) : dmax;
+    }
+#pragma unroll
+    for (int sh = 1; sh <= 4; sh <<= 1) c2 += __shfl_xor(c2, sh, 64);
+#pragma unroll
+    for (int sh = 8; sh <= 32; sh <<= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, sh, 64));
+    if (ry == 0) reinterpret_cast<uint2 *>(cen + sb * 32)[dq] = C.q;
+    if (lane == 0) {
+        const float r = sqrtf(dmax) * 1.000244140625f;                          // (1 + 2^-12): the fp32 rounding of the distance
+        rad[sb] = r;
+        bn[sb] = sqrtf(c2) * 1.000244140625f + r;                               // >= ||x|| for every row of the block
+    }
+}
+
+// one wave per query: the exact-enough maximum over the rows of the block the centroid search chose -> mlb, ||q||
+template <bool SPLIT>
+__global__ void __launch_bounds__(kThreads)
+k_frnn_seed_lb(const unsigned short *__restrict__ Qhi, const unsigned short *__restrict__ Qlo, const int32_t *__restrict__ qidx,
+               const unsigned short *__restrict__ Dhi, const unsigned short *__restrict__ Dlo, const float *__restrict__ bn,
+               unsigned long long *__restrict__ keysC, float *__restrict__ mlb, float *__restrict__ qnorm, int S_all, int NQ,
+               int H, int W, int NB, int NBp, const int32_t *__restrict__ qlist, const int32_t *__restrict__ qcount) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int S = qcount ? qcount[b] : S_all;
+    const int q = blockIdx.x * (kThreads / 64) + wave;
+    if (q >= S) return;
+    const size_t kb = (size_t)b * S_all;
+    const int slot = qlist ? qlist[kb + q] : q;
+    int qr = qidx ? qidx[kb + slot] : slot;
+    qr = qr < 0 ? 0 : (qr >= NQ ? NQ - 1 : qr);
+    const unsigned long long key = keysC[kb + slot];
+    int bs = key == 0ull ? 0 : (int)(0xffffffffu - (unsigned)(key & 0xffffffffull));
+    bs = bs < 0 ? 0 : (bs >= NB ? NB - 1 : bs);
+    float qv[32], x[32];
+    load_row32(Qhi, SPLIT ? Qlo : nullptr, (size_t)b * NQ + qr, qv);
+    const int BW = (W + 7) >> 3, by = bs / BW, bx = bs - by * BW;
+    const int py = by * 8 + (lane >> 3), px = bx * 8 + (lane & 7);
+    const bool ok = py < H && px < W;
+    load_row32(Dhi, SPLIT ? Dlo : nullptr, (size_t)b * H * W + (ok ? (size_t)py * W + px : (size_t)by * 8 * W + bx * 8), x);
+    float sc = 0.f, q2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) { sc = fmaf(qv[d], x[d], sc); q2 = fmaf(qv[d], qv[d], q2); }
+    sc = ok ? sc : -INFINITY;
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) sc = fmaxf(sc, __shfl_xor(sc, sh, 64));
+    if (lane == 0) {
+        const float qn = sqrtf(q2) * 1.000244140625f;
+        mlb[kb + slot] = sc - kSlack * qn * bn[(size_t)b * NBp + bs];
+        qnorm[kb + slot] = qn;
+        keysC[kb + slot] = 0ull;                                                 // the scratch keys are left zero
+    }
+}
+
+// surv [P][nqt_all][NBp / 64] words: bit i of word w = block 64 w + i may hold the maximum of one of the tile's 16 queries.
+// <q, c> on the matrix core with the QUERIES as the A operand: a lane then holds one block (column lane & 15) against four
+// queries (rows 4 g + j), ORs its four tests, two shuffles OR the four lane groups and ONE ballot yields the tile's 16
+// block bits.  (With the blocks as rows every (block, lane group) bit had to be cut out of four ballots on the scalar
+// unit - 120 instructions per MFMA, 82 us per search: more than the scoring of the survivors.)
+constexpr int kQG = 4;                      // query tiles per wave in k_frnn_survivors
+constexpr int kQE = 1;                      // query tiles per workgroup in k_frnn_eval (4: 135 instead of 55 us per search - the kernel is
+                                            // bound by the serial work of a wave, not by the gathers the tiles would share)
+constexpr int kEvalY = 4;                   // workgroups per query tile in k_frnn_eval (1 / 2 / 4 / 8: 1292 / 1148 / 1065 / 1084 us per matcher call)
+template <bool SPLIT>
+__global__ void __launch_bounds__(kThreads)
+k_frnn_survivors(const unsigned short *__restrict__ Qhi, const unsigned short *__restrict__ Qlo, const int32_t *__restrict__ qidx,
+                 const unsigned short *__restrict__ cen, const float *__restrict__ rad, const float *__restrict__ bn,
+                 const float *__restrict__ mlb, const float *__restrict__ qnorm, unsigned long long *__restrict__ surv,
+                 int32_t *__restrict__ total, int S_all, int NQ, int NBp, int nqt_all, int wpw,
+                 const int32_t *__restrict__ qlist, const int32_t *__restrict__ qcount) {
+    const int b = blockIdx.z, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, g = lane >> 4;
+    const int S = qcount ? qcount[b] : S_all;
+    const int qt0 = (blockIdx.x * (kThreads / 64) + wave) * kQG;                 // kQG consecutive query tiles share every centroid fragment
+    if (qt0 * 16 >= S) return;
+    const int nt = (S - qt0 * 16 + 15) / 16 < kQG ? (S - qt0 * 16 + 15) / 16 : kQG;   // wave-uniform
+    const size_t kb = (size_t)b * S_all, sbase = (size_t)b * NBp;
+    f16x8 qh[kQG], ql[SPLIT ? kQG : 1];
+    float mq[kQG][4], nq[kQG][4];                                                // the four queries per tile this lane gets scores of
+#pragma unroll
+    for (int u = 0; u < kQG; ++u) {
+        int q = (qt0 + u) * 16 + col;
+        q = q < S ? q : S - 1;
+        const int slot = qlist ? qlist[kb + q] : q;
+        int qr = qidx ? qidx[kb + slot] : slot;
+        qr = qr < 0 ? 0 : (qr >= NQ ? NQ - 1 : qr);
+        qh[u] = *reinterpret_cast<const f16x8 *>(Qhi + ((size_t)b * NQ + qr) * 32 + g * 8);   // A: row = query col, k chunk g
+        if (SPLIT) ql[u] = *reinterpret_cast<const f16x8 *>(Qlo + ((size_t)b * NQ + qr) * 32 + g * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int qq = (qt0 + u) * 16 + 4 * g + j;
+            qq = qq < S ? qq : S - 1;
+            const int sj = qlist ? qlist[kb + qq] : qq;
+            mq[u][j] = mlb[kb + sj];
+            nq[u][j] = qnorm[kb + sj];
+        }
+    }
+    const int NBW = NBp / 64;
+    const int w0 = blockIdx.y * wpw, w1 = w0 + wpw < NBW ? w0 + wpw : NBW;
+    int cnt = 0;
+    for (int w = w0; w < w1; ++w) {
+        f16x8 c[4];
+        float e[4], r[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {                                            // B: column = block col, k chunk g
+            const size_t blk = sbase + w * 64 + t * 16 + col;
+            c[t] = *reinterpret_cast<const f16x8 *>(cen + blk * 32 + g * 8);
+            r[t] = rad[blk];
+            e[t] = r[t] + kSlack * bn[blk];
+        }
+#pragma unroll
+        for (int u = 0; u < kQG; ++u) {
+            if (u >= nt) break;
+            unsigned long long bits = 0ull;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh[u], c[t], acc, 0, 0, 0);
+                if (SPLIT) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ql[u], c[t], acc, 0, 0, 0);
+                bool keep = false;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) keep = keep || !(acc[j] + nq[u][j] * e[t] < mq[u][j]);
+                int k = (keep && !(r[t] < 0.f)) ? 1 : 0;                          // padding blocks have r = -inf
+                k |= __shfl_xor(k, 16, 64);
+                k |= __shfl_xor(k, 32, 64);
+                bits |= (__ballot(k != 0) & 0xffffull) << (16 * t);
+            }
+            if (lane == 0) surv[((size_t)b * nqt_all + qt0 + u) * NBW + w] = bits;
+            cnt += __popcll(bits);
+        }
+    }
+    if (lane == 0 && cnt) atomicAdd(total + b, cnt);
+}
+
+// grid (groups of QG query tiles, Y, P): a group's 4 Y waves take the words of the UNION of its tiles' survivor rows
+// round-robin (interleaved by 64-block word so that a cluster of survivors spreads).  Every gathered block is scored against
+// all QG tiles of the group - consecutive tiles are neighbours on the seed grid (seed_order) and need nearly the same
+// blocks, so the gathers, which bound this kernel (a block is 4 - 8 KB for 4 MFMAs per tile), are shared; scoring a block a
+// tile did not ask for only adds real candidates.  The rows of the NEXT surviving block are requested before the current
+// block is scored (two register sets, alternating: with one set and a copy the wait for the copy exposed every round trip).
+template <int PASSES, int QG>
+__global__ void __launch_bounds__(kThreads)
+k_frnn_eval(const unsigned short *__restrict__ Qhi, const unsigned short *__restrict__ Qlo, const int32_t *__restrict__ qidx,
+            const unsigned short *__restrict__ Dhi, const unsigned short *__restrict__ Dlo,
+            const unsigned long long *__restrict__ surv, const int32_t *__restrict__ total, unsigned long long *__restrict__ keys,
+            int S_all, int NQ, int H, int W, int NB, int NBp, int nqt_all, const int32_t *__restrict__ qlist,
+            const int32_t *__restrict__ qcount) {
+    const int b = blockIdx.z, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, g = lane >> 4;
+    const int S = qcount ? qcount[b] : S_all;
+    const int qt0 = blockIdx.x * QG;
+    if (qt0 * 16 >= S || prune_overflow(total[b], S, NB)) return;
+    const int nt = (S - qt0 * 16 + 15) / 16 < QG ? (S - qt0 * 16 + 15) / 16 : QG;   // workgroup-uniform
+    const size_t kb = (size_t)b * S_all, db = (size_t)b * H * W;
+    const int BW = (W + 7) >> 3;
+    f16x8 qh[QG], ql[PASSES == 3 ? QG : 1];
+    int slot[QG];
+    float best[QG];
+    int bestn[QG];
+#pragma unroll
+    for (int u = 0; u < QG; ++u) {
+        const int q = (qt0 + u) * 16 + col, qc = q < S ? q : S - 1;
+        slot[u] = qlist ? qlist[kb + qc] : qc;
+        int qr = qidx ? qidx[kb + slot[u]] : slot[u];
+        qr = qr < 0 ? 0 : (qr >= NQ ? NQ - 1 : qr);
+        qh[u] = *reinterpret_cast<const f16x8 *>(Qhi + ((size_t)b * NQ + qr) * 32 + g * 8);
+        if (PASSES == 3) ql[u] = *reinterpret_cast<const f16x8 *>(Qlo + ((size_t)b * NQ + qr) * 32 + g * 8);
+        best[u] = -INFINITY;
+        bestn[u] = 0;
+    }
+    const int NBW = NBp / 64;
+    const unsigned long long *srow = surv + ((size_t)b * nqt_all + qt0) * NBW;
+    constexpr int NA = PASSES == 3 ? 8 : 4;
+    const int stride = (kThreads / 64) * (int)gridDim.y, first = wave + (kThreads / 64) * (int)blockIdx.y;
+    for (int wbase = first; wbase < NBW; wbase += 64 * stride) {                // 64 words of this wave at a time (one per lane)
+        const int wmine = wbase + lane * stride;
+        unsigned long long mine = 0ull;
+        if (wmine < NBW)
+            for (int u = 0; u < nt; ++u) mine |= srow[(size_t)u * NBW + wmine];
+        int k = -1;
+        unsigned long long bits = 0ull;
+        auto next_block = [&]() -> int {                                         // wave-uniform; -1 = no more
+            while (bits == 0ull) {
+                if (++k >= 64 || wbase + k * stride >= NBW) return -1;
+                const unsigned lo32 = __builtin_amdgcn_readlane((unsigned)mine, k), hi32 = __builtin_amdgcn_readlane((unsigned)(mine >> 32), k);
+                bits = ((unsigned long long)hi32 << 32) | lo32;
+            }
+            const int i = __builtin_ctzll(bits);
+            bits &= bits - 1ull;
+            return (wbase + k * stride) * 64 + i;
+        };
+        auto load_rows = [&](int blk, f16x8 (&a)[NA]) {                          // A rows 16 h + col = pixel (y0 + 2 h + (col >> 3), x0 + (col & 7))
+            const int by = blk / BW, bx = blk - by * BW;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                int py = by * 8 + 2 * h + (col >> 3), px = bx * 8 + (col & 7);
+                py = py < H ? py : H - 1;
+                px = px < W ? px : W - 1;
+                const size_t row = db + (size_t)py * W + px;
+                a[h] = *reinterpret_cast<const f16x8 *>(Dhi + row * 32 + g * 8);
+                if (PASSES == 3) a[4 + h] = *reinterpret_cast<const f16x8 *>(Dlo + row * 32 + g * 8);
+            }
+        };
+        auto score = [&](int blk, const f16x8 (&a)[NA]) {
+            const int by = blk / BW, bx = blk - by * BW;
+            const int y0 = by * 8, x0 = bx * 8;
+            // this lane's outputs: tile h, j -> block row 16 h + 4 g + j = pixel (y0 + 2 h + (g >> 1), x0 + 4 (g & 1) + j)
+            const int ox = x0 + 4 * (g & 1);
+            const bool edge = y0 + 8 > H || x0 + 8 > W;                         // tiles on the bottom / right edge
+#pragma unroll
+            for (int u = 0; u < QG; ++u) {
+                if (u >= nt) break;
+                f32x4 acc[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[h], qh[u], c, 0, 0, 0);   // the MFMA sequence of nn_step: same bits
+                    if (PASSES == 3) {
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[h], ql[u], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[4 + h], qh[u], c, 0, 0, 0);
+                    }
+                    acc[h] = c;
+                }
+                if (edge) {
+#pragma unroll
+                    for (int h = 0; h < 4; ++h)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (y0 + 2 * h + (g >> 1) >= H || ox + j >= W) acc[h][j] = -INFINITY;
+                }
+                float mx = acc[0][0];
+#pragma unroll
+                for (int h = 0; h < 4; ++h)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mx = __builtin_fmaxf(mx, acc[h][j]);
+                const bool ge = mx >= best[u] && mx > -INFINITY;                // ties included: the LOWEST pixel index must win
+                if (__any(ge)) {                                                // rare after the first few blocks
+                    int nn = 0x7fffffff;                                        // lowest pixel index of this lane that holds mx
+#pragma unroll
+                    for (int h = 3; h >= 0; --h)
+#pragma unroll
+                        for (int j = 3; j >= 0; --j) nn = (acc[h][j] == mx) ? (y0 + 2 * h + (g >> 1)) * W + ox + j : nn;
+                    if (ge && (mx > best[u] || nn < bestn[u])) { best[u] = mx; bestn[u] = nn; }
+                }
+            }
+        };
+        f16x8 ra[NA], rb[NA];
+        int ba = next_block();
+        if (ba >= 0) load_rows(ba, ra);
+        while (ba >= 0) {
+            const int bb = next_block();
+            if (bb >= 0) load_rows(bb, rb);
+            score(ba, ra);
+            if (bb < 0) break;
+            ba = next_block();
+            if (ba >= 0) load_rows(ba, ra);
+            score(bb, rb);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < QG; ++u) {
+        if (u >= nt) break;
+        float bs = best[u];
+        int bn_ = bs == -INFINITY ? 0 : bestn[u];
+#pragma unroll
+        for (int sh = 16; sh <= 32; sh <<= 1) {
+            const float os = __shfl_xor(bs, sh, 64);
+            const int on = __shfl_xor(bn_, sh, 64);
+            if (os > bs || (os == bs && on < bn_)) { bs = os; bn_ = on; }
+        }
+        if (g == 0 && (qt0 + u) * 16 + col < S) {
+            const unsigned long long key = ((unsigned long long)ordered_bits(bs) << 32) | (unsigned long long)(0xffffffffu - (unsigned)bn_);
+            atomicMax(keys + kb + slot[u], key);
+        }
+    }
+}
+
 // ---- one round of fast reciprocal NN on the device (matching.fast_reciprocal_nn_device), batched over P pairs -----------
 // mid: keys of the forward search -> xy2 (the view-2 pixel each seed landed on), keys cleared for the backward search
 __global__ void __launch_bounds__(kThreads)
@@ -312,14 +691,16 @@ k_frnn_mid(unsigned long long *__restrict__ keys, int32_t *__restrict__ xy2, lon
 // compact: the still-active seed slots of every pair, ascending, + their number - the query list of the next round's
 // searches.  One workgroup per pair walks its S flags in order (ballot + prefix counts): deterministic.
 __global__ void __launch_bounds__(kThreads)
-k_frnn_compact(const uint8_t *__restrict__ active, int32_t *__restrict__ list, int32_t *__restrict__ count, int S) {
+k_frnn_compact(const uint8_t *__restrict__ active, const int32_t *__restrict__ order, int32_t *__restrict__ list,
+               int32_t *__restrict__ count, int S) {
     __shared__ int base, wsum[kThreads / 64];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) base = 0;
     __syncthreads();
     for (int s0 = 0; s0 < S; s0 += kThreads) {
-        const int sl = s0 + tid;
-        const bool a = sl < S && active[(size_t)b * S + sl] != 0;
+        const int pos = s0 + tid;
+        const int sl = (order && pos < S) ? order[pos] : pos;                   // walk the slots in the caller's order (NULL: ascending)
+        const bool a = pos < S && sl >= 0 && sl < S && active[(size_t)b * S + sl] != 0;
         const unsigned long long m = __ballot(a);
         if (lane == 0) wsum[wave] = __popcll(m);
         __syncthreads();
@@ -478,9 +859,9 @@ int m3_nn_search_mfma(const void *Q, const void *DB, int32_t *idx_out, float *sc
     const dim3 grid(qblocks, splits, B);
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(keys_ws);
     if (in_f16) hipLaunchKernelGGL(k_nn_mfma<1>, grid, blk, 0, st, qhi, qlo, (const int32_t *)nullptr, dhi, dlo, keys, S, S, N, per_split,
-                                   (const int32_t *)nullptr, (const int32_t *)nullptr);
+                                   (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, 0);
     else hipLaunchKernelGGL(k_nn_mfma<3>, grid, blk, 0, st, qhi, qlo, (const int32_t *)nullptr, dhi, dlo, keys, S, S, N, per_split,
-                            (const int32_t *)nullptr, (const int32_t *)nullptr);
+                            (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, 0);
     M3_CHECK_LAUNCH("m3_nn_search_mfma");
     const long long total = (long long)B * S;
     hipLaunchKernelGGL(k_nn_unpack, dim3((unsigned)m3_cdiv(total, (long long)kThreads)), dim3(kThreads), 0, st,
@@ -524,8 +905,10 @@ static int frnn_search(const void *qpacked, int NQ, const int32_t *qidx, const v
     per_split = m3_cdiv(per_split, kRows) * kRows;
     splits = m3_cdiv(N, per_split);
     const dim3 grid(qblocks, splits, P), blk(kThreads);
-    if (in_f16) hipLaunchKernelGGL(k_nn_mfma<1>, grid, blk, 0, st, qhi, qlo, qidx, dhi, dlo, keys, S, NQ, N, per_split, qlist, qcount);
-    else hipLaunchKernelGGL(k_nn_mfma<3>, grid, blk, 0, st, qhi, qlo, qidx, dhi, dlo, keys, S, NQ, N, per_split, qlist, qcount);
+    if (in_f16) hipLaunchKernelGGL(k_nn_mfma<1>, grid, blk, 0, st, qhi, qlo, qidx, dhi, dlo, keys, S, NQ, N, per_split, qlist, qcount,
+                                   (const int32_t *)nullptr, 0);
+    else hipLaunchKernelGGL(k_nn_mfma<3>, grid, blk, 0, st, qhi, qlo, qidx, dhi, dlo, keys, S, NQ, N, per_split, qlist, qcount,
+                            (const int32_t *)nullptr, 0);
     return M3_OK;
 }
 
@@ -563,12 +946,133 @@ int m3_frnn_round_active(const void *packed1, const void *packed2, int32_t *cur,
     int32_t *list = act_ws, *count = act_ws + (size_t)P * S;
     const long long total = (long long)P * S;
     const dim3 eb(kThreads), eg((unsigned)m3_cdiv(total, (long long)kThreads));
-    hipLaunchKernelGGL(k_frnn_compact, dim3(P), eb, 0, st, (const uint8_t *)active, list, count, S);
+    hipLaunchKernelGGL(k_frnn_compact, dim3(P), eb, 0, st, (const uint8_t *)active, (const int32_t *)nullptr, list, count, S);
     frnn_search(packed1, N1, cur, packed2, N2, keys, P, S, in_f16, st, list, count);
     hipLaunchKernelGGL(k_frnn_mid, eg, eb, 0, st, keys, xy2_ws, total);
     frnn_search(packed2, N2, xy2_ws, packed1, N1, keys, P, S, in_f16, st, list, count);
     hipLaunchKernelGGL(k_frnn_end, eg, eb, 0, st, keys, (const int32_t *)xy2_ws, cur, active, got1, got2, total);
     M3_CHECK_LAUNCH("m3_frnn_round_active");
+    return M3_OK;
+}
+
+// ---- block-bound search: statistics of a packed map, scratch, and the round built on it ---------------------------------
+static inline int prune_nb(int H, int W) { return m3_cdiv(H, 8) * m3_cdiv(W, 8); }
+static inline int prune_nbp(int H, int W) { return m3_cdiv(prune_nb(H, W), 64) * 64; }
+// stats of a packed map [P][H * W]: centroids fp16 [P][NBp][32], then rad fp32 [P][NBp], then bn fp32 [P][NBp]
+int64_t m3_frnn_stats_bytes(int P, int H, int W) {
+    if (P <= 0 || H <= 0 || W <= 0) return 0;
+    return (int64_t)P * prune_nbp(H, W) * (64 + 4 + 4);
+}
+int m3_frnn_blockstats(const void *packed, void *stats, int P, int H, int W, int in_f16, void *stream) {
+    M3_REQUIRE(packed && stats && P > 0 && P <= 65535 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 31));
+    M3_REQUIRE((reinterpret_cast<size_t>(stats) & 15) == 0);
+    const unsigned short *hi = (const unsigned short *)packed, *lo = in_f16 ? nullptr : hi + (size_t)P * H * W * 32;
+    const int NB = prune_nb(H, W), NBp = prune_nbp(H, W);
+    unsigned short *cen = (unsigned short *)stats;
+    float *rad = reinterpret_cast<float *>(cen + (size_t)P * NBp * 32), *bn = rad + (size_t)P * NBp;
+    hipLaunchKernelGGL(k_frnn_blockstats, dim3(m3_cdiv(NBp, kThreads / 64), P), dim3(kThreads), 0, (hipStream_t)stream, hi, lo, cen, rad, bn,
+                       H, W, NB, NBp);
+    M3_CHECK_LAUNCH("m3_frnn_blockstats");
+    return M3_OK;
+}
+// scratch of m3_frnn_round_pruned for S seeds
+int64_t m3_frnn_prune_ws_bytes(int P, int S, int H1, int W1, int H2, int W2) {
+    if (P <= 0 || S <= 0 || H1 <= 0 || W1 <= 0 || H2 <= 0 || W2 <= 0) return 0;
+    const int64_t head = ((int64_t)P * S * 8 + (int64_t)P * 4 + 15) / 16 * 16;        // centroid-search keys + survivor totals (zeroed per search)
+    const int nbp = prune_nbp(H1, W1) > prune_nbp(H2, W2) ? prune_nbp(H1, W1) : prune_nbp(H2, W2);
+    return head + (int64_t)P * S * 8 + (int64_t)P * m3_cdiv(S, 16) * (nbp / 64) * 8;
+}
+
+static int frnn_search_pruned(const void *qpacked, int NQ, const int32_t *qidx, const void *dpacked, int H, int W, const void *dstats,
+                              unsigned long long *keys, int P, int S, int in_f16, hipStream_t st, const int32_t *qlist,
+                              const int32_t *qcount, void *ws) {
+    const int N = H * W;
+    const unsigned short *qhi = (const unsigned short *)qpacked, *qlo = in_f16 ? nullptr : qhi + (size_t)P * NQ * 32;
+    const unsigned short *dhi = (const unsigned short *)dpacked, *dlo = in_f16 ? nullptr : dhi + (size_t)P * N * 32;
+    const int NB = prune_nb(H, W), NBp = prune_nbp(H, W), NBW = NBp / 64, nqt = m3_cdiv(S, 16);
+    const unsigned short *cen = (const unsigned short *)dstats;
+    const float *rad = reinterpret_cast<const float *>(cen + (size_t)P * NBp * 32), *bn = rad + (size_t)P * NBp;
+    const int64_t head = ((int64_t)P * S * 8 + (int64_t)P * 4 + 15) / 16 * 16;
+    unsigned long long *keysC = (unsigned long long *)ws;
+    int32_t *total = reinterpret_cast<int32_t *>(keysC + (size_t)P * S);
+    float *mlb = reinterpret_cast<float *>((unsigned char *)ws + head), *qn = mlb + (size_t)P * S;
+    unsigned long long *surv = reinterpret_cast<unsigned long long *>(qn + (size_t)P * S);
+    M3_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)head, st), "m3_frnn_round_pruned/memset");
+    const dim3 blk(kThreads);
+    {   // 1. the most promising block per query: the brute-force kernel on the NB centroids (hi plane of the queries)
+        const int qblocks = m3_cdiv(S, kQPB);
+        int splits = m3_cdiv(1024, qblocks * P);
+        if (splits < 1) splits = 1;
+        if (splits > m3_cdiv(NB, kRows)) splits = m3_cdiv(NB, kRows);
+        int per_split = m3_cdiv(m3_cdiv(NB, splits), kRows) * kRows;
+        splits = m3_cdiv(NB, per_split);
+        hipLaunchKernelGGL(k_nn_mfma<1>, dim3(qblocks, splits, P), blk, 0, st, qhi, (const unsigned short *)nullptr, qidx, cen,
+                           (const unsigned short *)nullptr, keysC, S, NQ, NB, per_split, qlist, qcount, (const int32_t *)nullptr, 0);
+    }
+    const dim3 gl(m3_cdiv(S, kThreads / 64), P);
+    const int ngrp = m3_cdiv(nqt, kQG);
+    int ysplit = m3_cdiv(8192, ngrp * P);
+    ysplit = ysplit < 1 ? 1 : (ysplit > NBW ? NBW : ysplit);
+    const int wpw = m3_cdiv(NBW, ysplit);
+    const dim3 gs(m3_cdiv(ngrp, kThreads / 64), m3_cdiv(NBW, wpw), P), ge(m3_cdiv(nqt, kQE), kEvalY, P);
+    if (in_f16) {
+        hipLaunchKernelGGL(k_frnn_seed_lb<false>, gl, blk, 0, st, qhi, qlo, qidx, dhi, dlo, bn, keysC, mlb, qn, S, NQ, H, W, NB, NBp, qlist, qcount);
+        hipLaunchKernelGGL(k_frnn_survivors<false>, gs, blk, 0, st, qhi, qlo, qidx, cen, rad, bn, (const float *)mlb, (const float *)qn,
+                           surv, total, S, NQ, NBp, nqt, wpw, qlist, qcount);
+        hipLaunchKernelGGL((k_frnn_eval<1, kQE>), ge, blk, 0, st, qhi, qlo, qidx, dhi, dlo, (const unsigned long long *)surv,
+                           (const int32_t *)total, keys, S, NQ, H, W, NB, NBp, nqt, qlist, qcount);
+    } else {
+        hipLaunchKernelGGL(k_frnn_seed_lb<true>, gl, blk, 0, st, qhi, qlo, qidx, dhi, dlo, bn, keysC, mlb, qn, S, NQ, H, W, NB, NBp, qlist, qcount);
+        hipLaunchKernelGGL(k_frnn_survivors<true>, gs, blk, 0, st, qhi, qlo, qidx, cen, rad, bn, (const float *)mlb, (const float *)qn,
+                           surv, total, S, NQ, NBp, nqt, wpw, qlist, qcount);
+        hipLaunchKernelGGL((k_frnn_eval<3, kQE>), ge, blk, 0, st, qhi, qlo, qidx, dhi, dlo, (const unsigned long long *)surv,
+                           (const int32_t *)total, keys, S, NQ, H, W, NB, NBp, nqt, qlist, qcount);
+    }
+    {   // 4. the brute-force search, gated on the survivor count (its workgroups leave at once when the bounds worked)
+        const int qblocks = m3_cdiv(S, kQPB);
+        int splits = m3_cdiv(1024, qblocks * P);
+        if (splits < 1) splits = 1;
+        if (splits > m3_cdiv(N, kRows)) splits = m3_cdiv(N, kRows);
+        int per_split = m3_cdiv(m3_cdiv(N, splits), kRows) * kRows;
+        splits = m3_cdiv(N, per_split);
+        const dim3 grid(qblocks, splits, P);
+        if (in_f16) hipLaunchKernelGGL(k_nn_mfma<1>, grid, blk, 0, st, qhi, qlo, qidx, dhi, dlo, keys, S, NQ, N, per_split, qlist, qcount,
+                                       (const int32_t *)total, NB);
+        else hipLaunchKernelGGL(k_nn_mfma<3>, grid, blk, 0, st, qhi, qlo, qidx, dhi, dlo, keys, S, NQ, N, per_split, qlist, qcount,
+                                (const int32_t *)total, NB);
+    }
+    return M3_OK;
+}
+
+// m3_frnn_round / m3_frnn_round_active with the block-bound search: the maps are H1 x W1 / H2 x W2 pixels in raster order,
+// stats1 / stats2 = m3_frnn_blockstats of packed1 / packed2, prune_ws = m3_frnn_prune_ws_bytes(...) bytes of scratch
+// (16-byte aligned), act_ws as in m3_frnn_round_active or NULL (round on every seed slot).  seed_order int32 [S] (or NULL):
+// the order in which the active slots are listed - the searches work on groups of 16 / 64 CONSECUTIVE list entries, and
+// the fewer blocks the queries of a group need between them, the less is scored: an order that walks the seed grid in
+// 4 x 4 patches (matching.py) halves the surviving work of a row-major one.  It changes no result (requires act_ws).
+// Same cur / active / got1 / got2 as the brute-force rounds, bit for bit; the time follows how well the descriptor maps
+// cluster.
+int m3_frnn_round_pruned(const void *packed1, const void *packed2, const void *stats1, const void *stats2, int32_t *cur,
+                         uint8_t *active, int32_t *got1, int32_t *got2, int32_t *xy2_ws, uint64_t *keys_ws, int32_t *act_ws,
+                         const int32_t *seed_order, void *prune_ws, int P, int S, int H1, int W1, int H2, int W2, int in_f16,
+                         void *stream) {
+    M3_REQUIRE(packed1 && packed2 && stats1 && stats2 && cur && active && got1 && got2 && xy2_ws && keys_ws && prune_ws);
+    M3_REQUIRE(P > 0 && P <= 65535 && S > 0 && H1 > 0 && W1 > 0 && H2 > 0 && W2 > 0 && (reinterpret_cast<size_t>(prune_ws) & 15) == 0);
+    M3_REQUIRE((int64_t)H1 * W1 < (1ll << 31) && (int64_t)H2 * W2 < (1ll << 31) && (!seed_order || act_ws));
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(keys_ws);
+    const int32_t *list = act_ws, *count = act_ws ? act_ws + (size_t)P * S : nullptr;
+    const long long total = (long long)P * S;
+    const int N1 = H1 * W1, N2 = H2 * W2;
+    const dim3 eb(kThreads), eg((unsigned)m3_cdiv(total, (long long)kThreads));
+    if (act_ws) hipLaunchKernelGGL(k_frnn_compact, dim3(P), eb, 0, st, (const uint8_t *)active, seed_order, act_ws, act_ws + (size_t)P * S, S);
+    int rc = frnn_search_pruned(packed1, N1, cur, packed2, H2, W2, stats2, keys, P, S, in_f16, st, list, count, prune_ws);
+    if (rc != M3_OK) return rc;
+    hipLaunchKernelGGL(k_frnn_mid, eg, eb, 0, st, keys, xy2_ws, total);
+    rc = frnn_search_pruned(packed2, N2, xy2_ws, packed1, H1, W1, stats1, keys, P, S, in_f16, st, list, count, prune_ws);
+    if (rc != M3_OK) return rc;
+    hipLaunchKernelGGL(k_frnn_end, eg, eb, 0, st, keys, (const int32_t *)xy2_ws, cur, active, got1, got2, total);
+    M3_CHECK_LAUNCH("m3_frnn_round_pruned");
     return M3_OK;
 }
 

@@ -142,7 +142,24 @@ def nn_search(Q: torch.Tensor, DB: torch.Tensor, return_score: bool = False, met
     return (idx, score) if return_score else idx
 
 
-def fast_reciprocal_nn_maps(D1: torch.Tensor, D2: torch.Tensor, subsample: int = 8, max_iter: int = 10, tracker_maps: bool = True):
+_PATCH_ORDER: dict = {}
+
+
+def _seed_patch_order(hs: int, ws: int, dev) -> torch.Tensor:
+    """Seed slots (row-major hs x ws grid) listed patch by patch: 4 x 4 seeds = one 16-query tile of the pruned search, four
+    consecutive tiles = an 8 x 8 patch.  The queries of a tile / group then land close together in the other view and need
+    few blocks between them (m3_frnn_round_pruned's seed_order; results do not depend on it)."""
+    key = (hs, ws, str(dev))
+    if key not in _PATCH_ORDER:
+        iy, ix = torch.meshgrid(torch.arange(hs), torch.arange(ws), indexing="ij")
+        iy, ix = iy.reshape(-1), ix.reshape(-1)
+        k = ((iy // 8) * ((ws + 7) // 8) + ix // 8) * 64 + (((iy % 8) // 4) * 2 + (ix % 8) // 4) * 16 + (iy % 4) * 4 + ix % 4
+        _PATCH_ORDER[key] = torch.argsort(k, stable=True).to(torch.int32).to(dev)
+    return _PATCH_ORDER[key]
+
+
+def fast_reciprocal_nn_maps(D1: torch.Tensor, D2: torch.Tensor, subsample: int = 8, max_iter: int = 10, tracker_maps: bool = True,
+                            prune: bool = True):
     """Fast reciprocal NN for a batch of P pairs (D1, D2 [P,H,W,D], fp32 or fp16) with EVERYTHING on the device and every
     output of a fixed shape - no host synchronisation, no data-dependent allocation - so the call can be captured into a
     hipGraph.  Each descriptor map is packed to K-padded fp16 once (m3_frnn_pack) and serves as the database of one
@@ -151,7 +168,10 @@ def fast_reciprocal_nn_maps(D1: torch.Tensor, D2: torch.Tensor, subsample: int =
     m3_frnn_collect turns the rounds' reciprocal pairs into
         map1   int32 [P,N1]    view-1 pixel -> its reciprocal partner in view 2 (-1 = none)
         idx    int64 [P,N2], valid bool [P,N2,1]   the tracker's maps (view-2 pixel -> view-1 pixel)   (tracker_maps)
-        pairs  int32 [P,S,2], count int32 [P]      the distinct (p1, p2) per pair, sorted by p1; rows >= count are -1."""
+        pairs  int32 [P,S,2], count int32 [P]      the distinct (p1, p2) per pair, sorted by p1; rows >= count are -1.
+    prune (default): the searches use block bounds (m3_frnn_blockstats once per map, m3_frnn_round_pruned) - the same
+    arg-max bit for bit, most of the other view never scored when the descriptor maps are spatially coherent, the
+    brute-force kernel as the device-side fallback when they are not.  prune=False: brute force always."""
     if D1.dim() != 4 or D2.dim() != 4 or D1.shape[-1] != D2.shape[-1] or D1.shape[0] != D2.shape[0]:
         raise ValueError("D1, D2 must be [P,H,W,D] with the same P and D")
     if D1.dtype != D2.dtype:
@@ -181,8 +201,20 @@ def fast_reciprocal_nn_maps(D1: torch.Tensor, D2: torch.Tensor, subsample: int =
     xy2 = torch.empty((P, s), dtype=torch.int32, device=dev)
     keys = torch.zeros((P, s), dtype=torch.int64, device=dev)
     act_ws = torch.empty(P * (s + 1), dtype=torch.int32, device=dev)
+    if prune:
+        h2, w2 = B.shape[1], B.shape[2]
+        st1 = torch.empty(int(L.m3_frnn_stats_bytes(P, h1, w1)), dtype=torch.uint8, device=dev)
+        st2 = torch.empty(int(L.m3_frnn_stats_bytes(P, h2, w2)), dtype=torch.uint8, device=dev)
+        pws = torch.empty(int(L.m3_frnn_prune_ws_bytes(P, s, h1, w1, h2, w2)), dtype=torch.uint8, device=dev)
+        _ffi.call("m3_frnn_blockstats", _ffi.ptr(pk1), _ffi.ptr(st1), P, h1, w1, f16, st)
+        _ffi.call("m3_frnn_blockstats", _ffi.ptr(pk2), _ffi.ptr(st2), P, h2, w2, f16, st)
+        order = _seed_patch_order(len(ys), len(xs), dev)
     for r in range(max_iter):
-        if r == 0:
+        if prune:
+            _ffi.call("m3_frnn_round_pruned", _ffi.ptr(pk1), _ffi.ptr(pk2), _ffi.ptr(st1), _ffi.ptr(st2), _ffi.ptr(cur),
+                      _ffi.ptr(active), _ffi.ptr(got1[r]), _ffi.ptr(got2[r]), _ffi.ptr(xy2), _ffi.ptr(keys),
+                      _ffi.ptr(act_ws), _ffi.ptr(order), _ffi.ptr(pws), P, s, h1, w1, h2, w2, f16, st)
+        elif r == 0:
             _ffi.call("m3_frnn_round", _ffi.ptr(pk1), _ffi.ptr(pk2), _ffi.ptr(cur), _ffi.ptr(active), _ffi.ptr(got1[r]),
                       _ffi.ptr(got2[r]), _ffi.ptr(xy2), _ffi.ptr(keys), P, s, n1, n2, f16, st)
         else:

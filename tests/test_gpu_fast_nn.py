@@ -162,3 +162,46 @@ def test_fast_reciprocal_nn_maps_fixed_shapes_graph_capture_and_active_rounds(de
     torch.cuda.synchronize()
     assert out["count"].cpu().tolist() == counts[::-1]
     assert torch.equal(out["pairs"], m["pairs"].flip(0)) and torch.equal(out["idx"], m["idx"].flip(0))
+
+
+def _same_maps(a, b):
+    for k in ("map1", "pairs", "count", "idx", "valid"):
+        assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("case", ["smooth_f32", "smooth_f16", "random_f32", "random_f16", "ties_f16", "ragged_f32", "ragged_f16"])
+def test_block_bound_search_equals_brute_force_bit_for_bit(dev, case):
+    """m3_frnn_round_pruned (block bounds: centroid search -> lower bound -> survivor bits -> exact scoring of the
+    surviving 64-row blocks with the brute-force MFMA sequence) against m3_frnn_round / m3_frnn_round_active on
+      * smooth scenes (the case it is built for: a few blocks per query tile survive),
+      * random unit descriptors (no spatial coherence: nearly every block survives, the device-side gate hands the search
+        to the brute-force kernel),
+      * a map tiled from a small patch (every descriptor occurs many times: ties must go to the LOWEST index, so blocks
+        that merely tie with the maximum must survive too),
+      * maps whose row count is not a multiple of the 64-row block (the last block is short) nor of 16.
+    Every output of fast_reciprocal_nn_maps is compared with torch.equal."""
+    kind, dt = case.split("_")
+    half = dt == "f16"
+    rng = np.random.default_rng(7)
+    if kind == "smooth":
+        scs = [synthetic.geometric_pair(64, 96, seed=50 + k, batch=1) for k in range(3)]
+        D1 = np.stack([s["D21"][0] for s in scs]); D2 = np.stack([s["D11"][0] for s in scs])
+    elif kind == "random":
+        D1 = rng.normal(size=(2, 48, 64, 24)).astype(np.float32); D2 = rng.normal(size=(2, 48, 64, 24)).astype(np.float32)
+        D1 /= np.linalg.norm(D1, axis=-1, keepdims=True); D2 /= np.linalg.norm(D2, axis=-1, keepdims=True)
+    elif kind == "ties":
+        patch = rng.normal(size=(1, 8, 16, 24)).astype(np.float32)
+        patch /= np.linalg.norm(patch, axis=-1, keepdims=True)
+        D1 = np.tile(patch, (2, 6, 6, 1)); D2 = np.tile(patch[:, ::-1], (2, 6, 6, 1)).copy()
+    else:
+        sc = synthetic.geometric_pair(50, 70, seed=61, batch=2)                 # 3500 rows: 54 blocks + 44 rows
+        D1, D2 = sc["D21"], sc["D11"]
+    A, B = torch.from_numpy(np.ascontiguousarray(D1)).to(dev), torch.from_numpy(np.ascontiguousarray(D2)).to(dev)
+    if half:
+        A, B = A.half(), B.half()
+    for sub, rounds in ((4, 4), (8, 2)):
+        fast = matching.fast_reciprocal_nn_maps(A, B, subsample=sub, max_iter=rounds, prune=True)
+        brute = matching.fast_reciprocal_nn_maps(A, B, subsample=sub, max_iter=rounds, prune=False)
+        _same_maps(fast, brute)
+        if kind in ("smooth", "ragged"):
+            assert int(brute["count"].min()) > 20

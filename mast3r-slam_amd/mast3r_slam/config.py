@@ -24,6 +24,11 @@ DEFAULT_CONFIG: dict[str, Any] = {
         "refine_dilation": 2,
         "use_refine": True,
         "refine_chained": False,     # False = numpy-twin semantics, True = Metal/CUDA-original
+        # not in the reference (it has no fast reciprocal NN; BASELINE.json's north_star names it): when set, matching.match
+        # dispatches to match_fast_nn - seeds every `fast_nn_subsample` pixels, `fast_nn_rounds` forward / backward rounds
+        "use_fast_nn": False,
+        "fast_nn_subsample": 8,
+        "fast_nn_rounds": 3,
     },
     "tracking": {
         "min_match_frac": 0.05,

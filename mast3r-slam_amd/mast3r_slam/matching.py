@@ -103,7 +103,10 @@ def match_iterative_proj(X11, X21, D11, D21, idx_1_to_2_init=None, *, stop_scope
 
 
 def match(X11, X21, D11, D21, idx_1_to_2_init=None):
-    """matching.py:12-38: dispatch on config matching.use_simple (default True)."""
+    """matching.py:12-38: dispatch on config matching.use_simple (default True); matching.use_fast_nn (not in the reference,
+    default False) selects the fast reciprocal NN matcher instead."""
+    if get_config().get("matching", {}).get("use_fast_nn", False):
+        return match_fast_nn(X11, X21, D11, D21, idx_1_to_2_init)
     if get_config().get("matching", {}).get("use_simple", True):
         return match_simple(X11, X21, D11, D21, idx_1_to_2_init)
     return match_iterative_proj(X11, X21, D11, D21, idx_1_to_2_init)
@@ -232,6 +235,31 @@ def fast_reciprocal_nn_maps(D1: torch.Tensor, D2: torch.Tensor, subsample: int =
     if tracker_maps:
         out["idx"], out["valid"] = idx, valid.view(torch.bool)[:, :, None]
     return out
+
+
+def match_fast_nn(X11, X21, D11, D21, idx_1_to_2_init=None):
+    """The matcher BASELINE.json's north_star names, behind matching.match's contract (matching.py:12-38): descriptors
+    D11 [B,H,W,D] (the view the indices point INTO) and D21 [B,H,W,D] or [B,N,D] -> (idx_1_to_2 [B,N] int64, valid [B,N,1]
+    bool).  A pixel n of the second map is matched when it is the view-2 end of a reciprocal nearest-neighbour pair
+    (fast_reciprocal_nn_maps: seeds on a grid in view 1, `fast_nn_rounds` rounds) AND its 3-D points agree:
+    |X11[idx[n]] - X21[n]| < dist_thresh, the occlusion test of the reference's matchers (matching.py:75-90, :438-452).
+    The result is sparse by construction (at most one match per seed); idx_1_to_2_init is accepted and ignored (the seeds
+    do not depend on a previous match).  Everything stays on the stream: no host synchronisation."""
+    cfg = get_config()["matching"]
+    X11, X21, b, h, w = _check_maps(X11, X21)
+    n = h * w
+    D11 = _ffi.check(D11, (torch.float32, torch.float16), "D11")
+    D21 = _ffi.check(D21, D11.dtype, "D21")
+    d = D11.shape[-1]
+    if D11.numel() != b * n * d or D21.numel() != b * n * d:
+        raise ValueError(f"D11 / D21 must hold {b}x{h}x{w}x{d} values, got {tuple(D11.shape)} / {tuple(D21.shape)}")
+    m = fast_reciprocal_nn_maps(D11.reshape(b, h, w, d), D21.reshape(b, h, w, d), subsample=int(cfg.get("fast_nn_subsample", 8)),
+                                max_iter=int(cfg.get("fast_nn_rounds", 3)), tracker_maps=True)
+    idx = torch.empty((b, n), dtype=torch.int64, device=X11.device)
+    near = torch.empty((b, n), dtype=torch.uint8, device=X11.device)
+    _ffi.call("m3_match_simple", _ffi.ptr(X11), _ffi.ptr(X21), _ffi.ptr(m["idx"]), _ffi.ptr(idx), _ffi.ptr(near),
+              b, h, w, float(cfg["dist_thresh"]), _ffi.stream_ptr())
+    return idx, (m["valid"][:, :, 0] & near.bool())[:, :, None]
 
 
 def fast_reciprocal_nn_device(D1: torch.Tensor, D2: torch.Tensor, subsample: int = 8, max_iter: int = 10):

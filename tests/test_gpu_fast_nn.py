@@ -205,3 +205,35 @@ def test_block_bound_search_equals_brute_force_bit_for_bit(dev, case):
         _same_maps(fast, brute)
         if kind in ("smooth", "ragged"):
             assert int(brute["count"].min()) > 20
+
+
+def test_match_dispatches_to_the_fast_reciprocal_nn_matcher(dev):
+    """matching.match with matching.use_fast_nn (the switch is this repo's; the contract is matching.py:12-38's): idx / valid
+    in the dense matchers' format - valid exactly where a reciprocal pair ends AND the 3-D points agree within dist_thresh;
+    on the synthetic two-view scene most seeds match and the matches are the true correspondences; the FrameTracker's
+    gather + GN accept the maps as they are."""
+    from mast3r_slam import config
+    sc = synthetic.geometric_pair(64, 96, seed=77, batch=2)
+    X11, X21 = torch.from_numpy(sc["X11"]).to(dev), torch.from_numpy(sc["X21"]).to(dev)
+    D11, D21 = torch.from_numpy(sc["D11"]).to(dev), torch.from_numpy(sc["D21"]).to(dev)
+    config.set_config({"matching": {"use_fast_nn": True, "fast_nn_subsample": 4, "fast_nn_rounds": 4}})
+    try:
+        idx, valid = matching.match(X11, X21, D11, D21)
+    finally:
+        config.set_config({"matching": {"use_fast_nn": False, "fast_nn_subsample": 8, "fast_nn_rounds": 3}})
+    b, h, w, _ = X11.shape
+    n = h * w
+    assert idx.shape == (b, n) and idx.dtype == torch.int64 and valid.shape == (b, n, 1) and valid.dtype == torch.bool
+    m = matching.fast_reciprocal_nn_maps(D11, D21, subsample=4, max_iter=4)
+    near = (X11.reshape(b, n, 3).gather(1, m["idx"][:, :, None].expand(b, n, 3)) - X21.reshape(b, n, 3)).norm(dim=-1) < 0.1
+    assert torch.equal(valid[:, :, 0], m["valid"][:, :, 0] & near)
+    assert torch.equal(idx[valid[:, :, 0]], m["idx"][valid[:, :, 0]])
+    seeds = (h // 4) * (w // 4)
+    assert int(valid.sum()) > 0.7 * b * seeds
+    # matched view-2 pixels land on their true view-1 positions (uv_true: where each view-2 pixel lies in view 1)
+    for p in range(b):
+        v = valid[p, :, 0].cpu().numpy()
+        got = idx[p].cpu().numpy()[v]
+        uv = sc["uv_true"][p][v]
+        err = np.hypot(got % w - uv[:, 0], got // w - uv[:, 1])
+        assert np.median(err) < 1.0 and np.percentile(err, 95) < 2.5

@@ -266,6 +266,13 @@ class FrameTracker:
             T_WCf, T_CkCf, info = opt_pose_ray_dist_sim3(Xf, Xk_canon, frame.T_WC, keyframe.T_WC, Qk, valid_opt, self.cfg)
         host = torch.cat([counts.reshape(-1)[:2].double(), uniq.double(), info.reshape(-1)[3:4]]).cpu()
         self.last_info = info                                      # (iterations, cost, |tau|, status) of the last solve, on the device
+        # The fractions below are "of the pixels" for the reference's dense matchers.  The fast reciprocal NN matcher
+        # (matching.use_fast_nn, not in the reference) yields at most one match per seed: its fractions are of the SEEDS,
+        # or every frame would fall below min_match_frac.
+        mcfg = get_config().get("matching", {})
+        if mcfg.get("use_fast_nn", False):
+            sub = int(mcfg.get("fast_nn_subsample", 8))
+            n = max(1, len(range(sub // 2, img_size[0], sub)) * len(range(sub // 2, img_size[1], sub)))
         if float(host[0]) / n < self.cfg["min_match_frac"]:
             print(f"Skipped frame {frame.frame_id}")
             return False, [], True
@@ -274,7 +281,7 @@ class FrameTracker:
             return False, [], True
         frame.T_WC = T_WCf.reshape(1, 8)
         # Xkk = T_CkCf.act(Xkf); keyframe.update_pointmap(Xkk, Ckf)  (tracker.py:146-147) in one kernel
-        keyframe.update_pointmap(Xkf.reshape(n, 3), Ckf.reshape(n, 1), T=T_CkCf)
+        keyframe.update_pointmap(Xkf.reshape(-1, 3), Ckf.reshape(-1, 1), T=T_CkCf)
         self.keyframes[len(self.keyframes) - 1] = keyframe
         match_frac_k = float(host[1]) / n
         unique_frac_f = float(host[2]) / n

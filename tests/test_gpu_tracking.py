@@ -357,3 +357,48 @@ def test_frame_tracker_solve_failure_relocalises(dev):
     assert status == 2.0, status
     assert out == (False, [], True)
     assert torch.equal(frame.T_WC, pose0) and torch.equal(kfs.last_keyframe().X_canon, map0) and kfs.last_keyframe().N == n0
+
+
+def test_frame_tracker_with_the_fast_reciprocal_nn_matcher(dev):
+    """matching.use_fast_nn behind the tracker: the match operator runs matching.match (-> match_fast_nn) on the scene's
+    descriptor maps, so idx / valid are SPARSE (one match per seed at most).  The tracker's gates count fractions of the
+    seeds then: the frame is not skipped, the Gauss-Newton solve on ~1.5 % of the pixels still finds the scene's Sim(3),
+    and the keyframe statistics are fractions of the seed count."""
+    from types import SimpleNamespace
+    from mast3r_slam import config, matching
+    from mast3r_slam.frame import Keyframes, create_frame
+    h, w = 96, 128
+    n = h * w
+    z, _ = _track_scene(h, w, 9, dev)
+    sc = synthetic.geometric_pair(h, w, seed=9, batch=1, noise=2e-4)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    X11, X21, D11, D21 = d(sc["X11"]), d(sc["X21"]), d(sc["D11"]), d(sc["D21"])
+    seen = {}
+
+    def match_fn(model, frame, keyframe, idx_i2j_init=None):
+        idx, valid = matching.match(X11, X21, D11, D21, idx_i2j_init)
+        seen["valid"] = int(valid.sum())
+        return (idx, valid, d(z["Xff"])[None], d(z["Cff"])[None], d(z["Qff"])[None], d(z["Xkf"])[None], d(z["Ckf"])[None], d(z["Qkf"])[None])
+    T_WCk = np.array([0.2, -0.1, 0.05, 0.0, 0.0, np.sin(0.05), np.cos(0.05), 1.1], dtype=np.float32)
+    sub = 4
+    config.set_config({"matching": {"use_fast_nn": True, "fast_nn_subsample": sub, "fast_nn_rounds": 4}, "tracking": {"match_frac_thresh": 0.3}})
+    try:
+        img = torch.zeros((3, h, w), dtype=torch.uint8, device=dev)
+        kf = create_frame(0, img, T_WC=_t(T_WCk[None], dev))
+        kf.update_pointmap(_t(z["Xk_canon"], dev), _t(z["Ck"], dev))
+        frame = create_frame(1, img, T_WC=_t(T_WCk[None], dev))
+        kfs = Keyframes()
+        kfs.append(kf)
+        tr = tracker.FrameTracker(SimpleNamespace(device=dev), kfs)
+        new_kf, match_info, try_reloc = tr.track(frame, mast3r_match_fn=match_fn)
+    finally:
+        config.reset_config()
+    seeds = (h // sub) * (w // sub)
+    assert 0.5 * seeds < seen["valid"] <= seeds and seen["valid"] < 0.1 * n            # sparse: far below min_match_frac of the PIXELS
+    assert try_reloc is False and len(match_info) == 6
+    info = tr.last_info.cpu().numpy().reshape(-1)
+    assert info[3] == 1.0                                                              # converged
+    T_rel = S.sim3_mul_mlx(S.sim3_inv_mlx(T_WCk.astype(np.float64)), frame.T_WC.cpu().numpy().reshape(8).astype(np.float64))
+    assert np.abs(T_rel - z["T_true"]).max() < 3e-3                                    # the scene's Sim(3) from the sparse matches
+    mk, uf = tr.last_stats
+    assert 0.4 < mk <= 1.0 and 0.4 < uf <= 1.0 and new_kf is False                     # fractions of the seeds

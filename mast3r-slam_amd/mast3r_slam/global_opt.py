@@ -26,7 +26,7 @@ from typing import Optional
 
 import torch
 
-from . import kernels
+from . import kernels, matching
 from .config import get_config
 from .tracker import constrain_points_to_ray
 
@@ -82,6 +82,8 @@ class FactorGraph:
             valid_j = valid_match_j.bool() & (Qj > self.cfg["Q_conf"])
             valid_i = valid_match_i.bool() & (Qi > self.cfg["Q_conf"])
             frac = torch.minimum(valid_j.float().mean(dim=(1, 2)), valid_i.float().mean(dim=(1, 2)))
+            hw = [int(v) for v in torch.as_tensor(shape_i[0]).reshape(-1)[:2]]
+            frac = frac * matching.match_fraction_scale(hw[0], hw[1])                    # fractions of the seeds with use_fast_nn
             outs.append((idx_i2j, idx_j2i, valid_match_j.bool(), valid_match_i.bool(), Qj, Qi, frac))
         if outs:
             idx_i2j, idx_j2i, vmj, vmi, Qj, Qi, frac = (torch.cat([o[n] for o in outs]) for n in range(7))

@@ -237,6 +237,18 @@ def fast_reciprocal_nn_maps(D1: torch.Tensor, D2: torch.Tensor, subsample: int =
     return out
 
 
+def match_fraction_scale(h: int, w: int) -> float:
+    """What a "fraction of the pixels that matched" has to be multiplied with so that the reference's thresholds
+    (tracking.min_match_frac, match_frac_thresh, the factor graph's min_match_frac) keep their meaning: 1 for the dense
+    matchers; with matching.use_fast_nn the matcher yields at most one match per SEED, so pixels / seeds."""
+    cfg = get_config().get("matching", {})
+    if not cfg.get("use_fast_nn", False):
+        return 1.0
+    sub = int(cfg.get("fast_nn_subsample", 8))
+    seeds = len(range(sub // 2, h, sub)) * len(range(sub // 2, w, sub))
+    return float(h * w) / float(max(1, seeds))
+
+
 def match_fast_nn(X11, X21, D11, D21, idx_1_to_2_init=None):
     """The matcher BASELINE.json's north_star names, behind matching.match's contract (matching.py:12-38): descriptors
     D11 [B,H,W,D] (the view the indices point INTO) and D21 [B,H,W,D] or [B,N,D] -> (idx_1_to_2 [B,N] int64, valid [B,N,1]

@@ -269,10 +269,8 @@ class FrameTracker:
         # The fractions below are "of the pixels" for the reference's dense matchers.  The fast reciprocal NN matcher
         # (matching.use_fast_nn, not in the reference) yields at most one match per seed: its fractions are of the SEEDS,
         # or every frame would fall below min_match_frac.
-        mcfg = get_config().get("matching", {})
-        if mcfg.get("use_fast_nn", False):
-            sub = int(mcfg.get("fast_nn_subsample", 8))
-            n = max(1, len(range(sub // 2, img_size[0], sub)) * len(range(sub // 2, img_size[1], sub)))
+        from .matching import match_fraction_scale
+        n = n / match_fraction_scale(img_size[0], img_size[1])     # the seed count with use_fast_nn, the pixel count otherwise
         if float(host[0]) / n < self.cfg["min_match_frac"]:
             print(f"Skipped frame {frame.frame_id}")
             return False, [], True

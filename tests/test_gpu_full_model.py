@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from mast3r_slam import config, mast3r_utils, model as M, synthetic
+from mast3r_slam import config, mast3r_utils, matching as matching_mod, model as M, synthetic
 from mast3r_slam.frame import create_frame
 from oracle import matching as om
 from oracle import model as OM
@@ -347,3 +347,33 @@ def test_fp16_features_through_the_operator_api(tiny, dev):
     assert np.array_equal(idx_i2j.cpu().numpy(), io) and np.array_equal(valid_j.cpu().numpy(), vo)
     io, vo = om.match_iterative_proj(c(Xh[2])[None], c(Xh[3])[None], c(Dh[2])[None], c(Dh[3])[None], dilation_max=2)
     assert np.array_equal(idx_j2i.cpu().numpy(), io) and np.array_equal(valid_i.cpu().numpy(), vo)
+
+
+def test_match_operators_with_the_fast_reciprocal_nn_matcher(tiny, dev):
+    """matching.use_fast_nn behind the operator API (mast3r_match_asymmetric / _symmetric, mast3r_utils.py:451-533's
+    contract): same shapes and dtypes as with the dense matchers, at most one valid match per seed, every valid index is
+    the reciprocal nearest neighbour fast_reciprocal_nn_maps reports for the network's own descriptors (random weights:
+    maps without spatial coherence, i.e. the block-bound search hands over to its brute-force fallback on the device)."""
+    cfg, w, net = tiny
+    h, wd = 128, 256
+    n = h * wd
+    imi, imj = synthetic.textured_image(h, wd, 20), synthetic.textured_image(h, wd, 21)
+    fi = create_frame(0, torch.from_numpy(imi).to(dev)); fj = create_frame(1, torch.from_numpy(imj).to(dev))
+    X, C, D, Q = mast3r_utils.mast3r_asymmetric_inference(net, fi, fj)
+    config.set_config({"matching": {"use_fast_nn": True, "fast_nn_subsample": 8, "fast_nn_rounds": 3, "dist_thresh": 1e9}})
+    try:
+        idx, valid, Xii, Cii, Qii, Xji, Cji, Qji = mast3r_utils.mast3r_match_asymmetric(net, fi, fj)
+        shp = [torch.tensor([[h, wd]])]
+        s_ij, s_ji, v_j, v_i, *_ = mast3r_utils.mast3r_match_symmetric(net, fi.feat[None], None, fj.feat[None], None, shp, shp)
+    finally:
+        config.reset_config()
+    seeds = (h // 8) * (wd // 8)
+    assert idx.shape == (1, n) and idx.dtype == torch.int64 and valid.shape == (1, n, 1) and valid.dtype == torch.bool
+    assert Xii.shape == (1, n, 3) and Qji.shape == (1, n, 1)
+    assert 0 < int(valid.sum()) <= seeds
+    m = matching_mod.fast_reciprocal_nn_maps(D[0][None], D[1][None], subsample=8, max_iter=3)
+    assert torch.equal(valid[0, :, 0], m["valid"][0, :, 0])                      # dist_thresh switched off above
+    assert torch.equal(idx[0][valid[0, :, 0]], m["idx"][0][valid[0, :, 0]])
+    for s_, v_ in ((s_ij, v_j), (s_ji, v_i)):
+        assert s_.shape == (1, n) and v_.shape == (1, n, 1) and 0 < int(v_.sum()) <= seeds
+        assert int(s_.min()) >= 0 and int(s_.max()) < n

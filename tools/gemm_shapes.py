@@ -52,13 +52,27 @@ for name, m, n, k, epi, dt, groups, per_step in CASES:
         else:
             fn = lambda a=a, w=w, b=b, e=EPI[epi], x=x: ops.gemm_grouped2(a, w[0], w[1], b[0], b[1], e, out=x, resid=x)
         ref = lambda a=a, w=w: (torch.mm(a[0], w[0].T), torch.mm(a[1], w[1].T))
+        mm_ = lambda a=a, w=w, b=b: [torch.addmm(b[i].to(a.dtype), a[i], w[i].T) for i in range(2)]
     else:
         if epi == "rope":
             fn = lambda a=a, w=w, b=b, rc=rcols: ops.gemm_rope(a, w[0], b[0], rtok, rc)
         else:
             fn = lambda a=a, w=w, b=b, e=EPI[epi], x=x: ops.gemm(a, w[0], b[0], e, out=x, resid=x)
         ref = lambda a=a, w=w: torch.mm(a, w[0].T)
-    runs.append((name, 2.0 * groups * m * n * k, fn, ref, per_step, int(_ffi.lib().m3_gemm_pick_tile(m, n, groups))))
+        mm_ = lambda a=a, w=w, b=b: [torch.addmm(b[0].to(a.dtype), a, w[0].T)]
+    # the SAME work through the library: GEMM (+ bias) and then the epilogue as one separate elementwise pass over the output -
+    # fp32 residual: x += y; GELU: erf GELU in place; RoPE: ONE in-place multiply as a stand-in (a real rotation reads two
+    # tables on top: lower bound); plain: nothing
+    xs = None if x is None else (list(x) if groups == 2 else [x])
+    if epi == "acc":
+        eq = lambda mm_=mm_, xs=xs: [xi.add_(yi) for xi, yi in zip(xs, mm_())]
+    elif epi == "gelu":
+        eq = lambda mm_=mm_: [torch.nn.functional.gelu(yi) for yi in mm_()]
+    elif epi == "rope":
+        eq = lambda mm_=mm_: [yi.mul_(1.0009765625) for yi in mm_()]
+    else:
+        eq = mm_
+    runs.append((name, 2.0 * groups * m * n * k, fn, ref, per_step, int(_ffi.lib().m3_gemm_pick_tile(m, n, groups)), eq))
 
 GRAPH = "--graph" in sys.argv        # time hipGraph replays of 16 launches (small launches are host-bound when issued eagerly)
 _graphs = {}
@@ -83,19 +97,20 @@ def t(fn, n=8):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 
-for name, fl, fn, ref, _, _ in runs:
-    fn(); ref()
+for name, fl, fn, ref, _, _, eq in runs:
+    fn(); ref(); eq()
 torch.cuda.synchronize()
-res = {name: ([], []) for name, *_ in runs}
+res = {name: ([], [], []) for name, *_ in runs}
 for rnd in range(5):
-    for name, fl, fn, ref, _, _ in runs:
-        res[name][0].append(t(fn)); res[name][1].append(t(ref))
+    for name, fl, fn, ref, _, _, eq in runs:
+        res[name][0].append(t(fn)); res[name][1].append(t(ref)); res[name][2].append(t(eq))
 print(f"P = {P} pairs per step; M3_GEMM_TILE={os.environ.get('M3_GEMM_TILE', '-')}\n")
-print("| launch | tile | us (ours) | TFLOP/s | torch.mm us (no epilogue) | TFLOP/s | ours/mm time | per step ms |")
-print("|---|---|---|---|---|---|---|---|")
-tot = 0.0
-for name, fl, fn, ref, per_step, tile in runs:
-    a, b = statistics.median(res[name][0]), statistics.median(res[name][1])
+print("| launch | tile | us (ours, fused epilogue) | TFLOP/s | torch.mm us (no epilogue) | TFLOP/s | ours/mm time | torch.addmm + the epilogue as a separate pass, us | ours / that | per step ms |")
+print("|---|---|---|---|---|---|---|---|---|---|")
+tot = tot_eq = 0.0
+for name, fl, fn, ref, per_step, tile, eq in runs:
+    a, b, c = (statistics.median(res[name][i]) for i in range(3))
     tot += a * per_step / 1e3
-    print(f"| {name} | {tile} | {a:.1f} | {fl / a / 1e6:.0f} | {b:.1f} | {fl / b / 1e6:.0f} | {a / b:.2f} | {a * per_step / 1e3:.2f} |")
-print(f"\nsum over one step's launches: {tot:.2f} ms")
+    tot_eq += c * per_step / 1e3
+    print(f"| {name} | {tile} | {a:.1f} | {fl / a / 1e6:.0f} | {b:.1f} | {fl / b / 1e6:.0f} | {a / b:.2f} | {c:.1f} | {a / c:.2f} | {a * per_step / 1e3:.2f} |")
+print(f"\nsum over one step's launches: {tot:.2f} ms; the same work through torch.addmm + separate epilogue passes: {tot_eq:.2f} ms")

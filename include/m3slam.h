@@ -53,7 +53,7 @@ int m3_prep_iter_proj(const float *X11, const float *X21, const int64_t *idx_ini
 
 /* kernels.iter_proj (kernels.py:107-148, numpy twin :151-254; Metal iter_proj.metal:82).
  * rays_with_grad [B,H,W,9], pts3d_norm [B,N,3], p_init [B,N,2] -> p_out [B,N,2],
- * valid_out uint8 [B,N].  ws: uint32 [m3_iter_proj_ws_words(B, N, max_iter)] workspace (per-block step
+ * valid_out uint8 [B,N].  ws: uint32 [m3_iter_proj_ws_words(B, N, max_iter)] workspace (per-wave step
  * maxima, plain stores - no atomics - plus the per-item iteration limit).
  * stop_scope: 0 = reference behaviour, all points stop at the first LM iteration whose
  * max step norm over the WHOLE call is < convergence_thresh; 1 = per batch item. */

@@ -115,7 +115,6 @@ k_iter_proj(const float *__restrict__ rwg, const float *__restrict__ tgt, const 
             float *__restrict__ p_out, uint8_t *__restrict__ valid_out, uint32_t *__restrict__ stepmax,
             const uint32_t *__restrict__ limit, int H, int W, int N, int max_iter, float lam,
             float xhi, float yhi, int tiled) {
-    __shared__ unsigned wmax[kThreads / 64];
     const int b = blockIdx.y;
     int n_iter = max_iter;
     if (!FIRST) {
@@ -171,18 +170,13 @@ k_iter_proj(const float *__restrict__ rwg, const float *__restrict__ tgt, const 
             // per-block maximum of the step norm (as uint bits), one plain store per block and iteration:
             // thousands of atomics on ONE address per iteration serialise (~12 ns each) and used to cost 10x
             // the arithmetic of this kernel
+            // (round 4: per WAVE - the workgroup-level maximum cost two barriers per LM iteration, i.e. the four waves of
+            // a workgroup walked their data-dependent gathers in lock step)
             const float dn = sqrtf(dx * dx + dy * dy);
             unsigned bits = live ? (__float_as_uint(dn) & 0x7fffffffu) : 0u;
             bits = m3_wave_max(bits);
-            if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = bits;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                unsigned m = wmax[0];
-#pragma unroll
-                for (int w = 1; w < kThreads / 64; ++w) m = max(m, wmax[w]);
-                stepmax[((size_t)b * max_iter + it) * gridDim.x + blockIdx.x] = m;
-            }
-            __syncthreads();
+            if ((threadIdx.x & 63) == 0)
+                stepmax[((size_t)b * max_iter + it) * (gridDim.x * (kThreads / 64)) + blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)] = bits;
         }
     }
     if (live) {
@@ -608,7 +602,7 @@ int m3_prep_iter_proj(const float *X11, const float *X21, const int64_t *idx_ini
 
 int64_t m3_iter_proj_ws_words(int B, int N, int max_iter) {
     if (B <= 0 || N <= 0 || max_iter < 0) return 0;
-    return (int64_t)B * max_iter * m3_cdiv(N, kThreads) + B + (int64_t)B * max_iter;
+    return (int64_t)B * max_iter * m3_cdiv(N, kThreads) * (kThreads / 64) + B + (int64_t)B * max_iter;   // per-wave step maxima
 }
 
 int m3_iter_proj(const float *rwg, const float *tgt, const float *p_init, float *p_out,
@@ -618,8 +612,8 @@ int m3_iter_proj(const float *rwg, const float *tgt, const float *p_init, float 
     M3_REQUIRE(B > 0 && H > 0 && W > 0 && N > 0 && max_iter >= 0 && B <= 65535);
     M3_REQUIRE((int64_t)H * W < (1ll << 31) && (stop_scope == 0 || stop_scope == 1));
     hipStream_t st = (hipStream_t)stream;
-    const int nblk = m3_cdiv(N, kThreads);
-    uint32_t *stepmax = ws, *limit = ws + (size_t)B * max_iter * nblk, *red = limit + B;
+    const int nblk = m3_cdiv(N, kThreads), nwav = nblk * (kThreads / 64);
+    uint32_t *stepmax = ws, *limit = ws + (size_t)B * max_iter * nwav, *red = limit + B;
     const float xhi = (float)((double)W - 1.001), yhi = (float)((double)H - 1.001);
     dim3 grid(nblk, B);
     const int tiled = (N == H * W && H % 16 == 0 && W % 16 == 0) ? 1 : 0;
@@ -628,7 +622,7 @@ int m3_iter_proj(const float *rwg, const float *tgt, const float *p_init, float 
     M3_CHECK_LAUNCH("m3_iter_proj/pass1");
     if (max_iter > 1) {
         hipLaunchKernelGGL(k_iter_reduce, dim3(m3_cdiv(B * max_iter, kThreads / 64)), dim3(kThreads), 0, st,
-                           (const uint32_t *)stepmax, red, B * max_iter, nblk);
+                           (const uint32_t *)stepmax, red, B * max_iter, nwav);
         hipLaunchKernelGGL(k_iter_limit, dim3(1), dim3(64), 0, st, (const uint32_t *)red, limit, B, max_iter,
                            convergence_thresh, stop_scope);
         M3_CHECK_LAUNCH("m3_iter_proj/limit");

@@ -91,6 +91,36 @@ def main():
                             D11=sc["D11"], D21=D21, p1=p1, p_ref=ref.astype(np.int32),
                             radius=3, dilation_max=dmax)
 
+    # ---- 2b. edge cases (round 4): inputs the smooth scenes above never produce ----------------------------------
+    # iter_proj: random (non-smooth) ray map -> steps that leave the image, the determinant clamp, points that start outside
+    # the image or on its border, a subset of points (N != H * W), one and three iterations, a large damping
+    rng = np.random.default_rng(21)
+    h, w, n = 20, 28, 300
+    rays = rng.normal(size=(2, h, w, 9)).astype(np.float32)
+    rays[..., :3] /= np.linalg.norm(rays[..., :3], axis=-1, keepdims=True)
+    tgt = rng.normal(size=(2, n, 3)).astype(np.float32)
+    tgt /= np.linalg.norm(tgt, axis=-1, keepdims=True)
+    p0 = np.stack([rng.uniform(-3.0, w + 2.0, size=(2, n)), rng.uniform(-3.0, h + 2.0, size=(2, n))], -1).astype(np.float32)
+    p0[0, :10] = np.array([0.0, 0.0], np.float32); p0[0, 10:20] = np.array([w - 1.0, h - 1.0], np.float32)
+    p0[1, :10, 0] = w - 1.001
+    for tag, iters, lam in (("edge_it1", 1, 1e-8), ("edge_it3", 3, 1e-8), ("edge_lam", 10, 1e-2)):
+        p_ref, v_ref = rk._iter_proj_numpy(rays, tgt, p0, iters, lam, 1e-6)
+        np.savez_compressed(os.path.join(OUT, f"iter_proj_{tag}.npz"), rays_with_grad=rays, pts3d_norm=tgt, p_init=p0,
+                            p_ref=p_ref.astype(np.float32), valid_ref=v_ref, max_iter=iters, lambda_init=lam,
+                            convergence_thresh=1e-6)
+    # refine_matches: other descriptor lengths and radii, random descriptors, centres on and beyond every border, ties
+    for tag, d, radius in (("r2_d16", 16, 2), ("r4_d24", 24, 4), ("r1_d64", 64, 1), ("r3_d5", 5, 3)):
+        rng = np.random.default_rng(100 + d)
+        b, h, w, n = 2, 22, 31, 500
+        D11 = rng.normal(size=(b, h, w, d)).astype(np.float32)
+        D11[1, 5:9, 7:12] = D11[1, 5, 7]                     # a constant patch: ties inside the window
+        D21 = rng.normal(size=(b, n, d)).astype(np.float32)
+        p1 = np.stack([rng.integers(-5, w + 5, size=(b, n)), rng.integers(-5, h + 5, size=(b, n))], -1).astype(np.int32)
+        p1[1, :40] = np.stack([rng.integers(6, 12, 40), rng.integers(4, 9, 40)], -1)
+        ref = rk._refine_matches_numpy(D11, D21, p1, radius, 2)
+        np.savez_compressed(os.path.join(OUT, f"refine_matches_{tag}.npz"), D11=D11, D21=D21, p1=p1, p_ref=ref.astype(np.int32),
+                            radius=radius, dilation_max=2)
+
     # ---- 3. gauss_newton_rays on the reference's own generator ----------------
     rb = _bench_module()
     np.random.seed(42)

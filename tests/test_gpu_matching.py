@@ -42,6 +42,26 @@ def test_iter_proj_golden_bit_exact(dev, golden_dir, tag):
     assert np.array_equal(v.cpu().numpy(), z["valid_ref"])
 
 
+@pytest.mark.parametrize("tag", ["edge_it1", "edge_it3", "edge_lam"])
+def test_iter_proj_edge_case_goldens_bit_exact(dev, golden_dir, tag):
+    """Outputs of the REFERENCE's numpy twin on a random ray map: steps that leave the image, the determinant clamp, starts
+    outside the image and on its corners, N != H * W (the untiled thread mapping), 1 / 3 / 10 iterations, lambda 1e-2."""
+    z = _load(golden_dir, f"iter_proj_{tag}.npz")
+    p, v = kernels.iter_proj(_t(z["rays_with_grad"], dev), _t(z["pts3d_norm"], dev), _t(z["p_init"], dev),
+                             int(z["max_iter"]), float(z["lambda_init"]), float(z["convergence_thresh"]))
+    assert np.array_equal(p.cpu().numpy(), z["p_ref"])
+    assert np.array_equal(v.cpu().numpy(), z["valid_ref"])
+
+
+@pytest.mark.parametrize("tag", ["r2_d16", "r4_d24", "r1_d64", "r3_d5"])
+def test_refine_other_lengths_and_radii_goldens_bit_exact(dev, golden_dir, tag):
+    """Outputs of the REFERENCE's numpy twin for D = 16 / 24 / 64 / 5 and radius 2 / 4 / 1 / 3: the vector kernels of the
+    other descriptor lengths and the generic one, border handling, ties."""
+    z = _load(golden_dir, f"refine_matches_{tag}.npz")
+    r = kernels.refine_matches(_t(z["D11"], dev), _t(z["D21"], dev), _t(z["p1"], dev), int(z["radius"]), int(z["dilation_max"]))
+    assert np.array_equal(r.cpu().numpy(), z["p_ref"])
+
+
 def test_iter_proj_numpy_in_numpy_out_like_reference(golden_dir):
     z = _load(golden_dir, "iter_proj_b1.npz")
     p, v = kernels.iter_proj(z["rays_with_grad"], z["pts3d_norm"], z["p_init"], 10, 1e-8, 1e-6)

@@ -23,6 +23,31 @@ def test_iter_proj_matches_reference_bit_exact(golden_dir):
         assert v.mean() > 0.5
 
 
+EDGE_ITER = ("edge_it1", "edge_it3", "edge_lam")
+EDGE_REFINE = ("r2_d16", "r4_d24", "r1_d64", "r3_d5")
+
+
+def test_iter_proj_edge_cases_match_reference_bit_exact(golden_dir):
+    """Reference-generated (round 4): a random ray map (steps that leave the image, the determinant clamp), points starting
+    outside the image / on its corners, N != H * W, 1 / 3 / 10 iterations, lambda 1e-2."""
+    for tag in EDGE_ITER:
+        z = _load(golden_dir, f"iter_proj_{tag}.npz")
+        p, v = om.iter_proj(z["rays_with_grad"], z["pts3d_norm"], z["p_init"], int(z["max_iter"]),
+                            float(z["lambda_init"]), float(z["convergence_thresh"]), "global")
+        assert np.array_equal(p, z["p_ref"]), tag
+        assert np.array_equal(v, z["valid_ref"]), tag
+        assert 0.02 < v.mean() < 0.98, tag                  # both outcomes of the validity test occur
+
+
+def test_refine_matches_other_lengths_and_radii_bit_exact(golden_dir):
+    """Reference-generated (round 4): D = 16 / 24 / 64 / 5, radius 2 / 4 / 1 / 3, random descriptors, centres beyond every
+    border, a constant patch (ties: the first candidate in raster order wins)."""
+    for tag in EDGE_REFINE:
+        z = _load(golden_dir, f"refine_matches_{tag}.npz")
+        r = om.refine_matches(z["D11"], z["D21"], z["p1"], int(z["radius"]), int(z["dilation_max"]))
+        assert np.array_equal(r, z["p_ref"]), tag
+
+
 def test_iter_proj_early_stop_is_exercised(golden_dir):
     z = _load(golden_dir, "iter_proj_earlystop.npz")
     args = (z["rays_with_grad"], z["pts3d_norm"], z["p_init"], int(z["max_iter"]), float(z["lambda_init"]))

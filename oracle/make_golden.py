@@ -156,6 +156,21 @@ def main():
     np.savez_compressed(os.path.join(OUT, "gn_rays_chain.npz"), Twc=Twc, Xs=Xs, Cs=Cs, ii=ii, jj=jj,
                         idx=idx, valid=valid, Q=Q, Twc_ref=out, max_iter=10, pin=1)
 
+    # the same kind of graph with every optional argument off its default (round 4): two pinned poses, thresholds that cut
+    # points (confidence and match quality), another sigma, a convergence threshold that stops the loop early, and a graph
+    # with a repeated and a reversed edge
+    Twc, Xs, Cs, ii, jj, idx, valid, Q = synthetic.gn_graph(7, 180, 2, seed=17, chain=True, pose_noise=0.015)
+    ii = np.concatenate([ii, ii[:1], jj[1:2]]).astype(ii.dtype); jj2 = np.concatenate([jj, jj[:1], ii[1:2]]).astype(jj.dtype)
+    idx = np.concatenate([idx, idx[:1], idx[1:2]]); valid = np.concatenate([valid, valid[:1], valid[1:2]]); Q = np.concatenate([Q, Q[:1], Q[1:2]])
+    kw = dict(sigma_ray=0.01, sigma_dist=5.0, C_thresh=0.6, Q_thresh=2.0, max_iter=6, delta_thresh=2e-3, pin=2)
+    out = rgn.gauss_newton_rays(Twc, Xs, Cs, ii, jj2, idx, valid, Q, **kw)
+    np.savez_compressed(os.path.join(OUT, "gn_rays_params.npz"), Twc=Twc, Xs=Xs, Cs=Cs, ii=ii, jj=jj2, idx=idx, valid=valid, Q=Q,
+                        Twc_ref=out, **kw)
+    out = rgp.gauss_newton_points(Twc, Xs, Cs, ii, jj2, idx, valid, Q, sigma_point=0.02, C_thresh=0.6, Q_thresh=2.0, max_iter=6,
+                                  delta_thresh=2e-3, pin=2)
+    np.savez_compressed(os.path.join(OUT, "gn_points_params.npz"), Twc=Twc, Xs=Xs, Cs=Cs, ii=ii, jj=jj2, idx=idx, valid=valid, Q=Q,
+                        Twc_ref=out, sigma_point=0.02, C_thresh=0.6, Q_thresh=2.0, max_iter=6, delta_thresh=2e-3, pin=2)
+
     # ---- 4. sim3_ops known answers -------------------------------------------------
     rng = np.random.default_rng(1)
     q1 = rng.normal(size=(16, 4)); q1 /= np.linalg.norm(q1, axis=-1, keepdims=True)

@@ -43,6 +43,25 @@ def test_gauss_newton_rays_golden(golden_dir, tag, tol):
     assert np.array_equal(out[pinned], z["Twc"][pinned])
 
 
+def test_gauss_newton_goldens_with_every_argument_off_its_default(golden_dir):
+    """Outputs of the REFERENCE's twins with sigma / C_thresh / Q_thresh / max_iter / delta_thresh / pin all off their
+    defaults (two pinned poses, thresholds that cut points, an early stop, a repeated and a reversed edge)."""
+    z = _load(golden_dir, "gn_rays_params.npz")
+    kw = {k: (int(z[k]) if k in ("max_iter", "pin") else float(z[k])) for k in
+          ("sigma_ray", "sigma_dist", "C_thresh", "Q_thresh", "max_iter", "delta_thresh", "pin")}
+    out, info = kernels.gauss_newton_rays(z["Twc"], z["Xs"], z["Cs"], z["ii"], z["jj"], z["idx"], z["valid"], z["Q"],
+                                          return_info=True, **kw)
+    assert not info["failed"] and np.abs(out - z["Twc_ref"]).max() <= 5e-5, np.abs(out - z["Twc_ref"]).max()
+    assert np.array_equal(out[:2], z["Twc"][:2])
+    z = _load(golden_dir, "gn_points_params.npz")
+    kw = {k: (int(z[k]) if k in ("max_iter", "pin") else float(z[k])) for k in
+          ("sigma_point", "C_thresh", "Q_thresh", "max_iter", "delta_thresh", "pin")}
+    out, info = kernels.gauss_newton_points(z["Twc"], z["Xs"], z["Cs"], z["ii"], z["jj"], z["idx"], z["valid"], z["Q"],
+                                            return_info=True, **kw)
+    assert not info["failed"] and np.abs(out - z["Twc_ref"]).max() <= 5e-5, np.abs(out - z["Twc_ref"]).max()
+    assert np.array_equal(out[:2], z["Twc"][:2])
+
+
 def test_degenerate_graphs_return_input(dev):
     Twc, Xs, Cs, ii, jj, idx, valid, Q = synthetic.gn_graph(4, 64, 3, seed=1)
     out = kernels.gauss_newton_rays(Twc, Xs, Cs, ii[:0], jj[:0], idx[:0], valid[:0], Q[:0])

@@ -89,6 +89,22 @@ def test_gauss_newton_rays_matches_reference(golden_dir):
         assert np.array_equal(out[0], z["Twc"][np.unique(np.concatenate([z["ii"], z["jj"]]))[0]])  # pinned
 
 
+def test_gauss_newton_with_every_argument_off_its_default(golden_dir):
+    """Reference-generated (round 4): sigma, C_thresh and Q_thresh that cut points, pin = 2, a delta_thresh that stops the
+    loop early, a repeated and a reversed edge - rays and points variants."""
+    z = _load(golden_dir, "gn_rays_params.npz")
+    kw = {k: (int(z[k]) if k in ("max_iter", "pin") else float(z[k])) for k in
+          ("sigma_ray", "sigma_dist", "C_thresh", "Q_thresh", "max_iter", "delta_thresh", "pin")}
+    out = og.gauss_newton_rays(z["Twc"], z["Xs"], z["Cs"], z["ii"], z["jj"], z["idx"], z["valid"], z["Q"], **kw)
+    assert np.abs(out - z["Twc_ref"]).max() <= 1e-6 and np.abs(z["Twc_ref"] - z["Twc"]).max() > 1e-2
+    assert np.array_equal(out[:2], z["Twc"][:2])                     # two pinned poses
+    z = _load(golden_dir, "gn_points_params.npz")
+    kw = {k: (int(z[k]) if k in ("max_iter", "pin") else float(z[k])) for k in
+          ("sigma_point", "C_thresh", "Q_thresh", "max_iter", "delta_thresh", "pin")}
+    out = og.gauss_newton_points(z["Twc"], z["Xs"], z["Cs"], z["ii"], z["jj"], z["idx"], z["valid"], z["Q"], **kw)
+    assert np.abs(out - z["Twc_ref"]).max() <= 1e-6 and np.array_equal(out[:2], z["Twc"][:2])
+
+
 def test_sim3_ops_known_answers(golden_dir):
     z = _load(golden_dir, "sim3_ops.npz")
     assert np.array_equal(S.quat_multiply(z["q1"], z["q2"]), z["qmul"])

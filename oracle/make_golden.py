@@ -171,6 +171,14 @@ def main():
     np.savez_compressed(os.path.join(OUT, "gn_points_params.npz"), Twc=Twc, Xs=Xs, Cs=Cs, ii=ii, jj=jj2, idx=idx, valid=valid, Q=Q,
                         Twc_ref=out, sigma_point=0.02, C_thresh=0.6, Q_thresh=2.0, max_iter=6, delta_thresh=2e-3, pin=2)
 
+    # calibrated variant with its optional arguments off their defaults: a pixel border and a depth floor that reject
+    # projections, other sigmas, thresholds, two pinned poses (the well-conditioned chain graph of gn_calib_chain)
+    kwc = dict(pixel_border=40, z_eps=0.05, sigma_pixel=2.0, sigma_depth=0.3, C_thresh=0.6, Q_thresh=2.0, max_iter=5,
+               delta_thresh=1e-3, pin=2)
+    out = rgc.gauss_newton_calib(Tn.copy(), Xc, Cc, Kmat, iic, jjc, idxc, validc, Qc, (640, 480), **kwc)
+    np.savez_compressed(os.path.join(OUT, "gn_calib_params.npz"), Twc=Tn, Xs=Xc, Cs=Cc, K=Kmat, ii=iic, jj=jjc, idx=idxc,
+                        valid=validc, Q=Qc, Twc_ref=out, img_size=np.array([640, 480]), **kwc)
+
     # ---- 4. sim3_ops known answers -------------------------------------------------
     rng = np.random.default_rng(1)
     q1 = rng.normal(size=(16, 4)); q1 /= np.linalg.norm(q1, axis=-1, keepdims=True)

@@ -62,6 +62,18 @@ def test_gauss_newton_goldens_with_every_argument_off_its_default(golden_dir):
     assert np.array_equal(out[:2], z["Twc"][:2])
 
 
+def test_gauss_newton_calib_golden_with_every_argument_off_its_default(golden_dir):
+    """Reference twin of the calibrated variant with a pixel border and a depth floor that reject projections, other sigmas
+    and thresholds, two pinned poses, an early stop."""
+    z = _load(golden_dir, "gn_calib_params.npz")
+    kw = {k: (int(z[k]) if k in ("max_iter", "pin", "pixel_border") else float(z[k])) for k in
+          ("pixel_border", "z_eps", "sigma_pixel", "sigma_depth", "C_thresh", "Q_thresh", "max_iter", "delta_thresh", "pin")}
+    out, info = kernels.gauss_newton_calib(z["Twc"], z["Xs"], z["Cs"], z["K"], z["ii"], z["jj"], z["idx"], z["valid"], z["Q"],
+                                           tuple(int(v) for v in z["img_size"]), return_info=True, **kw)
+    assert not info["failed"] and np.abs(out - z["Twc_ref"]).max() <= 5e-5, np.abs(out - z["Twc_ref"]).max()
+    assert np.array_equal(out[:2], z["Twc"][:2])
+
+
 def test_degenerate_graphs_return_input(dev):
     Twc, Xs, Cs, ii, jj, idx, valid, Q = synthetic.gn_graph(4, 64, 3, seed=1)
     out = kernels.gauss_newton_rays(Twc, Xs, Cs, ii[:0], jj[:0], idx[:0], valid[:0], Q[:0])

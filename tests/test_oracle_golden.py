@@ -105,6 +105,16 @@ def test_gauss_newton_with_every_argument_off_its_default(golden_dir):
     assert np.abs(out - z["Twc_ref"]).max() <= 1e-6 and np.array_equal(out[:2], z["Twc"][:2])
 
 
+def test_gauss_newton_calib_with_every_argument_off_its_default(golden_dir):
+    z = _load(golden_dir, "gn_calib_params.npz")
+    kw = {k: (int(z[k]) if k in ("max_iter", "pin", "pixel_border") else float(z[k])) for k in
+          ("pixel_border", "z_eps", "sigma_pixel", "sigma_depth", "C_thresh", "Q_thresh", "max_iter", "delta_thresh", "pin")}
+    out = og.gauss_newton_calib(z["Twc"], z["Xs"], z["Cs"], z["K"], z["ii"], z["jj"], z["idx"], z["valid"], z["Q"],
+                                tuple(int(v) for v in z["img_size"]), **kw)
+    assert np.abs(out - z["Twc_ref"]).max() <= 1e-6 and np.abs(z["Twc_ref"] - z["Twc"]).max() > 1e-3
+    assert np.array_equal(out[:2], z["Twc"][:2])
+
+
 def test_sim3_ops_known_answers(golden_dir):
     z = _load(golden_dir, "sim3_ops.npz")
     assert np.array_equal(S.quat_multiply(z["q1"], z["q2"]), z["qmul"])

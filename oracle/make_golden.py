@@ -208,6 +208,15 @@ def main():
     np.savez_compressed(os.path.join(OUT, "cholesky_solve.npz"), H=H, g=g, x=rl.cholesky_solve(H, g, 1e-6),
                         H32=H.astype(np.float32), g32=g.astype(np.float32),
                         x32=rl.cholesky_solve(H.astype(np.float32), g.astype(np.float32), 1e-6))
+    # a backend-sized system (30 free keyframes = 210 unknowns: several 64-wide block columns of the device Cholesky) with
+    # the conditioning of a pose-graph normal matrix (eigenvalues over 6 decades)
+    rng = np.random.default_rng(2)
+    n = 210
+    U, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    H = (U * np.logspace(0, 6, n)) @ U.T
+    H = 0.5 * (H + H.T)
+    g = rng.normal(size=n) * 100.0
+    np.savez_compressed(os.path.join(OUT, "cholesky_solve_n210.npz"), H=H, g=g, x=rl.cholesky_solve(H, g, 1e-6))
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f:32s} {os.path.getsize(os.path.join(OUT, f)) / 1024:8.1f} KiB")

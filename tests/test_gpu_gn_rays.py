@@ -74,6 +74,15 @@ def test_gauss_newton_calib_golden_with_every_argument_off_its_default(golden_di
     assert np.array_equal(out[:2], z["Twc"][:2])
 
 
+def test_cholesky_solve_golden_backend_sized_system(dev, golden_dir):
+    """kernels.cholesky_solve (the blocked float64 device Cholesky, 4 block columns here) against the output of the
+    REFERENCE's linalg.cholesky_solve on a 210-unknown system with eigenvalues over 6 decades."""
+    z = _load(golden_dir, "cholesky_solve_n210.npz")
+    x = kernels.cholesky_solve(z["H"], z["g"], 1e-6)
+    assert isinstance(x, np.ndarray) and x.dtype == np.float64
+    assert np.abs(x - z["x"]).max() <= 1e-8 * np.abs(z["x"]).max(), np.abs(x - z["x"]).max() / np.abs(z["x"]).max()
+
+
 def test_degenerate_graphs_return_input(dev):
     Twc, Xs, Cs, ii, jj, idx, valid, Q = synthetic.gn_graph(4, 64, 3, seed=1)
     out = kernels.gauss_newton_rays(Twc, Xs, Cs, ii[:0], jj[:0], idx[:0], valid[:0], Q[:0])

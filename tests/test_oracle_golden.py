@@ -130,6 +130,12 @@ def test_sim3_ops_known_answers(golden_dir):
     assert np.array_equal(S.huber_weight(z["hub_r"]), z["hub_w"])
 
 
+def test_cholesky_solve_backend_sized_system(golden_dir):
+    z = _load(golden_dir, "cholesky_solve_n210.npz")
+    x = og.cholesky_solve(z["H"], z["g"])
+    assert np.abs(x - z["x"]).max() <= 1e-9 * np.abs(z["x"]).max()
+
+
 def test_cholesky_solve(golden_dir):
     z = _load(golden_dir, "cholesky_solve.npz")
     assert np.allclose(og.cholesky_solve(z["H"], z["g"]), z["x"], rtol=0, atol=1e-12)

@@ -217,6 +217,12 @@ def main():
     H = 0.5 * (H + H.T)
     g = rng.normal(size=n) * 100.0
     np.savez_compressed(os.path.join(OUT, "cholesky_solve_n210.npz"), H=H, g=g, x=rl.cholesky_solve(H, g, 1e-6))
+    # ---- 6. the reference's DEFAULT_CONFIG (config.py:53-...) as data: the constants the hot path reads must be the
+    # reference's (tests/test_abi_and_host.py compares mast3r_slam.config.DEFAULT_CONFIG key by key)
+    import json
+    from mlx_mast3r_slam import config as rcfg                                # imports pathlib / yaml only
+    with open(os.path.join(OUT, "reference_default_config.json"), "w") as f:
+        json.dump(rcfg.DEFAULT_CONFIG, f, indent=1, sort_keys=True)
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f:32s} {os.path.getsize(os.path.join(OUT, f)) / 1024:8.1f} KiB")

@@ -120,6 +120,36 @@ def test_config_defaults_and_merge():
     assert config.get_config()["matching"]["use_simple"] is True
 
 
+def test_default_config_equals_the_reference_constants(golden_dir):
+    """tests/golden/reference_default_config.json = the reference's DEFAULT_CONFIG (config.py:53-) dumped by
+    oracle/make_golden.py.  Every constant the hot path keeps must have the reference's value; what this repo ADDS is
+    listed here, with where its default comes from."""
+    import json
+    ref = json.load(open(os.path.join(golden_dir, "reference_default_config.json")))
+    ours = config.DEFAULT_CONFIG
+    added = {
+        ("matching", "refine_radius"), ("matching", "refine_dilation"), ("matching", "use_refine"),   # matching.py:405-407's .get() defaults
+        ("matching", "refine_chained"),                                                              # numpy-twin vs Metal semantics
+        ("matching", "use_fast_nn"), ("matching", "fast_nn_subsample"), ("matching", "fast_nn_rounds"),   # K8: not in the reference
+        ("local_opt", "min_match_frac"),                                                             # slam.py:309-311's .get() default
+    }
+    seen = 0
+    for sec, val in ours.items():
+        if isinstance(val, dict):
+            for k, v in val.items():
+                if (sec, k) in added:
+                    assert k not in ref.get(sec, {}), (sec, k)
+                    continue
+                assert sec in ref and k in ref[sec], (sec, k)
+                assert ref[sec][k] == v, (sec, k, ref[sec][k], v)
+                seen += 1
+        else:
+            assert ref[sec] == val, sec
+            seen += 1
+    assert seen >= 40
+    assert ours["local_opt"]["min_match_frac"] == 0.1 and ours["reloc"]["min_match_frac"] == ref["reloc"]["min_match_frac"] == 0.3
+
+
 def test_local_map_follows_reference_pinning():
     uniq, local, nfree = kernels._local_map(np.array([3, 1, 1]), np.array([1, 4, 3]), 6, pin=1)
     assert uniq.tolist() == [1, 3, 4] and nfree == 2

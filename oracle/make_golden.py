@@ -217,6 +217,16 @@ def main():
     H = 0.5 * (H + H.T)
     g = rng.normal(size=n) * 100.0
     np.savez_compressed(os.path.join(OUT, "cholesky_solve_n210.npz"), H=H, g=g, x=rl.cholesky_solve(H, g, 1e-6))
+    # ---- 5b. the sim3_ops helpers the first fixture left out: quat_inv, sim3_act, huber_weight with another k -------------
+    rng = np.random.default_rng(31)
+    q = rng.normal(size=(16, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    t = rng.normal(size=(16, 3)); sc_ = np.exp(rng.normal(size=(16, 1)) * 0.2)
+    X = rng.normal(size=(16, 50, 3))
+    r = rng.normal(size=128) * 4
+    np.savez_compressed(os.path.join(OUT, "sim3_ops_more.npz"), q=q, t=t, s=sc_, X=X, r=r,
+                        qinv=rs.quat_inv(q), act=rs.sim3_act(t[:, None, :], q[:, None, :], sc_[:, None, :], X),
+                        hub_k2=rs.huber_weight(r, 2.0), hub_k05=rs.huber_weight(r, 0.5))
+
     # ---- 6. the reference's DEFAULT_CONFIG (config.py:53-...) as data: the constants the hot path reads must be the
     # reference's (tests/test_abi_and_host.py compares mast3r_slam.config.DEFAULT_CONFIG key by key)
     import json

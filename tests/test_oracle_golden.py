@@ -130,6 +130,15 @@ def test_sim3_ops_known_answers(golden_dir):
     assert np.array_equal(S.huber_weight(z["hub_r"]), z["hub_w"])
 
 
+def test_sim3_ops_remaining_helpers(golden_dir):
+    """quat_inv, sim3_act (batched, broadcast over points) and huber_weight with other k: exact against the reference."""
+    z = _load(golden_dir, "sim3_ops_more.npz")
+    assert np.array_equal(S.quat_inv(z["q"]), z["qinv"])
+    act = S.sim3_act(z["t"][:, None, :], z["q"][:, None, :], z["s"][:, None, 0], z["X"])
+    assert np.array_equal(act, z["act"])
+    assert np.array_equal(S.huber_weight(z["r"], 2.0), z["hub_k2"]) and np.array_equal(S.huber_weight(z["r"], 0.5), z["hub_k05"])
+
+
 def test_cholesky_solve_backend_sized_system(golden_dir):
     z = _load(golden_dir, "cholesky_solve_n210.npz")
     x = og.cholesky_solve(z["H"], z["g"])

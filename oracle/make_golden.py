@@ -108,6 +108,17 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"iter_proj_{tag}.npz"), rays_with_grad=rays, pts3d_norm=tgt, p_init=p0,
                             p_ref=p_ref.astype(np.float32), valid_ref=v_ref, max_iter=iters, lambda_init=lam,
                             convergence_thresh=1e-6)
+    # the reference benchmark's OWN input recipe for iter_proj (benchmark_all_kernels.py:56-77, its first configuration:
+    # b = 1, 64 x 64, 1000 points; un-normalised random rays, random unit targets, uniform starts) under its seed
+    np.random.seed(42)
+    b_, h_, w_, n_ = 1, 64, 64, 1000
+    rays_b = np.random.randn(b_, h_, w_, 9).astype(np.float32)
+    pts_b = np.random.randn(b_, n_, 3).astype(np.float32)
+    pts_b = pts_b / np.linalg.norm(pts_b, axis=-1, keepdims=True)
+    p_b = np.stack([np.random.rand(b_, n_) * (w_ - 1), np.random.rand(b_, n_) * (h_ - 1)], axis=-1).astype(np.float32)
+    p_ref, v_ref = rk._iter_proj_numpy(rays_b, pts_b, p_b.copy(), 10, 1e-8, 1e-6)
+    np.savez_compressed(os.path.join(OUT, "iter_proj_refbench.npz"), rays_with_grad=rays_b, pts3d_norm=pts_b, p_init=p_b,
+                        p_ref=p_ref.astype(np.float32), valid_ref=v_ref, max_iter=10, lambda_init=1e-8, convergence_thresh=1e-6)
     # refine_matches: other descriptor lengths and radii, random descriptors, centres on and beyond every border, ties
     for tag, d, radius in (("r2_d16", 16, 2), ("r4_d24", 24, 4), ("r1_d64", 64, 1), ("r3_d5", 5, 3)):
         rng = np.random.default_rng(100 + d)

@@ -42,7 +42,7 @@ def test_iter_proj_golden_bit_exact(dev, golden_dir, tag):
     assert np.array_equal(v.cpu().numpy(), z["valid_ref"])
 
 
-@pytest.mark.parametrize("tag", ["edge_it1", "edge_it3", "edge_lam"])
+@pytest.mark.parametrize("tag", ["edge_it1", "edge_it3", "edge_lam", "refbench"])
 def test_iter_proj_edge_case_goldens_bit_exact(dev, golden_dir, tag):
     """Outputs of the REFERENCE's numpy twin on a random ray map: steps that leave the image, the determinant clamp, starts
     outside the image and on its corners, N != H * W (the untiled thread mapping), 1 / 3 / 10 iterations, lambda 1e-2."""

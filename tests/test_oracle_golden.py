@@ -23,7 +23,7 @@ def test_iter_proj_matches_reference_bit_exact(golden_dir):
         assert v.mean() > 0.5
 
 
-EDGE_ITER = ("edge_it1", "edge_it3", "edge_lam")
+EDGE_ITER = ("edge_it1", "edge_it3", "edge_lam", "refbench")
 EDGE_REFINE = ("r2_d16", "r4_d24", "r1_d64", "r3_d5")
 
 

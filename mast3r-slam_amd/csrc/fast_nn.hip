@@ -1,6 +1,8 @@
-// Brute-force nearest neighbour in descriptor space (maximum dot product) - the search primitive of
-// "fast reciprocal NN" matching (MASt3R, Leroy et al. 2024, section 3.3; mast3r/fast_nn.py of the public
-// implementation).  BASELINE.json's north_star names this matcher; the reference tree has no implementation
+// Nearest neighbour in descriptor space (maximum dot product) - the search primitive of "fast reciprocal NN" matching
+// (MASt3R, Leroy et al. 2024, section 3.3; mast3r/fast_nn.py of the public implementation).  Three forms, same result:
+// an fp32 FMA-chain kernel (k_nn_search), the brute-force search on the matrix cores (k_nn_mfma) and, since round 4, an
+// exact search that bounds most of the database away first (k_frnn_blockstats / _seed_lb / _survivors / _eval, further
+// down) with k_nn_mfma as its device-side fallback.  BASELINE.json's north_star names this matcher; the reference tree has no implementation
 // of it, so the semantics below are this repo's and are pinned by its own oracle:
 //
 //   score(s, n) = E + O,  E = fma chain over even k (ascending), O = fma chain over odd k (ascending), fp32

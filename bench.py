@@ -530,6 +530,10 @@ class PairsWorkload:
         result["fast_nn_matcher"] = {"ms_per_pair": round(ms_all / P, 3), "ms_all_pairs": round(ms_all, 3), "pairs": P,
                                      "reciprocal_pairs": int(mp["count"].sum()), "seeds_per_pair": seeds,
                                      "pruned_round_us": [round(u, 1) for u in us_of("m3_frnn_round_pruned")],
+                                     "ms_per_step_with_this_matcher": round(result["stage_ms"]["infer"] + ms_all + result["stage_ms"]["gn"], 3),
+                                     "pairs_per_s_with_this_matcher": round(P * 1e3 / (result["stage_ms"]["infer"] + ms_all + result["stage_ms"]["gn"]), 1),
+                                     "derived_note": "the two fields above = this run's infer and GN legs + this matcher's time (the timed step "
+                                                     "uses the reference's dense matcher; `--matcher fast_nn` times the step with this one)",
                                      "brute_force": {"ms_all_pairs": round(ms_brute, 3), "same_outputs_bit_for_bit": same,
                                                      "round_us": us_round,
                                                      "active_round_us": [round(u, 1) for u in us_of("m3_frnn_round_active")]},

@@ -65,6 +65,8 @@ def parse(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the collectives even with one rank")
+    ap.add_argument("--dist-overhead", action="store_true",
+                    help="also measure the dist_overhead block with --model tiny (always on for the full model unless --no-b1)")
     ap.add_argument("--no-b1", action="store_true", help="skip the extra measurements outside the timed step (batch 1, fp16 features, fast NN)")
     # backend workload (BASELINE configs[4])
     ap.add_argument("--keyframes", type=int, default=256)
@@ -270,7 +272,8 @@ class PairsWorkload:
         self.n = self.h * self.w
         self.tcfg = config.get_config()["tracking"]
         self.graphs = None
-        self.marks, self.pending, self.state = [], [], {}
+        self.marks, self.state = [], {}
+        self.gather, self.gathered = None, None
 
     def _make_scene(self, base):
         """What the matcher and the Gauss-Newton solve run on: P smooth two-view scenes of
@@ -320,8 +323,7 @@ class PairsWorkload:
     @staticmethod
     def wire(o1, o2, idx, valid, poses):
         """What travels: pointmaps + confidences fp32, match index int32, validity u8, poses."""
-        import torch
-        return (o1["pts3d"], o2["pts3d"], o1["conf"], o2["conf"], idx.to(torch.int32), valid, poses)
+        return (o1["pts3d"], o2["pts3d"], o1["conf"], o2["conf"], idx, valid, poses)
 
     def warm(self):
         """eager warm-up (lazy allocations, attribute setup), then capture each leg into its own hipGraph: the step
@@ -348,7 +350,7 @@ class PairsWorkload:
                 self.graphs = None
         self.state = {"o1": o1, "o2": o2, "idx": idx, "valid": valid, "gn": gn}
 
-    def step(self, timed=False):
+    def step(self, timed=False, exchange=None):
         torch, st, graphs = self.torch, self.state, self.graphs
         m = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
         if m: m[0].record()
@@ -373,21 +375,39 @@ class PairsWorkload:
         if m:
             m[3].record()
             self.marks.append(m)
-        if self.ctx.dist is not None:
-            # snapshot the result buffers (pack = one cat kernel) and let RCCL gather the snapshot on its own
-            # stream while the next step computes; at most one gather in flight
-            self.drain()
-            self.pending.append(self.m3dist.all_gather_results(self.wire(st["o1"], st["o2"], st["idx"], st["valid"], st["gn"][0]),
-                                                               async_op=True))
+        if (self.ctx.dist is not None) if exchange is None else exchange:
+            self.exchange()
+
+    def exchange(self):
+        """Snapshot the result buffers into the pre-allocated packed send buffer (one copy kernel per field; the index
+        is narrowed to int32 inside its copy) and let RCCL gather the snapshot on the communicator's stream while the
+        next step computes; at most one gather in flight.  Nothing is allocated here (dist.PackedGather), and the
+        gathered results are strided views of the receive buffer - no unpacking copies."""
+        torch, st = self.torch, self.state
+        fields = self.wire(st["o1"], st["o2"], st["idx"], st["valid"], st["gn"][0])
+        if self.gather is None:
+            dts = [torch.int32 if t.dtype == torch.int64 else t.dtype for t in fields]
+            self.gather = self.m3dist.PackedGather(fields, dtypes=dts, group=self.ctx.group)
+        self.gather.post(fields)
 
     def drain(self):
-        if self.pending:
-            self.pending.pop().wait()                               # the last step's gather belongs to the timed region
+        if self.gather is not None:
+            self.gathered = self.gather.wait()                      # the last step's gather belongs to the timed region
 
     def report(self, result, args):
         torch, np, P, ctx, sc, n, tcfg = self.torch, self.np, self.P, self.ctx, self.sc, self.n, self.tcfg
         from mast3r_slam import _ffi, ops
         marks = self.marks
+        if self.gathered is not None:
+            # the exchange delivered this rank's last results: its row of every gathered view against the local tensors
+            st = self.state
+            local = self.wire(st["o1"], st["o2"], st["idx"], st["valid"], st["gn"][0])
+            same = all(bool(torch.equal(g[ctx.rank], l.to(g.dtype))) for g, l in zip(self.gathered, local))
+            result["exchange"] = {"bytes_per_rank": int(self.gather.nbytes), "fields": len(local),
+                                  "own_row_equals_local_results": same,
+                                  "gathered_shapes": [list(g.shape) for g in self.gathered]}
+            if not same:
+                raise SystemExit("bench invalid: the all-gathered results differ from this rank's local results")
         stage_ms = {k: sum(m[i].elapsed_time(m[i + 1]) for m in marks) / len(marks) for i, k in enumerate(("infer", "match", "gn"))}
         stage_ms["sum"] = sum(stage_ms.values())
         # ---- did the match and GN legs do the work they name? ----
@@ -453,8 +473,51 @@ class PairsWorkload:
         })
         if world == 1 and not args.no_b1:
             self._extras(result, args)
+            if args.model == "full" or args.dist_overhead:
+                self._dist_overhead(result, args)
         if ctx.rank == 0 and world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline_pairs(args, self.net)
+
+    def _dist_overhead(self, result, args, steps: int = 10, rounds: int = 3):
+        """What the N > 1 step adds on ONE GPU: the same graph replays with and without the result exchange (snapshot into the
+        packed send buffer + a one-rank RCCL all-gather on the communicator's stream + the views of the receive buffer), in
+        interleaved rounds on one high-priority compute stream.  The xGMI transfer itself is not in it (one rank)."""
+        import statistics
+        import tempfile
+        import torch.distributed as tdist
+        torch = self.torch
+        own = not tdist.is_initialized()
+        if own:
+            f = tempfile.NamedTemporaryFile(prefix="m3_bench_rdzv1_", delete=False)
+            f.close(); os.unlink(f.name)
+            tdist.init_process_group("nccl", rank=0, world_size=1, init_method="file://" + f.name, device_id=self.ctx.dev)
+
+        def run(with_exchange):
+            for _ in range(2):
+                self.step(exchange=with_exchange)
+            self.drain(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step(exchange=with_exchange)
+            if with_exchange:
+                self.drain()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps * 1e3
+        hp = torch.cuda.Stream(priority=-1)
+        hp.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(hp):
+            arms = [(run(False), run(True)) for _ in range(rounds)]
+        torch.cuda.synchronize()
+        without, with_x = statistics.median(a for a, _ in arms), statistics.median(b for _, b in arms)
+        result["dist_overhead"] = {"ms_per_step_without_exchange": round(without, 3), "ms_per_step_with_exchange": round(with_x, 3),
+                                   "delta_ms": round(with_x - without, 3), "packed_bytes_per_rank": int(self.gather.nbytes),
+                                   "rounds": [[round(a, 3), round(b, 3)] for a, b in arms],
+                                   "note": "one rank: dist.PackedGather.post (7 field copies into the pre-allocated send buffer) + "
+                                           "all_gather_into_tensor(async_op=True) on RCCL's stream + wait (stream-ordered) + strided "
+                                           "views of the receive buffer; compute on a high-priority stream; medians of interleaved rounds"}
+        if own:
+            self.gather = None
+            tdist.destroy_process_group()
 
     def _extras(self, result, args):
         """Measurements outside the timed step (N = 1 only)."""
@@ -977,6 +1040,12 @@ def run_rank(args) -> int:
             import __graft_entry__
             __graft_entry__.build()
     wl = (StubWorkload if args.stub else BackendWorkload if args.workload == "backend" else PairsWorkload)(args, ctx)
+    if dist is not None and not args.stub and dev.type == "cuda":
+        # RCCL's kernels run on the communicator's (normal-priority) stream: put the compute on a high-priority one, so that
+        # where both want a CU the GEMM's workgroups (one per CU, 128 KiB of LDS) are dispatched first
+        hp = torch.cuda.Stream(device=dev, priority=-1)
+        hp.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(hp)
     wl.warm()
     for _ in range(args.warmup):
         wl.step()

@@ -40,6 +40,9 @@ int m3_abi_version(void);
 const char *m3_status_string(int status);
 /* Text of the last HIP error seen by this library on the calling thread ("" if none). */
 const char *m3_last_hip_error(void);
+/* Compute units of the current device (cached per device): the "fills the chip" grid thresholds of the convolution
+ * dispatch (ops.conv3x3_direct_ok, the sliced single-pass convolution) derive from it instead of a constant 256. */
+int m3_device_cu_count(void);
 
 /* ------------------------------------------------------------------ matching */
 

@@ -13,7 +13,7 @@ extern "C" {
 // 2000 (round 3): m3_chol_solve's workspace is m3_chol_ws_doubles(dim) (was 1 + dim); m3_track_* info carries the
 // solver-failure flag; the RoPE GEMM entry points take (rope_tok, tokens_per_image, rope_cols) since 1001 -> callers built
 // against a 1xxx header must be rebuilt (tests assert the exact value).
-int m3_abi_version(void) { return 2002; }
+int m3_abi_version(void) { return 2003; }
 
 const char *m3_status_string(int status) {
     switch (status) {
@@ -26,5 +26,19 @@ const char *m3_status_string(int status) {
 }
 
 const char *m3_last_hip_error(void) { return g_err; }
+
+// Compute units of the current device (hipDeviceProp_t.multiProcessorCount; 256 on an MI355X in SPX mode, fewer in a
+// CPX / NPS partition), read once per device.  Grid-size thresholds ("does this launch fill the chip") derive from it.
+int m3_device_cu_count(void) {
+    static std::atomic<int> cached[64];
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) return 256;
+    int v = cached[d].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d) != hipSuccess || prop.multiProcessorCount <= 0) return 256;
+    cached[d].store(prop.multiProcessorCount, std::memory_order_relaxed);
+    return prop.multiProcessorCount;
+}
 
 }  // extern "C"

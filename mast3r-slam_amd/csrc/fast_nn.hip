@@ -1005,11 +1005,15 @@ static int frnn_search_pruned(const void *qpacked, int NQ, const int32_t *qidx, 
         const int qblocks = m3_cdiv(S, kQPB);
         int splits = m3_cdiv(1024, qblocks * P);
         if (splits < 1) splits = 1;
-        if (splits > m3_cdiv(NB, kRows)) splits = m3_cdiv(NB, kRows);
-        int per_split = m3_cdiv(m3_cdiv(NB, splits), kRows) * kRows;
-        splits = m3_cdiv(NB, per_split);
+        // the centroid table is [P][NBp][32] (NBp = NB rounded up to 64): the search runs over NBp rows so that pair b's
+        // rows start at b * NBp as k_frnn_blockstats laid them out (with N = NB every pair b > 0 scored the wrong rows
+        // whenever NB % 64 != 0, e.g. 224 x 224: results stayed exact, the lower bound - and with it the pruning - did not);
+        // the padding rows are zero vectors and k_frnn_seed_lb clamps the chosen block to < NB
+        if (splits > m3_cdiv(NBp, kRows)) splits = m3_cdiv(NBp, kRows);
+        int per_split = m3_cdiv(m3_cdiv(NBp, splits), kRows) * kRows;
+        splits = m3_cdiv(NBp, per_split);
         hipLaunchKernelGGL(k_nn_mfma<1>, dim3(qblocks, splits, P), blk, 0, st, qhi, (const unsigned short *)nullptr, qidx, cen,
-                           (const unsigned short *)nullptr, keysC, S, NQ, NB, per_split, qlist, qcount, (const int32_t *)nullptr, 0);
+                           (const unsigned short *)nullptr, keysC, S, NQ, NBp, per_split, qlist, qcount, (const int32_t *)nullptr, 0);
     }
     const dim3 gl(m3_cdiv(S, kThreads / 64), P);
     const int ngrp = m3_cdiv(nqt, kQG);

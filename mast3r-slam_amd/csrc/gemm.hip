@@ -362,7 +362,7 @@ int run_split(const GemmArgs &a, int S, int epi, void *ws, hipStream_t st) {
         // enough output tiles to give every CU a workgroup: one pass, the S slice sums added in the finishing order (same bits)
         const long tiles = (long)m3_cdiv(a.M, BM) * m3_cdiv(a.N, BN) * (a.groups > 1 ? a.groups : 1);
         static const bool sliced_ok = [] { const char *e = getenv("M3_CONV_SLICED"); return !(e && atoi(e) == 0); }();
-        if (sliced_ok && tiles >= 256) {
+        if (sliced_ok && tiles >= m3_device_cu_count()) {
             GemmArgs q = a;
             q.slices = S; q.splits = 1;
             return launch<MODE>(q, epi, st);

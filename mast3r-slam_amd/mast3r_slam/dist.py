@@ -20,30 +20,93 @@ def shard_range(total: int, rank: int, world: int) -> range:
     return range(lo, lo + q + (1 if rank < r else 0))
 
 
+def _layout(meta):
+    """Byte offset and length of every field of a packed buffer (fields start on 16-byte boundaries) + the total."""
+    spans, off = [], 0
+    for shape, dtype in meta:
+        nbytes = torch.empty(0, dtype=dtype).element_size()
+        for s in shape:
+            nbytes *= int(s)
+        spans.append((off, nbytes))
+        off += nbytes + ((-nbytes) % 16)
+    return spans, off
+
+
 def pack(tensors):
     """Flatten a tuple of tensors into one uint8 buffer (+ the metadata to undo it)."""
-    meta = [(t.shape, t.dtype) for t in tensors]
-    flat = [t.contiguous().view(-1).view(torch.uint8) for t in tensors]
-    pad = [(-f.numel()) % 16 for f in flat]                      # keep every segment 16-byte aligned
-    parts = []
-    for f, p in zip(flat, pad):
-        parts.append(f)
-        if p:
-            parts.append(torch.zeros(p, dtype=torch.uint8, device=f.device))
-    return torch.cat(parts), meta
+    meta = [(tuple(t.shape), t.dtype) for t in tensors]
+    spans, total = _layout(meta)
+    buf = torch.zeros(total, dtype=torch.uint8, device=tensors[0].device)
+    for (off, nbytes), t in zip(spans, tensors):
+        buf[off:off + nbytes].view(t.dtype).view(t.shape).copy_(t)
+    return buf, meta
 
 
-def unpack(buf, meta, world):
-    """buf uint8 [world, nbytes] -> tuple of tensors with the rank axis folded into dim 0."""
-    out, off = [], 0
-    for shape, dtype in meta:
-        nbytes = int(torch.empty(0, dtype=dtype).element_size())
-        for s in shape:
-            nbytes *= s
-        seg = buf[:, off:off + nbytes].contiguous().view(-1).view(dtype)
-        out.append(seg.view((world * shape[0],) + tuple(shape[1:])))
-        off += nbytes + ((-nbytes) % 16)
+def unpack(buf, meta, world, fold: bool = True):
+    """buf uint8 [world, nbytes] -> tuple of tensors.
+    fold=False: STRIDED VIEWS of `buf`, shape [world, *shape] - no byte moves (a field of rank r sits at
+    buf[r, off:off+n]; 16-byte field offsets keep every dtype aligned).
+    fold=True: the rank axis folded into dim 0, [world * shape[0], ...] - still a view at world == 1; for
+    world > 1 the ranks' rows are not adjacent in the packed buffer, so this form copies (cold paths only:
+    the per-step exchange uses PackedGather, whose views never copy)."""
+    spans, _ = _layout(meta)
+    out = []
+    for (off, nbytes), (shape, dtype) in zip(spans, meta):
+        v = buf[:, off:off + nbytes].view(dtype).view((world,) + tuple(shape))
+        if fold:
+            v = v.reshape((world * shape[0],) + tuple(shape[1:])) if len(shape) else v.reshape(world)
+        out.append(v)
     return tuple(out)
+
+
+class PackedGather:
+    """The per-step result exchange with every buffer allocated ONCE: a packed send buffer (16-byte aligned fields),
+    a [world, nbytes] receive buffer and per-field strided views of both.  post() snapshots the step's result tensors
+    into the send buffer (one copy kernel per field on the caller's stream; dtype conversions such as int64 -> int32
+    indices happen inside that copy) and issues ONE asynchronous all-gather; wait() makes the caller's stream wait
+    for it and returns the receive VIEWS, shape [world, *field shape] - nothing is re-allocated or copied per step.
+    At most one gather is in flight; post() waits for the previous one first (stream-ordered, no host sync), which
+    also orders the new collective behind every read of the previous step's views on the caller's stream."""
+
+    def __init__(self, like, dtypes=None, group=None):
+        self.group, self.world = group, dist.get_world_size(group)
+        dtypes = list(dtypes) if dtypes is not None else [t.dtype for t in like]
+        self.meta = [(tuple(t.shape), dt) for t, dt in zip(like, dtypes)]
+        spans, total = _layout(self.meta)
+        dev = like[0].device
+        self.nccl = dist.get_backend(group) == "nccl"
+        self.device = dev
+        self.send = torch.zeros(total, dtype=torch.uint8, device=dev)
+        self.send_views = [self.send[off:off + n].view(dt).view(shape) for (off, n), (shape, dt) in zip(spans, self.meta)]
+        if self.nccl:
+            self.recv = torch.empty((self.world, total), dtype=torch.uint8, device=dev)
+        else:                                                   # gloo (CPU tests; ranks sharing one GPU in tests): through the host
+            self.recv = torch.empty((self.world, total), dtype=torch.uint8)
+            self.hsend = torch.empty(total, dtype=torch.uint8)
+            self.parts = list(self.recv.unbind(0))              # row views of the receive buffer: gathered in place
+            self.dev_recv = torch.empty((self.world, total), dtype=torch.uint8, device=dev) if dev.type != "cpu" else None
+        self.views = unpack(self.recv if self.nccl or self.dev_recv is None else self.dev_recv, self.meta, self.world, fold=False)
+        self.nbytes = total
+        self.work = None
+
+    def post(self, tensors):
+        self.wait()
+        for v, t in zip(self.send_views, tensors):
+            v.copy_(t)
+        if self.nccl:
+            self.work = dist.all_gather_into_tensor(self.recv.view(-1), self.send, group=self.group, async_op=True)
+        else:
+            self.hsend.copy_(self.send)
+            self.work = dist.all_gather(self.parts, self.hsend, group=self.group, async_op=True)
+        return self
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+            if not self.nccl and self.dev_recv is not None:
+                self.dev_recv.copy_(self.recv)
+        return self.views
 
 
 class GatherHandle:

@@ -82,8 +82,9 @@ class FactorGraph:
             valid_j = valid_match_j.bool() & (Qj > self.cfg["Q_conf"])
             valid_i = valid_match_i.bool() & (Qi > self.cfg["Q_conf"])
             frac = torch.minimum(valid_j.float().mean(dim=(1, 2)), valid_i.float().mean(dim=(1, 2)))
-            hw = [int(v) for v in torch.as_tensor(shape_i[0]).reshape(-1)[:2]]
-            frac = frac * matching.match_fraction_scale(hw[0], hw[1])                    # fractions of the seeds with use_fast_nn
+            if matching.use_fast_nn_enabled():                                           # fractions of the SEEDS with use_fast_nn;
+                hw = [int(v) for v in torch.as_tensor(shape_i[0]).reshape(-1)[:2]]       # the dense matchers (default) never read
+                frac = frac * matching.match_fraction_scale(hw[0], hw[1])                # the shape tensor: no host sync per batch
             outs.append((idx_i2j, idx_j2i, valid_match_j.bool(), valid_match_i.bool(), Qj, Qi, frac))
         if outs:
             idx_i2j, idx_j2i, vmj, vmi, Qj, Qi, frac = (torch.cat([o[n] for o in outs]) for n in range(7))

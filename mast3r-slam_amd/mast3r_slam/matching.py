@@ -154,10 +154,13 @@ def _seed_patch_order(hs: int, ws: int, dev) -> torch.Tensor:
     few blocks between them (m3_frnn_round_pruned's seed_order; results do not depend on it)."""
     key = (hs, ws, str(dev))
     if key not in _PATCH_ORDER:
-        iy, ix = torch.meshgrid(torch.arange(hs), torch.arange(ws), indexing="ij")
+        if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            # argsort allocates and the table is cached across calls: it must exist before a capture starts
+            raise RuntimeError("fast_reciprocal_nn_maps: call once eagerly (warm-up) for this map size before capturing it into a graph")
+        iy, ix = torch.meshgrid(torch.arange(hs, device=dev), torch.arange(ws, device=dev), indexing="ij")    # no host -> device copy
         iy, ix = iy.reshape(-1), ix.reshape(-1)
         k = ((iy // 8) * ((ws + 7) // 8) + ix // 8) * 64 + (((iy % 8) // 4) * 2 + (ix % 8) // 4) * 16 + (iy % 4) * 4 + ix % 4
-        _PATCH_ORDER[key] = torch.argsort(k, stable=True).to(torch.int32).to(dev)
+        _PATCH_ORDER[key] = torch.argsort(k, stable=True).to(torch.int32)
     return _PATCH_ORDER[key]
 
 
@@ -235,6 +238,10 @@ def fast_reciprocal_nn_maps(D1: torch.Tensor, D2: torch.Tensor, subsample: int =
     if tracker_maps:
         out["idx"], out["valid"] = idx, valid.view(torch.bool)[:, :, None]
     return out
+
+
+def use_fast_nn_enabled() -> bool:
+    return bool(get_config().get("matching", {}).get("use_fast_nn", False))
 
 
 def match_fraction_scale(h: int, w: int) -> float:

@@ -242,7 +242,12 @@ def conv3x3_grouped2(x, w0, w1, b0, b1, epi: int = EPI_BF16, stride: int = 1, re
     return out
 
 
-DIRECT_CONV_MIN_WGS = 256      # direct convolution once its grid fills the chip (one workgroup per CU); same bits either way
+DIRECT_CONV_MIN_WGS = None     # direct convolution once its grid fills the chip (one workgroup per CU); same bits either way.
+                               # None: the device's CU count (m3_device_cu_count, 256 on an MI355X); an int overrides it
+
+
+def _direct_conv_min_wgs() -> int:
+    return int(DIRECT_CONV_MIN_WGS) if DIRECT_CONV_MIN_WGS is not None else int(_ffi.lib().m3_device_cu_count())
 
 
 def conv3x3_direct_ok(x, cout: int, stride: int = 1) -> bool:
@@ -253,7 +258,7 @@ def conv3x3_direct_ok(x, cout: int, stride: int = 1) -> bool:
         return False
     if int(_ffi.lib().m3_conv3x3_splitk_bytes(1, h, w, cin, cout, 1)) > 0:
         return False        # a geometry the implicit-GEMM form runs as split-K (partial planes: another summation order)
-    return (h // 16) * ((w + 31) // 32) * b * (cout // 128) * g >= DIRECT_CONV_MIN_WGS
+    return (h // 16) * ((w + 31) // 32) * b * (cout // 128) * g >= _direct_conv_min_wgs()
 
 
 def _conv3x3_direct(x, w0, w1, b0, b1, epi, resid, relu_input):

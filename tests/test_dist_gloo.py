@@ -39,6 +39,21 @@ def _worker(rank, world, port, q):
             ok &= torch.equal(out[0][sl], Xr) and torch.equal(out[1][sl], ir)
             ok &= torch.equal(out[2][sl], vr) and torch.equal(out[3][sl], pr)
         ok &= out[1].dtype == torch.int64 and out[2].dtype == torch.bool and out[0].shape == (world * p, 4, 6, 3)
+        # the per-step exchange of bench.py: buffers allocated once, index narrowed to int32 inside its copy, results as
+        # strided views [world, ...] of ONE receive buffer; two steps through the same object
+        X = torch.randn(p, 4, 6, 3, generator=torch.Generator().manual_seed(100 + rank))
+        pg = m3dist.PackedGather((X, idx, valid, pose), dtypes=[torch.float32, torch.int32, torch.bool, torch.float32])
+        base = pg.recv.data_ptr()
+        for step in range(2):
+            v = pg.post((X + step, idx, valid, pose)).wait()
+            ok &= all(t.data_ptr() >= base and t.data_ptr() < base + pg.recv.numel() for t in v)       # views, not copies
+            ok &= v[0].shape == (world, p, 4, 6, 3) and v[1].dtype == torch.int32 and pg.recv.data_ptr() == base
+            for r in range(world):
+                gr = torch.Generator().manual_seed(100 + r)
+                Xr = torch.randn(p, 4, 6, 3, generator=gr); ir = torch.randint(0, 24, (p, 24), generator=gr)
+                vr = torch.rand(p, 24, 1, generator=gr) > 0.5; pr = torch.randn(p, 8, generator=gr)
+                ok &= torch.equal(v[0][r], Xr + step) and torch.equal(v[1][r], ir.to(torch.int32))
+                ok &= torch.equal(v[2][r], vr) and torch.equal(v[3][r], pr)
         q.put((rank, ok, pairs))
     finally:
         dist.destroy_process_group()
@@ -73,6 +88,11 @@ def test_pack_unpack_roundtrip_single_rank():
     assert buf.numel() % 16 == 0
     out = m3dist.unpack(buf[None], meta, 1)
     assert all(torch.equal(a, b) for a, b in zip(ts, out))
+    assert all(o.data_ptr() >= buf.data_ptr() for o in out)                      # one rank: views of the buffer
+    two = torch.stack([buf, buf])
+    views = m3dist.unpack(two, meta, 2, fold=False)                              # rank axis kept: strided views, no copy
+    assert all(v.shape == (2,) + tuple(t.shape) and torch.equal(v[1], t) for v, t in zip(views, ts))
+    assert all(two.data_ptr() <= v.data_ptr() < two.data_ptr() + two.numel() for v in views)
 
 
 def _worker_edges(rank, world, port, q):

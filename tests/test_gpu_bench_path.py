@@ -1,5 +1,5 @@
 """The code the driver launches: bench.py end to end on one GPU, including the N > 1 branch of its step
-(graph replays + packed snapshot + asynchronous RCCL all-gather + `pending` hand-over) under a ONE-rank RCCL
+(graph replays + packed snapshot + asynchronous RCCL all-gather + hand-over of the receive views) under a ONE-rank RCCL
 process group - the builder has one GPU at a time, so this is the only way that branch executes before the
 driver's 8-GPU run.  Runs in a child process (its own process group, its own HIP context)."""
 import json
@@ -28,6 +28,8 @@ def _run(extra):
 def test_bench_step_with_rccl_gather_one_rank():
     res = _run(["--force-dist"])
     assert res["n_gpus"] == 1 and res["value"] > 0 and "RCCL all-gather" in res["config"]["launch"]
+    ex = res["exchange"]                     # the pre-allocated packed exchange returned this rank's own results (views, no copies)
+    assert ex["own_row_equals_local_results"] and ex["fields"] == 7 and ex["gathered_shapes"][0][:2] == [1, 1]
     assert res["match_valid_frac"] > 0.5 and res["valid_frac"] > 0.5          # the legs ran on accepted points
     assert res["gn_pose_max_abs_err_vs_true_sim3"] < 5e-3                      # ... and the solve found the scene's Sim(3)
     s = res["stage_ms"]

@@ -395,7 +395,11 @@ int m3_launch_gemm256_conv(const GemmArgs &a, int epi, hipStream_t st);
 // Large dense tiles go to the ping-pong kernel.  (A one-wave-per-SIMD 256x256 variant with AGPR accumulators was built
 // and measured in round 2 - bit-identical, 20-80 % slower: tools/experiments/gemm4w.hip, DESIGN.md section 3.  Round 3: a
 // 256x128x32 tile with TWO independent workgroups per CU, meant to run one tile's epilogue under the other's K loop -
-// bit-identical, 13-34 % slower: tools/experiments/gemm_dual.hip)
+// bit-identical, 13-34 % slower: tools/experiments/gemm_dual.hip, DESIGN.md section 10.  Round 5: the same idea with the
+// ping-pong alternation kept INSIDE each of two 8-wave workgroups (256x128x64, 128 registers, 80 KiB of LDS each) -
+// bit-identical, within -4 ... +9 % of k_gemm256, and every forced stagger of the two workgroups slower: the K loop is bound
+// by the L2 -> LDS operand feed, which a 256x128 tile loads 1.5x harder: tools/experiments/gemm_duo.hip,
+// profiles/r05_gemm_duo_experiment.md.)
 static int launch_dense_big(const GemmArgs &a, int epi, int tile, hipStream_t st) {
     return m3_launch_gemm256_dense(a, epi, tile, st);
 }

@@ -13,6 +13,9 @@
 //     32 MFMAs the other one issues its LDS reads / global loads.  Each group has its own
 //     straight-line loop (register liveness stays per phase); both execute the same barrier count.
 // LDS image, swizzle, swapped-operand accumulator layout and epilogues are those of gemm.hip.
+// (Round 5, measured and not kept: every global_load_lds issued in an MFMA phase of its wave - ping all eight in phase 1, pong
+// four each in phases 0 and 2 - so that the READ phases carry fragment reads only: bit-identical, 3-5 % slower on every encoder
+// shape, profiles/r05_gemm_duo_experiment.md.)
 #include "gemm_common.h"
 
 using namespace m3gemm;

@@ -295,7 +295,12 @@ __device__ __forceinline__ void rope_strip(const GemmArgs &g, f32x4 *t, int m, i
 // Bias / activation / RoPE are applied in the accumulator layout before the transpose, residuals
 // (fp32 accumulate, bf16 add) on the row-contiguous side.  Falls back to store_tile when the
 // output is not 16-byte aligned.
-template <int EPI, int NI, int NJ = 4, int DT = DT_BF16>
+// TPMAX / RESID_AHEAD trade registers for latency hiding (k_gemm_duo lives on 128 registers and has a second
+// workgroup on the CU to cover the epilogue's round trips): TPMAX caps the accumulator row tiles per pass of the
+// 16-bit path (RoPE keeps TP x NJ/2 coefficient sets live), RESID_AHEAD = false loads a pass's residual tile in the
+// pass itself instead of one pass ahead (one register set instead of two).
+// ALIGNED = true: the host has checked the alignment conditions below, the element-wise fallback is not compiled in.
+template <int EPI, int NI, int NJ = 4, int DT = DT_BF16, int TPMAX = 4, bool RESID_AHEAD = true, bool ALIGNED = false>
 __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI][NJ], unsigned char *wlds,
                                               int m_base, int n_base, int lane) {
     constexpr bool F32OUT = (EPI == EPI_F32 || EPI == EPI_F32_ACCUM);
@@ -304,7 +309,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
     const bool aligned = ((reinterpret_cast<size_t>(g.C) & 15) == 0) && (g.ldc % (F32OUT ? 4 : 8) == 0) &&
                          (F32OUT || g.N % 8 == 0) &&
                          (!(EPI == EPI_F32_ACCUM || EPI == EPI_BF16_ADD) || (reinterpret_cast<size_t>(g.R) & 15) == 0);
-    if (!aligned) {
+    if (!ALIGNED && !aligned) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             if (EPI == EPI_BF16_ROPE) rope_strip<NJ>(g, acc[i], m_base + i * 16 + r, n_base, lane);
@@ -334,7 +339,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
         // Residual tile of a pass: read row-contiguous, 16 B per lane, from CLAMPED addresses with no branch
         // around the loads, and one pass AHEAD of its use - the first version loaded each chunk inside the
         // bounds test, i.e. one exposed L2/HBM round trip per chunk (32 per wave): 18.6 us of a 52 us launch.
-        uint4 q[2][RESID ? NIT : 1];
+        uint4 q[RESID_AHEAD ? 2 : 1][RESID ? NIT : 1];
         auto load_resid = [&](int pass, uint4 (&dst)[RESID ? NIT : 1]) {
             if constexpr (RESID) {
 #pragma unroll
@@ -349,10 +354,11 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
                 }
             }
         };
-        load_resid(0, q[0]);
+        if (RESID_AHEAD) load_resid(0, q[0]);
 #pragma unroll
         for (int pass = 0; pass < NI / PT; ++pass) {
-            if (pass + 1 < NI / PT) load_resid(pass + 1, q[(pass + 1) & 1]);
+            if (RESID_AHEAD) { if (pass + 1 < NI / PT) load_resid(pass + 1, q[(pass + 1) & (RESID_AHEAD ? 1 : 0)]); }
+            else load_resid(pass, q[0]);
 #pragma unroll
             for (int ii = 0; ii < PT; ++ii)
 #pragma unroll
@@ -369,7 +375,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
                     float4 v = *reinterpret_cast<const float4 *>(wlds + rl * RS + ((SWZ32 ? (ch ^ (rl & 7)) : ch) << 4));
                     const int m = m_base + pass * PR + rl, n = n_base + ch * 4;
                     if (EPI == EPI_F32_ACCUM) {
-                        const uint4 u = q[pass & 1][it];
+                        const uint4 u = q[RESID_AHEAD ? (pass & 1) : 0][it];
                         v.x += __uint_as_float(u.x); v.y += __uint_as_float(u.y); v.z += __uint_as_float(u.z); v.w += __uint_as_float(u.w);
                     }
                     if (m < g.M && n < g.N)
@@ -382,7 +388,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
                     const float4 a = *reinterpret_cast<const float4 *>(wlds + rl * RS + ch * 32);
                     const float4 b = *reinterpret_cast<const float4 *>(wlds + rl * RS + ch * 32 + 16);
                     const int m = m_base + pass * PR + rl, n = n_base + ch * 8;
-                    const uint4 u = q[pass & 1][it];
+                    const uint4 u = q[RESID_AHEAD ? (pass & 1) : 0][it];
                     uint4 o;
                     o.x = pack16<DT>(a.x + lo16<DT>(u.x), a.y + hi16<DT>(u.x));
                     o.y = pack16<DT>(a.z + lo16<DT>(u.y), a.w + hi16<DT>(u.y));
@@ -407,7 +413,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
         // 256 x 256 tile (profiles/r03_gemm_pmc.md).  Other widths keep the padded rows.
         constexpr bool SWZ = (NJ == 4);
         constexpr int RS = SWZ ? 128 : NJ * 32 + 16;              // 16*NJ 16-bit values (+ 16 bytes of padding)
-        constexpr int TP = NI < 4 ? NI : 4;                       // accumulator row tiles per pass
+        constexpr int TP = NI < TPMAX ? NI : TPMAX;               // accumulator row tiles per pass (TPMAX: register budget)
         constexpr int PR = 16 * TP, CPR = NJ * 2;                 // rows per pass, 16-byte chunks (8 columns) per row
         RopeFreq fr{};
         if constexpr (EPI == EPI_BF16_ROPE) { if (g.rope_pos) fr = rope_freqs(g, lane); }

@@ -99,6 +99,42 @@ int m3_gemm_grouped2_dt(const void *A, const void *W0, const void *W1, const flo
                         int64_t a_gstride, int64_t c_gstride, int epilogue, const float *rope_tok,
                         int tokens_per_image, int rope_cols, int q_cols, float q_scale, int dtype, void *stream);
 
+/* General dense GEMM entry (one or two groups, any epilogue, position-mode RoPE) with the LayerNorm FOLD: the reference's
+ * network applies LayerNorm between every residual update and the projection that follows (public MASt3R / CroCo block:
+ * x + proj(attn(norm1(x))), x + fc2(gelu(fc1(norm2(x))))).  Instead of a LayerNorm pass over the fp32 stream (read 4 B,
+ * write 2 B per element, one launch per norm) the two GEMMs around it share the work:
+ *   producer (epilogue M3_EPI_F32 / M3_EPI_F32_ACCUM, c16 / stats_out set): besides the fp32 stream x' it writes c16 = x'
+ *     rounded to the launch's 16-bit type (same ldc) and, per row and 32-column slot, (sum x', sum x'^2) of the fp32 values
+ *     into stats_out [N/32][M][2] (slot-major: a tile's rows are contiguous within a slot; N % 32 == 0, M even);
+ *   consumer (16-bit epilogues, ln_stats set): A is such a copy of the RAW stream, W = gamma-scaled weights, ln_colsum[n] =
+ *     sum_k W[n][k] of the ROUNDED 16-bit weights, bias = b + W . beta; with mean / rstd of row m from ln_stats
+ *     [ln_slots][M][2] (ln_slots = K / 32, a multiple of 4) the epilogue computes rstd[m] * (acc - mean[m] * ln_colsum[n])
+ *     + bias[n] = LayerNorm(x')[m] . W_orig[n]^T + b[n] up to the rounding of x' (instead of LayerNorm(x')) to 16 bits.
+ * Every kernel adds a row's slots in the same order, so the statistics - like the products - do not depend on the tile
+ * shape a launch is dispatched to.  Group 1 of a 2-group launch reads ln_stats + ln_gstride (floats; may be negative: the
+ * decoder's cross-attention memory is the OTHER branch's stream) and writes stats_out + stats_gstride, c16 + c_gstride.
+ * Fields not used by a launch are 0 / NULL.  rope_pos != NULL selects M3_EPI_BF16_ROPE's position mode. */
+typedef struct m3_gemm_desc {
+    const void *A, *W, *W1;            /* W1: group 1's weights (groups == 2) */
+    const float *bias, *bias1;
+    void *C;
+    const void *R;
+    const int32_t *rope_pos;
+    void *c16;
+    float *stats_out;
+    const float *ln_stats, *ln_colsum, *ln_colsum1;
+    const void *r_lo;                  /* hi / lo stream (fp16 launches, producer): the residual stream lives in two 16-bit planes, */
+    void *c_lo;                        /* x = hi + lo (hi = x rounded to fp16, lo = the rounded remainder: 22 bits).  R = hi in,     */
+                                       /* r_lo = lo in, c16 = hi out, c_lo = lo out (in place allowed); C is NULL and not written.   */
+                                       /* The hi plane IS the consumer's operand: the residual launch moves 4 + 4 bytes per element  */
+                                       /* as with an fp32 stream, and neither a LayerNorm pass nor a 16-bit copy exists.             */
+    int64_t a_gstride, c_gstride, ln_gstride, stats_gstride;
+    int32_t M, N, K, ldc, epilogue, dtype, groups;
+    int32_t tokens_per_image, rope_cols, q_cols, ln_slots;
+    float rope_base, q_scale, ln_eps;
+} m3_gemm_desc;
+int m3_gemm_ex(const m3_gemm_desc *desc, void *stream);
+
 /* 3x3 convolution, padding 1, stride 1 or 2, as an implicit GEMM: X bf16 NHWC [B,H,W,Cin],
  * W bf16 [Cout,3,3,Cin], Y NHWC [B,OH,OW,Cout].  Cin % 64 == 0, Cout % 4 == 0.  zero16: 16
  * zero bytes in device memory (source of the padding taps). */

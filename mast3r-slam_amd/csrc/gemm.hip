@@ -28,12 +28,20 @@ namespace {
 constexpr int BM = 128, BN = 128;                         // default tile; T = 64 gives 64x64 tiles (latency regime)
 constexpr int kThreads = 256;
 
+#ifndef M3_GEMM64_STAGES
+#define M3_GEMM64_STAGES 2        // 4: three K-tiles in flight - measured at one pair per step: 21.9 vs 21.7 us per launch, no gain (the 64 x 64 tile is bound by LDS-DMA ISSUE, 4 pieces per 8 MFMAs and wave, not by load latency)
+#endif
+constexpr int k_gemm_stages(int T) { return T == 64 ? M3_GEMM64_STAGES : 2; }
+
 template <int MODE /*0 dense, 1 conv3x3*/, int EPI, int T, int DT, bool SLICED = false>
 __global__ void __launch_bounds__(kThreads)
 k_gemm(const GemmArgs gin) {
     constexpr int BM = T, BN = T;
     constexpr int NT = T / 32;                               // MFMA tiles per wave and direction; 32-row load issues
     constexpr int kStageBytes = (BM + BN) * BK * 2;          // 32 KiB (16 KiB)
+    // LDS stages (the loop below takes any power of two): two.  Four for T = 64 (three K-tiles in flight) were measured in
+    // round 5 at one pair per step - no change, see M3_GEMM64_STAGES
+    constexpr int STAGES = k_gemm_stages(T);
     GemmArgs g = select_group<EPI>(gin, blockIdx.y);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -125,15 +133,31 @@ k_gemm(const GemmArgs gin) {
     const int slices = CAN_SLICE ? g.slices : 1;
     int slice = 0, slice_end = slices > 1 ? (int)((long long)nk * 1 / slices) : nk;
 
-    stage(0, 0);
+#pragma unroll
+    for (int t0 = 0; t0 < STAGES - 1; ++t0)
+        if (t0 < nk) stage(t0, t0);
+    // LayerNorm fold (kernel-uniform): two threads per row fetch the row's mean / rstd now - under the first loads - and carry
+    // them through the K loop in two registers; the table is written behind the waves' epilogue scratch after the loop
+    float2 ln_mr = make_float2(0.f, 0.f);
+    if (MODE == 0 && g.ln_stats) ln_mr = ln_row_stats<BM>(g, m0, tid);
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
-        // wait for tile kt only (the 2*NT loads of tile kt+1 may stay in flight)
-        if (kt + 1 < nk) {
-            if constexpr (NT == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int buf = kt & (STAGES - 1);
+        // refill the stage the previous iteration finished with (its trailing barrier orders the fragment reads before this)
+        if (kt + STAGES - 1 < nk) stage(kt + STAGES - 1, (kt + STAGES - 1) & (STAGES - 1));
+        // wait for tile kt only: the 2*NT loads of each of the up to STAGES - 1 younger tiles may stay in flight
+        const int ahead = nk - 1 - kt < STAGES - 1 ? nk - 1 - kt : STAGES - 1;
+        if constexpr (STAGES == 2) {
+            if (ahead) {
+                if constexpr (NT == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            static_assert(STAGES == 2 || (STAGES == 4 && NT == 2), "vmcnt immediates below are for 4 loads per tile");
+            if (ahead == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         lds_barrier();                          // every wave's loads of tile kt have landed
         const unsigned char *As = lds + buf * kStageBytes;
         const unsigned char *Ws = As + BM * BK * 2;
@@ -247,14 +271,21 @@ k_gemm(const GemmArgs gin) {
             }
         }
     } else {
+        float2 *lnt = nullptr;
+        if (MODE == 0 && g.ln_stats) {                       // the stages are dead after the loop's last barrier
+            lnt = reinterpret_cast<float2 *>(lds + 4 * (NT == 4 ? 9216 : 4608));
+            if (tid < 2 * BM && (tid & 1) == 0) lnt[tid >> 1] = ln_mr;
+            __syncthreads();
+        }
         // ---- epilogue: row-contiguous stores through a per-wave LDS scratch (gemm_common.h) --------
-        epilogue_rows<EPI, NT, NT, DT>(g, acc, lds + wave * (NT == 4 ? 9216 : 4608), m0 + wr * (T / 2), n0 + wc * (T / 2), lane);
+        epilogue_rows<EPI, NT, NT, DT>(g, acc, lds + wave * (NT == 4 ? 9216 : 4608), m0 + wr * (T / 2), n0 + wc * (T / 2), lane, lnt,
+                                       wr * (T / 2));
     }
 }
 
 template <int MODE, int T, int DT>
 int launch_dt(const GemmArgs &a, int epi, hipStream_t st) {
-    constexpr int kLdsBytes = 2 * (2 * T) * BK * 2;      // 64 KiB (32 KiB)
+    constexpr int kLdsBytes = k_gemm_stages(T) * (2 * T) * BK * 2;      // 64 KiB (T = 128: 2 stages; T = 64: 4 stages)
     const int tiles = m3_cdiv(a.M, T) * m3_cdiv(a.N, T);
     dim3 grid(tiles, a.groups > 1 ? a.groups : 1, a.splits > 1 ? a.splits : 1), blk(kThreads);
 #define M3_L(E) case E: hipLaunchKernelGGL((k_gemm<MODE, E, T, DT>), grid, blk, kLdsBytes, st, a); break
@@ -521,6 +552,56 @@ int m3_gemm_bf16_grouped2(const void *A, const void *W0, const void *W1, const f
                           int tokens_per_image, int rope_cols, void *stream) {
     return m3_gemm_grouped2_dt(A, W0, W1, bias0, bias1, C, R, M, N, K, ldc, a_gstride, c_gstride, epilogue, rope_tok,
                                tokens_per_image, rope_cols, 0, 1.0f, DT_BF16, stream);
+}
+
+int m3_gemm_ex(const m3_gemm_desc *d, void *stream) {
+    M3_REQUIRE(d && d->A && d->W && (d->C || d->c_lo) && d->M > 0 && d->N > 0 && d->K > 0);
+    const int epi = d->epilogue, groups = d->groups > 1 ? 2 : 1;
+    const bool rope = epi == EPI_BF16_ROPE;
+    M3_REQUIRE(rope ? dt_ok_rope(d->dtype) : dt_ok(d->dtype));
+    M3_REQUIRE(d->K % BK == 0 && d->N % 4 == 0 && d->ldc >= d->N && d->ldc % 4 == 0);
+    M3_REQUIRE(!((epi == EPI_F32_ACCUM || epi == EPI_BF16_ADD) && !d->R));
+    M3_REQUIRE(epi >= EPI_BF16 && epi <= EPI_BF16_ROPE);
+    if (d->c_lo)                            // hi / lo stream: fp16 planes through the row-contiguous fp32 epilogue
+        M3_REQUIRE((epi == EPI_F32 || epi == EPI_F32_ACCUM) && d->dtype == DT_F16 && d->c16 && !d->C && d->N % 8 == 0 && d->ldc % 8 == 0 &&
+                   d->M % 2 == 0 && (reinterpret_cast<size_t>(d->c_lo) & 15) == 0 && (reinterpret_cast<size_t>(d->c16) & 15) == 0 &&
+                   (epi == EPI_F32 || (d->r_lo && (reinterpret_cast<size_t>(d->R) & 15) == 0 && (reinterpret_cast<size_t>(d->r_lo) & 15) == 0)));
+    if (groups == 2) M3_REQUIRE(d->W1 && (d->bias == nullptr) == (d->bias1 == nullptr));
+    if (rope)
+        M3_REQUIRE(d->rope_pos && d->tokens_per_image > 0 && d->rope_base > 1.0f && d->N % 64 == 0 && d->rope_cols % 64 == 0 &&
+                   d->rope_cols <= d->N && d->q_cols >= 0 && d->q_cols <= d->rope_cols && d->q_cols % 64 == 0);
+    const bool f32out = epi == EPI_F32 || epi == EPI_F32_ACCUM;
+    if (d->c16 || d->stats_out) {          // LayerNorm fold, producer: the row-contiguous epilogue must be the one that runs
+        M3_REQUIRE(f32out && (d->N % 32 == 0 || !d->stats_out) && d->M % 2 == 0 && d->ldc % 8 == 0 && (reinterpret_cast<size_t>(d->C) & 15) == 0 &&
+                   (!d->R || (reinterpret_cast<size_t>(d->R) & 15) == 0) &&
+                   (!d->c16 || (reinterpret_cast<size_t>(d->c16) & 15) == 0) &&
+                   (!d->stats_out || (reinterpret_cast<size_t>(d->stats_out) & 15) == 0));
+        if (groups == 2) M3_REQUIRE(d->c_gstride % 8 == 0 && d->stats_gstride % 4 == 0);
+    }
+    if (d->ln_stats) {                     // LayerNorm fold, consumer
+        M3_REQUIRE(!f32out && epi != EPI_BF16_ADD && d->ln_colsum && d->ln_slots * 32 == d->K && d->ln_slots % 4 == 0 &&
+                   d->ln_eps > 0.0f && (reinterpret_cast<size_t>(d->ln_stats) & 7) == 0 &&
+                   (reinterpret_cast<size_t>(d->ln_colsum) & 15) == 0 && (reinterpret_cast<size_t>(d->C) & 15) == 0 &&
+                   d->ldc % 8 == 0 && d->N % 8 == 0);
+        if (groups == 2) M3_REQUIRE(d->ln_colsum1 && (reinterpret_cast<size_t>(d->ln_colsum1) & 15) == 0 && d->ln_gstride % 2 == 0);
+    }
+    GemmArgs a{};
+    a.A = (const bf16_t *)d->A; a.W = (const bf16_t *)d->W; a.W2 = (const bf16_t *)d->W1; a.bias = d->bias; a.bias2 = d->bias1;
+    a.C = d->C; a.R = d->R; a.M = d->M; a.N = d->N; a.K = d->K; a.ldc = d->ldc;
+    if (rope) set_dt(a, d->dtype); else a.dt = d->dtype;
+    a.a_gstride = d->a_gstride; a.c_gstride = d->c_gstride; a.groups = groups == 2 ? 2 : 0;
+    if (rope) {
+        a.rope_pos = d->rope_pos; a.rope_log2_base = log2f(d->rope_base); a.tokens_per_image = d->tokens_per_image;
+        a.rope_cols = d->rope_cols; a.q_cols = d->q_cols; a.q_scale = d->q_scale;
+    }
+    a.C16 = d->c16; a.stats_out = d->stats_out; a.stats_gstride = d->stats_gstride;
+    a.R_lo = d->r_lo; a.C_lo = d->c_lo;
+    a.ln_stats = d->ln_stats; a.ln_colsum = d->ln_colsum; a.ln_colsum2 = d->ln_colsum1; a.ln_slots = d->ln_slots;
+    a.ln_eps = d->ln_eps; a.ln_gstride = d->ln_gstride;
+    const int tile = pick_tile(d->M, d->N, groups);
+    if (tile >= 192) return launch_dense_big(a, epi, tile, (hipStream_t)stream);
+    if (tile == 64) return launch<0, 64>(a, epi, (hipStream_t)stream);
+    return launch<0>(a, epi, (hipStream_t)stream);
 }
 
 int64_t m3_conv3x3_splitk_bytes(int B, int H, int Wd, int Cin, int Cout, int stride) {

@@ -166,8 +166,14 @@ k_gemm256(const GemmArgs gin) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // prologue: tile 0 into stage 0, visible to everyone
+    // prologue: tile 0 into stage 0, visible to everyone; LayerNorm fold: the rows' mean / rstd table goes into the 2 KiB
+    // behind the stages while those first loads fly (dense launches only)
     stage(0, 0);
+    float2 *lnt = nullptr;
+    if (MODE == 0 && g.ln_stats) {                           // kernel-uniform
+        lnt = reinterpret_cast<float2 *>(lds + 2 * kStageBytes);
+        ln_row_table<BM>(g, lnt, m0, tid);
+    }
     phase_end_wait();
 
     if (group == 0) {
@@ -209,12 +215,13 @@ k_gemm256(const GemmArgs gin) {
 
     // epilogue: the operand stages are dead after the last barrier; each wave transposes its sub-tile
     // through a private LDS scratch (9 / 13 KiB) and stores full rows (gemm_common.h)
-    epilogue_rows<EPI, NI, NJ, DT>(g, acc, lds + wave * (64 * (32 * NJ + 16)), m0 + wr * (16 * NI), n0 + wc * (16 * NJ), lane);
+    epilogue_rows<EPI, NI, NJ, DT>(g, acc, lds + wave * (64 * (32 * NJ + 16)), m0 + wr * (16 * NI), n0 + wc * (16 * NJ), lane, lnt,
+                                   wr * (16 * NI));
 }
 
 template <int MODE, int BN, int DT>
 int launch256(const GemmArgs &a, int epi, hipStream_t st) {
-    constexpr int kLdsBytes = 2 * (BM + BN) * BK * 2;    // 128 KiB / 112 KiB
+    constexpr int kLdsBytes = 2 * (BM + BN) * BK * 2 + BM * 8;    // 128 KiB / 112 KiB of stages + the LayerNorm-fold row table
     const int tiles = m3_cdiv(a.M, BM) * m3_cdiv(a.N, BN);
     dim3 grid(tiles, a.groups > 1 ? a.groups : 1), blk(kThreads);
 #define M3_L(E)                                                                                              \

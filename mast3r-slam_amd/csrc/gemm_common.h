@@ -134,6 +134,25 @@ struct GemmArgs {
                             //   relu(x) -> conv1 without materialising relu(x)  (M3_EPI_INPUT_RELU)
     int v_bf16;             // EPI_BF16_ROPE in a DT_F16 launch: the columns >= rope_cols (v of a q|k|v or k|v projection) are
                             //   stored as bf16 - the operand type of the fast attention loop's P.V product (M3_DT_F16_PVBF16)
+    // ---- LayerNorm folded into the GEMMs on both sides of it (m3_gemm_ex; fp16 trunk) ----
+    // producer (EPI_F32 / EPI_F32_ACCUM): besides the fp32 stream x' the launch writes C16 = x' rounded to the launch's 16-bit
+    // type (same ldc) and, per row and 32-column slot, (sum x', sum x'^2) into stats_out [M][N/32][2] - from the fp32 values
+    void *C16;
+    float *stats_out;
+    // hi / lo form of the stream (C_lo set; fp16 launches): the stream is kept as TWO 16-bit planes, x = hi + lo with hi = x
+    // rounded to fp16 and lo = the rounded remainder (22 significant bits; |x| < 65504).  hi IS the consumer's operand, so the
+    // residual launch moves 4 + 4 bytes per element as with an fp32 stream and no separate copy exists: R = hi in, R_lo = lo in,
+    // C16 = hi out, C_lo = lo out (in place allowed), C is not written.
+    const void *R_lo;
+    void *C_lo;
+    // consumer (16-bit epilogues): A is such a copy of the RAW stream and W carries gamma; the epilogue turns the product into
+    // the product with the normalised row: rstd[m] * (acc - mean[m] * ln_colsum[n]) (+ bias, which carries beta . W^T);
+    // mean / rstd of row m come from ln_stats [M][ln_slots][2], ln_slots = K / 32 (summed in ONE order by every kernel)
+    const float *ln_stats;
+    const float *ln_colsum, *ln_colsum2;       // [N] sums over k of the 16-bit weights (group 0 / group 1)
+    int ln_slots;
+    float ln_eps;
+    long long ln_gstride, stats_gstride;       // floats between group 0's and group 1's statistics (may be negative)
 };
 
 // Per-group view of the arguments (group 1 of a 2-group launch).
@@ -147,6 +166,14 @@ __device__ __forceinline__ GemmArgs select_group(const GemmArgs &in, int grp) {
         g.bias = in.bias2;
         g.C = reinterpret_cast<unsigned char *>(in.C) + in.c_gstride * esz;
         if (in.R) g.R = reinterpret_cast<const unsigned char *>(in.R) + in.c_gstride * esz;
+        if (in.C16) g.C16 = reinterpret_cast<unsigned char *>(in.C16) + in.c_gstride * 2;
+        if (in.C_lo) {                                          // hi / lo stream: 16-bit planes, C / R are not fp32 tensors
+            g.C_lo = reinterpret_cast<unsigned char *>(in.C_lo) + in.c_gstride * 2;
+            if (in.R) g.R = reinterpret_cast<const unsigned char *>(in.R) + in.c_gstride * 2;
+            if (in.R_lo) g.R_lo = reinterpret_cast<const unsigned char *>(in.R_lo) + in.c_gstride * 2;
+        }
+        if (in.stats_out) g.stats_out = in.stats_out + in.stats_gstride;
+        if (in.ln_stats) { g.ln_stats = in.ln_stats + in.ln_gstride; g.ln_colsum = in.ln_colsum2; }
     }
     return g;
 }
@@ -280,6 +307,53 @@ __device__ __forceinline__ void rope_strip(const GemmArgs &g, f32x4 *t, int m, i
     rope_apply<NJ>(g, t, cf, bj, n_base);
 }
 
+// Sum over the aligned group of 8 lanes a lane belongs to, result in every lane, on the DPP path (three v_add_f32 with a lane
+// permutation; __shfl_xor compiles to ds_bpermute - an LDS round trip per step).  xor 1, xor 2 inside the quad, then the
+// half-row mirror (lane i <-> 7 - i) pairs the two quads: every lane adds the same two quad sums, so all 8 hold the same bits.
+__device__ __forceinline__ float dpp_sum8(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    return v;
+}
+// value of the lane's quad neighbour lane ^ 1
+__device__ __forceinline__ unsigned dpp_xor1(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+}
+
+// LayerNorm fold, consumer side: mean and 1 / sqrt(var + eps) of the tile's rows -> LDS table float2[ROWS] (written before the
+// kernel's first workgroup barrier, read in the epilogue).  Two threads per row: each adds half of the row's 32-column slots
+// in index order, then low + high - the one summation order of every kernel and tile shape, so a row's statistics do not
+// depend on which kernel multiplies it.  ln_slots is a multiple of 4 (host check); rows past M read the last row.
+template <int ROWS>
+__device__ __forceinline__ float2 ln_row_stats(const GemmArgs &g, int m0, int tid) {     // (mean, rstd) of row tid >> 1
+    if (tid >= 2 * ROWS) return make_float2(0.f, 0.f);
+    const int row = tid >> 1, half = tid & 1, hs = g.ln_slots >> 1;
+    int m = m0 + row;
+    m = m < g.M ? m : g.M - 1;
+    // statistics are stored slot-major, [ln_slots][M][2]: the rows of a tile are contiguous within a slot (coalesced on both sides)
+    const float2 *p = reinterpret_cast<const float2 *>(g.ln_stats) + (size_t)half * hs * g.M + m;
+    float s = 0.f, q = 0.f;
+    for (int i0 = 0; i0 < hs; i0 += 16) {                    // up to 16 loads in flight
+        float2 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = (i0 + i < hs) ? p[(size_t)(i0 + i) * g.M] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s += v[i].x; q += v[i].y; }
+    }
+    s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, true));
+    q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0xB1, 0xF, 0xF, true));
+    const float inv = 1.0f / (float)(g.ln_slots * 32);
+    const float mean = s * inv;
+    const float var = fmaxf(q * inv - mean * mean, 0.f);
+    return make_float2(mean, rsqrtf(var + g.ln_eps));
+}
+template <int ROWS>
+__device__ __forceinline__ void ln_row_table(const GemmArgs &g, float2 *tab, int m0, int tid) {
+    const float2 mr = ln_row_stats<ROWS>(g, m0, tid);
+    if (tid < 2 * ROWS && (tid & 1) == 0) tab[tid >> 1] = mr;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Row-contiguous epilogue through LDS.
 //
@@ -302,7 +376,7 @@ __device__ __forceinline__ void rope_strip(const GemmArgs &g, f32x4 *t, int m, i
 // ALIGNED = true: the host has checked the alignment conditions below, the element-wise fallback is not compiled in.
 template <int EPI, int NI, int NJ = 4, int DT = DT_BF16, int TPMAX = 4, bool RESID_AHEAD = true, bool ALIGNED = false>
 __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI][NJ], unsigned char *wlds,
-                                              int m_base, int n_base, int lane) {
+                                              int m_base, int n_base, int lane, const float2 *lnt = nullptr, int lrow = 0) {
     constexpr bool F32OUT = (EPI == EPI_F32 || EPI == EPI_F32_ACCUM);
     constexpr bool F32LDS = F32OUT || EPI == EPI_BF16_ADD;        // keep one rounding for the bf16 residual add
     const int r = lane & 15, gq = lane >> 4;
@@ -332,13 +406,16 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
         constexpr bool SWZ32 = F32OUT && (NJ == 4);
         constexpr int RS = SWZ32 ? 256 : NJ * 64 + 16;            // 16*NJ fp32 (+ 16 bytes of padding)
         constexpr bool RESID = (EPI == EPI_F32_ACCUM || EPI == EPI_BF16_ADD);
-        constexpr int PT = RESID ? 1 : 2;                         // accumulator row tiles per pass (residual tiles are
+        constexpr int PT = 1;      // ONE accumulator row tile per pass: the statistics staging below needs the room behind a 16-row
+                                   // transpose image inside the wave's scratch (two-tile passes of EPI_F32 overran it), and residual tiles are
         constexpr int PR = 16 * PT;                               // double-buffered in registers: keep a pass small)
         constexpr int CPR = F32OUT ? NJ * 4 : NJ * 2;             // 16-byte output chunks per row (4 fp32 / 8 x 16-bit columns)
         constexpr int NIT = PR * CPR / 64;
         // Residual tile of a pass: read row-contiguous, 16 B per lane, from CLAMPED addresses with no branch
         // around the loads, and one pass AHEAD of its use - the first version loaded each chunk inside the
         // bounds test, i.e. one exposed L2/HBM round trip per chunk (32 per wave): 18.6 us of a 52 us launch.
+        // LayerNorm-fold statistics of the sub-tile, staged behind the transpose scratch: [NJ / 2 slots][16 NI rows] float2
+        float2 *wst = reinterpret_cast<float2 *>(wlds + ((PR * RS + 15) & ~15));
         uint4 q[RESID_AHEAD ? 2 : 1][RESID ? NIT : 1];
         auto load_resid = [&](int pass, uint4 (&dst)[RESID ? NIT : 1]) {
             if constexpr (RESID) {
@@ -349,6 +426,11 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
                     m = m < g.M ? m : g.M - 1;
                     n = n < g.N ? n : 0;
                     const size_t off = (size_t)m * g.ldc + n;
+                    if (F32OUT && g.C_lo) {                         // kernel-uniform: hi / lo stream, 4 + 4 values of 16 bits
+                        const uint2 hi = *reinterpret_cast<const uint2 *>(reinterpret_cast<const bf16_t *>(g.R) + off);
+                        const uint2 lo = *reinterpret_cast<const uint2 *>(reinterpret_cast<const bf16_t *>(g.R_lo) + off);
+                        dst[it] = uint4{hi.x, hi.y, lo.x, lo.y};
+                    } else
                     dst[it] = F32OUT ? *reinterpret_cast<const uint4 *>(reinterpret_cast<const float *>(g.R) + off)
                                      : *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16_t *>(g.R) + off);
                 }
@@ -376,10 +458,40 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
                     const int m = m_base + pass * PR + rl, n = n_base + ch * 4;
                     if (EPI == EPI_F32_ACCUM) {
                         const uint4 u = q[RESID_AHEAD ? (pass & 1) : 0][it];
-                        v.x += __uint_as_float(u.x); v.y += __uint_as_float(u.y); v.z += __uint_as_float(u.z); v.w += __uint_as_float(u.w);
+                        if (g.C_lo) {                               // x = hi + lo is exact in fp32 (11 + 11 bits), then ONE rounding
+                            v.x += lo16<DT>(u.x) + lo16<DT>(u.z); v.y += hi16<DT>(u.x) + hi16<DT>(u.z);
+                            v.z += lo16<DT>(u.y) + lo16<DT>(u.w); v.w += hi16<DT>(u.y) + hi16<DT>(u.w);
+                        } else {
+                            v.x += __uint_as_float(u.x); v.y += __uint_as_float(u.y); v.z += __uint_as_float(u.z); v.w += __uint_as_float(u.w);
+                        }
                     }
+                    if (g.C_lo) {                                   // kernel-uniform: hi / lo planes instead of the fp32 tensor
+                        const unsigned h0 = pack16<DT>(v.x, v.y), h1 = pack16<DT>(v.z, v.w);
+                        const unsigned l0 = pack16<DT>(v.x - lo16<DT>(h0), v.y - hi16<DT>(h0));
+                        const unsigned l1 = pack16<DT>(v.z - lo16<DT>(h1), v.w - hi16<DT>(h1));
+                        const unsigned g0 = dpp_xor1(h0), g1 = dpp_xor1(h1), k0 = dpp_xor1(l0), k1 = dpp_xor1(l1);
+                        if (!(lane & 1) && m < g.M && n < g.N) {    // the even lane of a pair stores 8 columns of both planes
+                            *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(g.C16) + (size_t)m * g.ldc + n) = uint4{h0, h1, g0, g1};
+                            *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(g.C_lo) + (size_t)m * g.ldc + n) = uint4{l0, l1, k0, k1};
+                        }
+                    } else {
                     if (m < g.M && n < g.N)
                         *reinterpret_cast<float4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + n) = v;
+                    if (g.C16) {                                    // kernel-uniform: 16-bit copy of the stream (LayerNorm fold)
+                        // two neighbouring lanes hold 8 consecutive columns of a row: the even one stores all 16 bytes
+                        const unsigned p0 = pack16<DT>(v.x, v.y), p1 = pack16<DT>(v.z, v.w);
+                        const unsigned q0 = dpp_xor1(p0), q1 = dpp_xor1(p1);
+                        if (!(lane & 1) && m < g.M && n < g.N)
+                            *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(g.C16) + (size_t)m * g.ldc + n) = uint4{p0, p1, q0, q1};
+                    }
+                    }
+                    if (g.stats_out) {                              // kernel-uniform: (sum, sum of squares) per 32-column slot
+                        const bool live = m < g.M && n < g.N;
+                        const float s1 = dpp_sum8(live ? (v.x + v.y) + (v.z + v.w) : 0.f);
+                        const float s2 = dpp_sum8(live ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f);
+                        if ((ch & 7) == 0)                          // staged in the wave's scratch: [slot][row of the sub-tile]
+                            wst[(ch >> 3) * (16 * NI) + pass * PR + rl] = make_float2(s1, s2);
+                    }
                 }
             } else {                                              // EPI_BF16_ADD: 8 columns per lane
 #pragma unroll
@@ -400,6 +512,19 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
             }
             asm volatile("" ::: "memory");
         }
+        if (F32OUT && g.stats_out) {
+            // the sub-tile's statistics leave as runs of 16 NI rows x 8 B per slot (slot-major layout [N / 32][M][2]), 16 bytes
+            // = two rows per lane: M and the sub-tile's first row are even (host check), so a pair is inside or outside together
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            constexpr int ROWS = 16 * NI;
+#pragma unroll
+            for (int sl = 0; sl < NJ / 2; ++sl) {
+                const int n = n_base + sl * 32, m = m_base + 2 * lane;
+                if (2 * lane < ROWS && m < g.M && n < g.N)
+                    *reinterpret_cast<float4 *>(g.stats_out + ((size_t)(n >> 5) * g.M + m) * 2) =
+                        *reinterpret_cast<const float4 *>(wst + sl * ROWS + 2 * lane);
+            }
+        }
     } else {
         // 64-column sub-tiles (NJ = 4: 128-byte rows) use an UNPADDED scratch: the 16-byte chunk c of row r is stored at
         // chunk c ^ ((r >> 1) & 7), and odd rows store the two 8-byte halves of a chunk swapped.
@@ -417,6 +542,27 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
         constexpr int PR = 16 * TP, CPR = NJ * 2;                 // rows per pass, 16-byte chunks (8 columns) per row
         RopeFreq fr{};
         if constexpr (EPI == EPI_BF16_ROPE) { if (g.rope_pos) fr = rope_freqs(g, lane); }
+        if (lnt) {
+            // LayerNorm fold (kernel-uniform), before any bias: acc <- rstd[m] * (acc - mean[m] * colsum[n]).  Done for the whole
+            // sub-tile up front so that the column sums are dead before the RoPE coefficients of the passes become live (with
+            // both live the 128 x 128 kernel's RoPE instantiation lost its second workgroup per CU)
+            float4 csj[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = n_base + j * 16 + gq * 4;
+                csj[j] = n < g.N ? *reinterpret_cast<const float4 *>(g.ln_colsum + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const float2 mr = lnt[lrow + i * 16 + r];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    f32x4 &v = acc[i][j];
+                    v[0] = mr.y * (v[0] - mr.x * csj[j].x); v[1] = mr.y * (v[1] - mr.x * csj[j].y);
+                    v[2] = mr.y * (v[2] - mr.x * csj[j].z); v[3] = mr.y * (v[3] - mr.x * csj[j].w);
+                }
+            }
+        }
 #pragma unroll
         for (int pass = 0; pass < NI / TP; ++pass) {
             RopeCoef cf[EPI == EPI_BF16_ROPE ? TP : 1][NJ / 2];

@@ -75,6 +75,18 @@ def lib():
     return _lib
 
 
+class GemmDesc(C.Structure):
+    """m3_gemm_desc of include/m3slam_model.h (field order and types must match the header)."""
+    _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("W1", C.c_void_p), ("bias", C.c_void_p), ("bias1", C.c_void_p),
+                ("C", C.c_void_p), ("R", C.c_void_p), ("rope_pos", C.c_void_p), ("c16", C.c_void_p), ("stats_out", C.c_void_p),
+                ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_colsum1", C.c_void_p), ("r_lo", C.c_void_p), ("c_lo", C.c_void_p),
+                ("a_gstride", C.c_int64), ("c_gstride", C.c_int64), ("ln_gstride", C.c_int64), ("stats_gstride", C.c_int64),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("ldc", C.c_int32), ("epilogue", C.c_int32),
+                ("dtype", C.c_int32), ("groups", C.c_int32), ("tokens_per_image", C.c_int32), ("rope_cols", C.c_int32),
+                ("q_cols", C.c_int32), ("ln_slots", C.c_int32),
+                ("rope_base", C.c_float), ("q_scale", C.c_float), ("ln_eps", C.c_float)]
+
+
 def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 

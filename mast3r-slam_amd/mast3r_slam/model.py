@@ -251,6 +251,12 @@ class Mast3rFull:
         # needs bf16's exponent range for P, the logits need fp16's mantissa.  M3_ATTN_PV=fp16 keeps
         # everything fp16 (max-tracking loop, ~20 % slower attention).
         self.pv_bf16 = self.tdt == torch.float16 and os.environ.get("M3_ATTN_PV", "bf16") != "fp16"
+        # LayerNorm fold (fp16 trunk only; M3_LN_FOLD=0 restores the LayerNorm kernels): the residual GEMMs also write the 16-bit
+        # copy of the stream and its row statistics, the projections that follow a LayerNorm multiply that raw copy by
+        # gamma-scaled weights and normalise in their epilogue (ops.gemm_ex) - no LayerNorm pass, no LayerNorm launch.  Costs
+        # 7-10 % of the fp16 trunk's error budget (tools/experiments/emul_lnfold.py: rounding the raw stream instead of the
+        # normalised values; the bf16 trunk cannot afford it and keeps the kernels).
+        self.ln_fold = self.tdt == torch.float16 and os.environ.get("M3_LN_FOLD", "1") != "0"
         self.host_weights = weights if weights is not None else init_random_weights(self.cfg, seed)
         self._prepare(self.host_weights)
         self._rope_cache = {}
@@ -309,6 +315,17 @@ class Mast3rFull:
             P[p + ".w"] = t.to(dev, wdt).contiguous()
             P[p + ".b"] = w[p + ".bias"].repeat(s * s).to(dev, torch.float32).contiguous()
 
+        def fold(dst, wt, bs, npre):
+            """Consumer of LayerNorm `npre`: weights with gamma folded in (rounded to the operand type), the column sums of
+            those ROUNDED weights (what mean * sum_k W[n][k] must cancel exactly), bias + W . beta."""
+            if not self.ln_fold:
+                return
+            gam, bet = w[npre + ".weight"].double(), w[npre + ".bias"].double()
+            wf = (wt.double() * gam[None, :]).to(torch.float32).to(wdt)
+            P[dst + ".fw"] = wf.to(dev).contiguous()
+            P[dst + ".fcs"] = wf.double().sum(1).to(torch.float32).to(dev).contiguous()
+            P[dst + ".fb"] = (bs.double() + wt.double() @ bet).to(torch.float32).to(dev).contiguous()
+
         c = self.cfg
         P["patch.w"] = w["patch_embed.proj.weight"].reshape(c["enc_dim"], -1).to(dev, wdt).contiguous()
         P["patch.b"] = w["patch_embed.proj.bias"].to(dev, torch.float32).contiguous()
@@ -316,6 +333,8 @@ class Mast3rFull:
             p = f"enc_blocks.{i}"
             norm(p + ".norm1"); lin(p + ".attn.qkv"); lin(p + ".attn.proj")
             norm(p + ".norm2"); lin(p + ".mlp.fc1"); lin(p + ".mlp.fc2")
+            fold(p + ".attn.qkv", w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], p + ".norm1")
+            fold(p + ".mlp.fc1", w[p + ".mlp.fc1.weight"], w[p + ".mlp.fc1.bias"], p + ".norm2")
         norm("enc_norm"); lin("decoder_embed")
         for name in ("dec_blocks", "dec_blocks2"):
             for i in range(c["dec_depth"]):
@@ -327,6 +346,11 @@ class Mast3rFull:
                 P[p + ".cross_attn.kv.b"] = torch.cat([w[p + ".cross_attn.projk.bias"],
                                                        w[p + ".cross_attn.projv.bias"]], 0).to(dev, torch.float32).contiguous()
                 norm(p + ".norm3"); lin(p + ".mlp.fc1"); lin(p + ".mlp.fc2")
+                fold(p + ".attn.qkv", w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], p + ".norm1")
+                fold(p + ".cross_attn.projq", w[p + ".cross_attn.projq.weight"], w[p + ".cross_attn.projq.bias"], p + ".norm2")
+                fold(p + ".cross_attn.kv", torch.cat([w[p + ".cross_attn.projk.weight"], w[p + ".cross_attn.projv.weight"]], 0),
+                     torch.cat([w[p + ".cross_attn.projk.bias"], w[p + ".cross_attn.projv.bias"]], 0), p + ".norm_y")
+                fold(p + ".mlp.fc1", w[p + ".mlp.fc1.weight"], w[p + ".mlp.fc1.bias"], p + ".norm3")
         norm("dec_norm")
         ld = c["layer_dims"]
         wdt = self.hdt
@@ -401,6 +425,8 @@ class Mast3rFull:
             ops.patchify16(imgs_u8, dt, out=patches[:b * t])
             ops.patchify16(imgs2_u8, dt, out=patches[b * t:])
             b = 2 * b
+        if self.ln_fold:
+            return self._encode_fold(patches, b, t, rtok), (gh, gw)
         x = ops.gemm(patches, P["patch.w"], P["patch.b"], ops.EPI_F32)                        # fp32 residual stream
         for i in range(c["enc_depth"]):
             p = f"enc_blocks.{i}"
@@ -411,6 +437,30 @@ class Mast3rFull:
             hdn = ops.gemm(xn, P[p + ".mlp.fc1.w"], P[p + ".mlp.fc1.b"], ops.EPI_BF16_GELU)
             ops.gemm(hdn, P[p + ".mlp.fc2.w"], P[p + ".mlp.fc2.b"], ops.EPI_F32_ACCUM, out=x, resid=x)
         return ops.layernorm(x, P["enc_norm.g"], P["enc_norm.b"], dtype=dt), (gh, gw)
+
+    def _encode_fold(self, patches, b, t, rtok):
+        """The encoder blocks with the LayerNorm fold: the residual stream lives in two fp16 planes (x = hi + lo, 22 bits) that
+        the residual GEMMs update in place together with the rows' statistics; hi is the operand of the qkv / fc1
+        projections, whose epilogues apply norm1 / norm2 - no LayerNorm pass, no 16-bit copy of the stream."""
+        P, c, dt = self.P, self.cfg, self.tdt
+        E, heads = c["enc_dim"], c["enc_heads"]
+        m = patches.shape[0]
+        hl = ops.ln_hl_buffers(m, E, patches.device)              # the stream as hi + lo fp16 planes (+ row statistics)
+        x16, _, st = hl
+        ops.gemm_ex(patches, P["patch.w"], P["patch.b"], ops.EPI_F32, hl=hl)
+        n_blk = c["enc_depth"]
+        for i in range(n_blk):
+            p = f"enc_blocks.{i}"
+            qkv = ops.gemm_ex(x16, P[p + ".attn.qkv.fw"], P[p + ".attn.qkv.fb"], ops.EPI_BF16_ROPE,
+                              rope=(rtok, 2 * E, E, ops.QK_PRESCALE), pv_bf16=self.pv_bf16, fold_in=(st, P[p + ".attn.qkv.fcs"]))
+            a = torch.empty((b * t, E), dtype=dt, device=x16.device)
+            ops.attention(qkv, qkv[:, E:], qkv[:, 2 * E:], a, nbatch=b, heads=heads, tq=t, tk=t,
+                          q_row_stride=3 * E, kv_row_stride=3 * E, o_row_stride=E, q_batch_stride=t * 3 * E,
+                          kv_batch_stride=t * 3 * E, o_batch_stride=t * E, prescaled=True, pv_bf16=self.pv_bf16)
+            ops.gemm_ex(a, P[p + ".attn.proj.w"], P[p + ".attn.proj.b"], ops.EPI_F32_ACCUM, hl=hl)
+            hdn = ops.gemm_ex(x16, P[p + ".mlp.fc1.fw"], P[p + ".mlp.fc1.fb"], ops.EPI_BF16_GELU, fold_in=(st, P[p + ".mlp.fc1.fcs"]))
+            ops.gemm_ex(hdn, P[p + ".mlp.fc2.w"], P[p + ".mlp.fc2.b"], ops.EPI_F32_ACCUM, hl=hl)
+        return ops.layernorm(ops.hl_to_f32(hl), P["enc_norm.g"], P["enc_norm.b"], dtype=dt)      # enc_norm stays a kernel
 
     def encode(self, img):
         """model.encode(img) (mast3r_utils.py:278): uint8 [H,W,3] -> tokens [T,1024] (16-bit tensor of the trunk type);
@@ -440,6 +490,8 @@ class Mast3rFull:
             fcat = torch.as_strided(f1, (2, m, f1.shape[1]), (m * f1.shape[1], f1.shape[1], 1))   # adjacent halves of the encoder batch
         else:
             fcat = torch.stack([f1, f2])                                                 # [2,M,1024]
+        if self.ln_fold:
+            return self._decode_fold(fcat, f1, f2, npairs, t, rtok)
         x = ops.gemm_grouped2(fcat, P["decoder_embed.w"], P["decoder_embed.w"], P["decoder_embed.b"],
                               P["decoder_embed.b"], ops.EPI_F32)                         # fp32 residual streams [2,M,D]
         # tap 0 = the cached encoder features; the heads read them in their own 16-bit type (bf16 -> fp16 is exact
@@ -487,6 +539,66 @@ class Mast3rFull:
                     tap = ops.layernorm_grouped2(x, P["dec_norm.g"], P["dec_norm.b"], P["dec_norm.g"], P["dec_norm.b"], dtype=hdt)
                 else:
                     tap = ops.cast_f32(x, hdt)
+                taps[0].append(tap[0])
+                taps[1].append(tap[1])
+        return taps
+
+    def _decode_fold(self, fcat, f1, f2, npairs, t, rtok):
+        """decode_tokens with the LayerNorm fold (fp16 trunk): every norm1 / norm2 / norm_y / norm3 lives in the epilogue of
+        the projection behind it; the residual GEMMs keep the 16-bit copy x16 of both streams and their row statistics st
+        up to date.  Group g of the k|v projection multiplies the OTHER branch's copy (a_swap)."""
+        P, c = self.P, self.cfg
+        D, heads = c["dec_dim"], c["dec_heads"]
+        m = npairs * t
+        dev = fcat.device
+        dt, hdt, pv = self.tdt, self.hdt, self.pv_bf16
+        hl = ops.ln_hl_buffers(m, D, dev, groups=2)               # both residual streams [2,M,D] as hi + lo planes
+        x16, _, st = hl
+        ops.gemm_ex(fcat, P["decoder_embed.w"], P["decoder_embed.b"], ops.EPI_F32, w1=P["decoder_embed.w"],
+                    bias1=P["decoder_embed.b"], hl=hl)
+        if hdt == dt:
+            taps = [[f1], [f2]]
+        else:
+            c16 = ops.cast16(fcat.reshape(2 * m, -1), hdt)
+            taps = [[c16[:m]], [c16[m:]]]
+        hooks = set(c["hooks"])
+        W = lambda i, s: (P[f"dec_blocks.{i}.{s}"], P[f"dec_blocks2.{i}.{s}"])
+
+        def consume(i, name, epi, **kw):
+            (w0, w1), (b0, b1), (s0, s1) = W(i, name + ".fw"), W(i, name + ".fb"), W(i, name + ".fcs")
+            return ops.gemm_ex(x16, w0, b0, epi, w1=w1, bias1=b1, fold_in=(st, s0, s1), **kw)
+
+        def produce(i, name, a):
+            (w0, w1), (b0, b1) = W(i, name + ".w"), W(i, name + ".b")
+            ops.gemm_ex(a, w0, b0, ops.EPI_F32_ACCUM, w1=w1, bias1=b1, hl=hl)
+
+        for i in range(c["dec_depth"]):
+            # cross-attention memory: norm_y of the OTHER view's previous-layer tokens, then the k|v projection
+            kv = consume(i, "cross_attn.kv", ops.EPI_BF16_ROPE, rope=(rtok, D), pv_bf16=pv, a_swap=True)   # [2,M,2D], k rotated
+            qkv = consume(i, "attn.qkv", ops.EPI_BF16_ROPE, rope=(rtok, 2 * D, D, ops.QK_PRESCALE), pv_bf16=pv).view(2 * m, 3 * D)
+            a = torch.empty((2, m, D), dtype=dt, device=dev)
+            ops.attention(qkv, qkv[:, D:], qkv[:, 2 * D:], a, nbatch=2 * npairs, heads=heads, tq=t, tk=t,
+                          q_row_stride=3 * D, kv_row_stride=3 * D, o_row_stride=D, q_batch_stride=t * 3 * D,
+                          kv_batch_stride=t * 3 * D, o_batch_stride=t * D, prescaled=True, pv_bf16=pv)
+            produce(i, "attn.proj", a)
+            q = consume(i, "cross_attn.projq", ops.EPI_BF16_ROPE, rope=(rtok, D, D, ops.QK_PRESCALE)).view(2 * m, D)
+            kvf = kv.view(2 * m, 2 * D)
+            a = torch.empty((2, m, D), dtype=dt, device=dev)
+            ops.attention(q, kvf, kvf[:, D:], a, nbatch=2 * npairs, heads=heads, tq=t, tk=t, q_row_stride=D,
+                          kv_row_stride=2 * D, o_row_stride=D, q_batch_stride=t * D, kv_batch_stride=t * 2 * D,
+                          o_batch_stride=t * D, prescaled=True, pv_bf16=pv)
+            produce(i, "cross_attn.proj", a)
+            hdn = consume(i, "mlp.fc1", ops.EPI_BF16_GELU)
+            produce(i, "mlp.fc2", hdn)
+            layer = i + 1
+            if layer in hooks:
+                if layer == c["dec_depth"]:
+                    tap = ops.layernorm_grouped2(ops.hl_to_f32(hl), P["dec_norm.g"], P["dec_norm.b"], P["dec_norm.g"], P["dec_norm.b"],
+                                                 dtype=hdt)
+                elif hdt == dt:
+                    tap = x16.clone()                      # the hi plane IS the stream rounded to the heads' type
+                else:
+                    tap = ops.cast_f32(ops.hl_to_f32(hl), hdt)
                 taps[0].append(tap[0])
                 taps[1].append(tap[1])
         return taps

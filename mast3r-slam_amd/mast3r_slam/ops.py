@@ -8,6 +8,8 @@ from __future__ import annotations
 
 import os
 
+import ctypes as C
+
 import torch
 
 from . import _ffi
@@ -562,6 +564,138 @@ def gemm_grouped2(a, w0, w1, b0, b1, epi=EPI_BF16, out=None, resid=None, rope=No
                   _ffi.ptr(resid), m, n, k, ldc, m * k, m * ldc, epi, _ffi.ptr(rtok), tpi, rc, int(qc), float(qs), dt, _ffi.stream_ptr())
     _prof_end(e0, _gemm_kind(m, n, 2), 4.0 * m * n * k,
               2.0 * (2.0 * (m * k + n * k) + out.element_size() * m * n * (1 if resid is None else 2)))
+    return out
+
+
+LN_EPS = 1e-6
+
+
+def ln_fold_buffers(rows: int, cols: int, dtype, device, groups: int = 1):
+    """Buffers of the LayerNorm fold for a [rows, cols] (or [2, rows, cols]) fp32 stream: (x16, stats) - the 16-bit copy of the
+    stream and the partial statistics [cols / 32, rows, 2] (slot-major) that a producer GEMM (gemm_ex(..., fold_out=...)) fills."""
+    if cols % 128:
+        raise ValueError("LayerNorm fold: the stream width must be a multiple of 128")
+    lead = (2,) if groups == 2 else ()
+    return (torch.empty(lead + (rows, cols), dtype=dtype, device=device),
+            torch.empty(lead + (cols // 32, rows, 2), dtype=torch.float32, device=device))
+
+
+def ln_hl_buffers(rows: int, cols: int, device, groups: int = 1):
+    """The hi / lo form of a [rows, cols] (or [2, rows, cols]) residual stream: (hi, lo, stats) - two fp16 planes with
+    x = hi + lo (22 significant bits) and the slot-major row statistics.  gemm_ex(..., hl=...) keeps all three up to date;
+    `hi` is what the projections behind a LayerNorm multiply (gemm_ex(hi, ..., fold_in=(stats, ...)))."""
+    hi, st = ln_fold_buffers(rows, cols, torch.float16, device, groups)
+    return hi, torch.empty_like(hi), st
+
+
+def hl_to_f32(hl):
+    """fp32 view of a hi / lo stream (the two LayerNorms that still run as kernels - enc_norm, dec_norm - read it)."""
+    return torch.add(hl[0].float(), hl[1])
+
+
+def gemm_ex(a, w, bias=None, epi: int = EPI_BF16, out=None, resid=None, w1=None, bias1=None, rope=None, pv_bf16: bool = False,
+            fold_in=None, fold_out=None, a_swap: bool = False, hl=None):
+    """m3_gemm_ex: one or two groups, any epilogue, with the LayerNorm fold (include/m3slam_model.h).
+      a [M,K] (w1 None) or [2,M,K]; w (and w1) [N,K]; out / resid like gemm / gemm_grouped2; rope = (positions int32 [T,2],
+      rope_cols[, q_cols, q_scale]) with EPI_BF16_ROPE.
+      fold_out = (x16, stats): PRODUCER - with EPI_F32 / EPI_F32_ACCUM also writes the 16-bit copy of the fp32 output and the
+        rows' partial statistics (ln_fold_buffers).
+      fold_in = (stats, colsum[, colsum1]): CONSUMER - `a` is the 16-bit copy of the raw stream, w carries gamma, bias carries
+        beta . W^T; the epilogue applies rstd * (acc - mean * colsum) before the bias.
+      a_swap (two groups): group g multiplies a[1 - g] (and reads the statistics of stream 1 - g) - the decoder's
+        cross-attention memory is the other view's stream.
+      hl = (hi, lo, stats) (ln_hl_buffers; fp16): PRODUCER on a hi / lo stream, in place - EPI_F32: the stream becomes
+        a @ w^T + bias; EPI_F32_ACCUM: it is updated by that product.  No fp32 tensor is written; returns None."""
+    grouped = w1 is not None
+    a = _ffi.check(a, H16, "a")
+    w = _ffi.check(w, H16, "w")
+    if grouped:
+        if a.dim() != 3 or a.shape[0] != 2:
+            raise ValueError(f"a must be [2,M,K], got {tuple(a.shape)}")
+        w1 = _ffi.check(w1, H16, "w1", tuple(w.shape))
+    elif a.dim() != 2:
+        raise ValueError(f"a must be [M,K], got {tuple(a.shape)}")
+    m, k = a.shape[-2:]
+    n = w.shape[0]
+    if w.shape[1] != k:
+        raise ValueError(f"K mismatch: a {tuple(a.shape)} vs w {tuple(w.shape)}")
+    if pv_bf16 and epi != EPI_BF16_ROPE:
+        raise ValueError("pv_bf16 goes with epi=EPI_BF16_ROPE")
+    dt = _pv_code(_same16(a, w, w1), pv_bf16)
+    odt = torch.float32 if epi in _F32_EPIS else a.dtype
+    lead = (2,) if grouped else ()
+    if hl is not None:
+        if epi not in _F32_EPIS or a.dtype != torch.float16 or out is not None or resid is not None or fold_out is not None:
+            raise ValueError("hl goes with EPI_F32 / EPI_F32_ACCUM on fp16 operands, without out / resid / fold_out")
+        hi, lo, stats = hl
+        for t_ in (hi, lo):
+            if t_.dtype != torch.float16 or tuple(t_.shape) != lead + (m, n) or not t_.is_contiguous():
+                raise ValueError("bad hi / lo planes (ln_hl_buffers)")
+        if stats.dtype != torch.float32 or tuple(stats.shape) != lead + (n // 32, m, 2) or not stats.is_contiguous():
+            raise ValueError("bad statistics buffer (ln_hl_buffers)")
+        d = _ffi.GemmDesc()
+        d.A, d.W, d.W1 = a.data_ptr(), w.data_ptr(), _ffi.ptr(w1)
+        d.bias, d.bias1 = _ffi.ptr(bias), _ffi.ptr(bias1)
+        d.c16, d.c_lo, d.stats_out = hi.data_ptr(), lo.data_ptr(), stats.data_ptr()
+        if epi == EPI_F32_ACCUM:
+            d.R, d.r_lo = hi.data_ptr(), lo.data_ptr()
+        d.M, d.N, d.K, d.ldc, d.epilogue, d.dtype, d.groups = m, n, k, n, epi, dt, 2 if grouped else 1
+        d.a_gstride, d.c_gstride = (m * k, m * n) if grouped else (0, 0)
+        d.stats_gstride = m * (n // 32) * 2 if grouped else 0
+        e0 = _prof_begin()
+        _ffi.call("m3_gemm_ex", C.addressof(d), _ffi.stream_ptr())
+        g_ = 2 if grouped else 1
+        _prof_end(e0, _gemm_kind(m, n, g_), 2.0 * g_ * m * n * k,
+                  g_ * (2.0 * (m * k + n * k) + 4.0 * m * n * (1 if epi == EPI_F32 else 2) + 8.0 * m * (n // 32)),
+                  f"gemm_ex hl {g_}x{m}x{n}x{k} epi{epi}")
+        return None
+    if out is None:
+        out = torch.empty(lead + (m, n), dtype=odt, device=a.device)
+    elif out.dtype != odt or tuple(out.shape[:-1]) != lead + (m,) or out.shape[-1] < n or not out.is_contiguous():
+        raise ValueError("bad `out`")
+    ldc = out.shape[-1]
+    if resid is not None and (resid.dtype != odt or tuple(resid.shape) != tuple(out.shape) or not resid.is_contiguous()):
+        raise ValueError("bad `resid`")
+    d = _ffi.GemmDesc()
+    d.A = (a[1] if (grouped and a_swap) else a).data_ptr()
+    d.W, d.W1 = w.data_ptr(), _ffi.ptr(w1)
+    d.bias, d.bias1 = _ffi.ptr(bias), _ffi.ptr(bias1)
+    d.C, d.R = out.data_ptr(), _ffi.ptr(resid)
+    d.M, d.N, d.K, d.ldc, d.epilogue, d.dtype, d.groups = m, n, k, ldc, epi, dt, 2 if grouped else 1
+    d.a_gstride = (-m * k if a_swap else m * k) if grouped else 0
+    d.c_gstride = m * ldc if grouped else 0
+    if rope is not None:
+        rtok, rc, qc, qs = (tuple(rope) + (0, 1.0))[:4]
+        rtok = _ffi.check(rtok, torch.int32, "rope positions", (None, 2))
+        d.rope_pos, d.tokens_per_image, d.rope_base = rtok.data_ptr(), rtok.shape[0], float(ROPE_BASE)
+        d.rope_cols, d.q_cols, d.q_scale = int(rc), int(qc), float(qs)
+    if fold_out is not None:
+        x16, stats = fold_out
+        if (x16.dtype != a.dtype or tuple(x16.shape) != tuple(out.shape) or not x16.is_contiguous() or stats.dtype != torch.float32
+                or tuple(stats.shape) != lead + (n // 32, m, 2) or not stats.is_contiguous() or ldc != n):
+            raise ValueError("bad fold_out buffers (ln_fold_buffers)")
+        d.c16, d.stats_out = x16.data_ptr(), stats.data_ptr()
+        d.stats_gstride = m * (n // 32) * 2 if grouped else 0
+    if fold_in is not None:
+        stats, cs0 = fold_in[0], fold_in[1]
+        cs1 = fold_in[2] if len(fold_in) > 2 else None
+        if stats.dtype != torch.float32 or tuple(stats.shape) != lead + (k // 32, m, 2) or not stats.is_contiguous():
+            raise ValueError("bad fold_in statistics")
+        cs0 = _ffi.check(cs0, torch.float32, "colsum", (n,))
+        if grouped:
+            cs1 = _ffi.check(cs1, torch.float32, "colsum1", (n,))
+        per = m * (k // 32) * 2
+        d.ln_stats = (stats[1] if (grouped and a_swap) else stats).data_ptr()
+        d.ln_colsum, d.ln_colsum1 = cs0.data_ptr(), _ffi.ptr(cs1)
+        d.ln_slots, d.ln_eps = k // 32, float(LN_EPS)
+        d.ln_gstride = (-per if a_swap else per) if grouped else 0
+    e0 = _prof_begin()
+    _ffi.call("m3_gemm_ex", C.addressof(d), _ffi.stream_ptr())
+    g = 2 if grouped else 1
+    nb = 2.0 * (m * k + n * k) + out.element_size() * m * n * (1 if resid is None else 2)
+    if fold_out is not None:
+        nb += 2.0 * m * n + 8.0 * m * (n // 32)
+    _prof_end(e0, _gemm_kind(m, n, g), 2.0 * g * m * n * k, g * nb, f"gemm_ex {g}x{m}x{n}x{k} epi{epi} {a.dtype}")
     return out
 
 

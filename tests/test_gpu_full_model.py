@@ -87,8 +87,10 @@ def test_full_depth_network_vs_cpu_oracle(dev, full_weights, shape):
         assert report[("bf16", v)]["pts3d"] < report[("bf16+bf16heads", v)]["pts3d"]
 
 
-def test_benchmarked_configuration_eight_pairs_through_the_graph(dev, full_weights):
-    """What bench.py times (BASELINE configs[3]'s per-GPU shard): FULL_CFG, 8 pairs at 512x512, default precision,
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_benchmarked_configuration_eight_pairs_through_the_graph(dev, full_weights, prec):
+    """What bench.py times (BASELINE configs[3]'s per-GPU shard): FULL_CFG, 8 pairs at 512x512, bench.py's default precision
+    ("fp16": the LayerNorm-folded trunk) and the bf16 trunk BASELINE configs[1] names,
     replayed from the hipGraph of `net.graphed(8, 512, 512)` - i.e. the k_gemm256 256x256 / 256x192 tiles, the 2-group
     launches and the XCD-ordered grids, none of which a one-pair eager pass reaches (it runs on the 64 / 128 tiles).
     Contract: mast3r_utils.py:281-294.
@@ -100,7 +102,7 @@ def test_benchmarked_configuration_eight_pairs_through_the_graph(dev, full_weigh
     P = 8
     im1 = np.stack([synthetic.textured_image(h, w, 2 * p) for p in range(P)])          # bench.py's images of rank 0
     im2 = np.stack([synthetic.textured_image(h, w, 2 * p + 1) for p in range(P)])
-    net = M.Mast3rFull(weights=full_weights, device=dev, precision="bf16")
+    net = M.Mast3rFull(weights=full_weights, device=dev, precision=prec)
     g = net.graphed(P, h, w)
     o1, o2 = g(im1, im2)
     o1, o2 = ({k: v.clone() for k, v in o.items()} for o in (o1, o2))
@@ -115,7 +117,7 @@ def test_benchmarked_configuration_eight_pairs_through_the_graph(dev, full_weigh
             assert torch.equal(o2[k][p], e2[k][0]), (p, k, "view 2", _rel(o2[k][p], e2[k][0]))
     r1, r2 = _oracle_pair(full_weights, "plain", h, w)
     for o, r in ((o1, r1), (o2, r2)):
-        for k, tol in FULL_TOL["bf16"].items():
+        for k, tol in FULL_TOL[prec].items():
             assert _rel(o[k][0], r[k][0]) < tol, (k, _rel(o[k][0], r[k][0]))
     assert not torch.equal(o1["pts3d"][0], o1["pts3d"][1])                             # the pairs really differ
 
@@ -182,11 +184,13 @@ def test_trained_like_weight_statistics_at_full_depth(dev):
         assert report[("fp16", v)]["pts3d"] < 0.5 * report[("bf16", v)]["pts3d"]       # the 3 extra mantissa bits pay
 
 
-@pytest.fixture(scope="module")
-def tiny(dev):
+@pytest.fixture(scope="module", params=["bf16", "fp16"])
+def tiny(dev, request):
+    """Both trunk precisions: "fp16" (load_mast3r's default) runs the LayerNorm fold (m3_gemm_ex) - ragged token counts,
+    cached-token decodes and the operator API all go through it; "bf16" keeps the LayerNorm kernels."""
     cfg = M.TINY_CFG
     w = M.init_random_weights(cfg, seed=1)
-    return cfg, w, M.Mast3rFull(weights=w, cfg=cfg, device=dev)
+    return cfg, w, M.Mast3rFull(weights=w, cfg=cfg, device=dev, precision=request.param)
 
 
 @pytest.mark.parametrize("shape", [(336, 512), (288, 512), (224, 224), (512, 336)])
@@ -225,7 +229,7 @@ def test_checkpoint_round_trip_and_precision_argument(tiny, dev, tmp_path):
     from safetensors.torch import save_file
     save_file({k: v.contiguous() for k, v in w.items()}, str(st))
     for path in (bare, wrapped, st):
-        m2 = mast3r_utils.load_mast3r("mast3r_full", "base", 512, "bf16", weights_path=str(path), cfg=cfg, device=dev)
+        m2 = mast3r_utils.load_mast3r("mast3r_full", "base", 512, net.precision, weights_path=str(path), cfg=cfg, device=dev)
         o1, o2 = m2.reconstruct_batch(im1, im2)
         for k in ref1:
             assert torch.equal(o1[k], ref1[k]) and torch.equal(o2[k], ref2[k]), (path.name, k)
@@ -324,7 +328,7 @@ def test_fp16_features_through_the_operator_api(tiny, dev):
     rounded once); the symmetric match operator on them equals the numpy oracle matcher run on the half-rounded
     descriptors bit for bit, and everything else the network returns is unchanged."""
     cfg, w, net = tiny
-    net16 = M.Mast3rFull(weights=w, cfg=cfg, device=dev, features="fp16")
+    net16 = M.Mast3rFull(weights=w, cfg=cfg, device=dev, features="fp16", precision=net.precision)
     with pytest.raises(ValueError, match="features"):
         M.Mast3rFull(weights=w, cfg=cfg, device=dev, features="int8")
     h, wd = 128, 256

@@ -875,3 +875,132 @@ def test_layernorm_dual2_equals_two_grouped_launches(dev, dt):
     y_own, y_cross = ops.layernorm_dual2(x, own, cross, dtype=dt)
     assert torch.equal(y_own, ops.layernorm_grouped2(x, prm[0], prm[1], prm[2], prm[3], dtype=dt))
     assert torch.equal(y_cross, ops.layernorm_grouped2(x, prm[4], prm[5], prm[6], prm[7], swap=True, dtype=dt))
+
+
+def _fold_problem(m, c, n, seed, dt=torch.float16):
+    """A residual stream x [m,c] with outlier channels and a mean offset, a LayerNorm (gamma over a decade, beta) and the
+    projection behind it; returns the float64 reference LayerNorm(x) @ W^T + b and the folded operands."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(m, c, generator=g) * 1.5 + 0.3
+    x[:, 17] *= 20.0; x[:, c // 2 + 5] -= 12.0                              # massive-activation channels
+    gam = torch.exp(torch.randn(c, generator=g) * 0.5); bet = torch.randn(c, generator=g) * 0.1
+    W = (torch.randn(n, c, generator=g) * 0.05).to(torch.bfloat16).float(); b = torch.randn(n, generator=g) * 0.1
+    ref = F.layer_norm(x.double(), (c,), gam.double(), bet.double(), ops.LN_EPS) @ W.double().T + b.double()
+    wf = (W.double() * gam.double()[None]).float().to(dt)
+    return x, gam, bet, W, b, ref, wf, wf.double().sum(1).float(), (b.double() + W.double() @ bet.double()).float()
+
+
+@pytest.mark.parametrize("shape", [(512, 1024, 3072), (2048, 768, 768), (16384, 1024, 1024), (300, 256, 128)])
+def test_layernorm_fold_producer_and_consumer(dev, shape):
+    """m3_gemm_ex: the residual GEMM also emits the 16-bit copy of the stream and per-row statistics; the projection behind
+    the LayerNorm multiplies that RAW copy by gamma-scaled weights and normalises in its epilogue.  Against float64:
+    the producer's fp32 stream / copy / statistics exactly as defined, the consumer within the rounding of the raw copy."""
+    m, c, n = shape
+    x, gam, bet, W, b, ref, wf, cs, fb = _fold_problem(m, c, n, seed=m + c + n)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    # producer: x' = r + a @ wp^T + bp  (r such that x' is the stream above: a = 0 rows would not exercise the MFMAs)
+    kp = 128
+    a = torch.randn(m, kp, generator=g).half(); wp = (torch.randn(c, kp, generator=g) * 0.05).half(); bp = torch.randn(c, generator=g)
+    r = (x.double() - (a.double() @ wp.double().T + bp.double())).float()
+    xs = r.to(dev).clone()
+    fo = ops.ln_fold_buffers(m, c, torch.float16, dev)
+    out = ops.gemm_ex(a.to(dev), wp.to(dev), bp.to(dev), ops.EPI_F32_ACCUM, out=xs, resid=xs, fold_out=fo)
+    plain = ops.gemm(a.to(dev), wp.to(dev), bp.to(dev), ops.EPI_F32_ACCUM, out=r.to(dev).clone(), resid=r.to(dev).clone())
+    assert torch.equal(out, plain)                                           # the fp32 stream is what the plain launch writes
+    x16, st = fo
+    assert torch.equal(x16, out.half())                                      # the copy is the stream rounded once
+    xo = out.double().cpu().view(m, c // 32, 32)
+    assert torch.allclose(st[..., 0].double().cpu().T, xo.sum(-1), rtol=1e-5, atol=1e-3)          # slot-major [c / 32, m, 2]
+    assert torch.allclose(st[..., 1].double().cpu().T, (xo * xo).sum(-1), rtol=1e-5, atol=1e-3)
+    # consumer, three epilogues
+    ref_d = F.layer_norm(out.double().cpu(), (c,), gam.double(), bet.double(), ops.LN_EPS) @ W.double().T + b.double()
+    y = ops.gemm_ex(x16, wf.to(dev), fb.to(dev), ops.EPI_BF16, fold_in=(st, cs.to(dev)))
+    shipped = ops.gemm(ops.layernorm(out, gam.to(dev), bet.to(dev), dtype=torch.float16), W.half().to(dev), b.to(dev), ops.EPI_BF16)
+    e_fold, e_ship = _rel(y, ref_d), _rel(shipped, ref_d)
+    assert e_fold < 1.5e-3 and e_fold < 4 * e_ship + 2e-4, (e_fold, e_ship)   # rounding raw x instead of LN(x): same order of error
+    yg = ops.gemm_ex(x16, wf.to(dev), fb.to(dev), ops.EPI_BF16_GELU, fold_in=(st, cs.to(dev)))
+    assert _rel(yg, F.gelu(ref_d)) < 2e-3
+    if n % 64 == 0:
+        t = 16
+        pos = torch.stack(torch.meshgrid(torch.arange(4), torch.arange(4), indexing="ij"), -1).reshape(-1, 2).to(torch.int32).to(dev)
+        if m % t == 0:
+            yr = ops.gemm_ex(x16, wf.to(dev), fb.to(dev), ops.EPI_BF16_ROPE, rope=(pos, n), fold_in=(st, cs.to(dev)))
+            plain_r = ops.gemm_rope(ops.layernorm(out, gam.to(dev), bet.to(dev), dtype=torch.float16), W.half().to(dev), b.to(dev), pos, n)
+            assert _rel(yr, plain_r) < 3e-3
+
+
+def test_layernorm_fold_is_tile_shape_invariant(dev):
+    """Statistics are kept per 32-column slot and added in one order by every kernel, so producer outputs AND consumer
+    outputs are bitwise the same whichever tile shape a launch is dispatched to (64 / 128 / 192 / 256)."""
+    m, c, n = 4096, 768, 1536
+    x, gam, bet, W, b, ref, wf, cs, fb = _fold_problem(m, c, n, seed=3)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    a = torch.randn(m, 256, generator=g).half().to(dev); wp = (torch.randn(c, 256, generator=g) * 0.05).half().to(dev)
+    got = []
+    prev = ops._ffi.lib().m3_gemm_set_tile(0)
+    try:
+        for tile in (64, 128, 192, 256):
+            ops._ffi.lib().m3_gemm_set_tile(tile)
+            xs = x.to(dev).clone()
+            fo = ops.ln_fold_buffers(m, c, torch.float16, dev)
+            ops.gemm_ex(a, wp, None, ops.EPI_F32_ACCUM, out=xs, resid=xs, fold_out=fo)
+            y = ops.gemm_ex(fo[0], wf.to(dev), fb.to(dev), ops.EPI_BF16_GELU, fold_in=(fo[1], cs.to(dev)))
+            got.append((xs, fo[0], fo[1], y))
+    finally:
+        ops._ffi.lib().m3_gemm_set_tile(prev)
+    for other in got[1:]:
+        for p, q in zip(got[0], other):
+            assert torch.equal(p, q)
+
+
+def test_layernorm_fold_two_groups_and_swapped_memory(dev):
+    """Two-group launches (the decoder branches): group g's producer fills its half of the copy / statistics; with a_swap the
+    consumer of group g multiplies the OTHER stream's copy with the other stream's statistics (cross-attention memory)."""
+    m, c, n = 1024, 768, 1536
+    P0, P1 = _fold_problem(m, c, n, seed=21), _fold_problem(m, c, n, seed=22)
+    x = torch.stack([P0[0], P1[0]]).to(dev)
+    g = torch.Generator(device="cpu").manual_seed(2)
+    a = torch.randn(2, m, 64, generator=g).half().to(dev); wp = [(torch.randn(c, 64, generator=g) * 0.05).half().to(dev) for _ in range(2)]
+    xs = x.clone()
+    fo = ops.ln_fold_buffers(m, c, torch.float16, dev, groups=2)
+    ops.gemm_ex(a, wp[0], None, ops.EPI_F32_ACCUM, out=xs, resid=xs, w1=wp[1], fold_out=fo)
+    for gi in range(2):                                                       # each group = the single-group launch on its half
+        x1 = x[gi].clone(); f1 = ops.ln_fold_buffers(m, c, torch.float16, dev)
+        ops.gemm_ex(a[gi].contiguous(), wp[gi], None, ops.EPI_F32_ACCUM, out=x1, resid=x1, fold_out=f1)
+        assert torch.equal(xs[gi], x1) and torch.equal(fo[0][gi], f1[0]) and torch.equal(fo[1][gi], f1[1])
+    wf = [P0[6].to(dev), P1[6].to(dev)]; cs = [P0[7].to(dev), P1[7].to(dev)]; fb = [P0[8].to(dev), P1[8].to(dev)]
+    for swap in (False, True):
+        y = ops.gemm_ex(fo[0], wf[0], fb[0], ops.EPI_BF16, w1=wf[1], bias1=fb[1], fold_in=(fo[1], cs[0], cs[1]), a_swap=swap)
+        for gi in range(2):
+            src = 1 - gi if swap else gi
+            one = ops.gemm_ex(fo[0][src].contiguous(), wf[gi], fb[gi], ops.EPI_BF16, fold_in=(fo[1][src].contiguous(), cs[gi]))
+            assert torch.equal(y[gi], one)
+
+
+@pytest.mark.parametrize("shape", [(16384, 1024, 256), (2048, 768, 128), (300, 256, 64)])
+def test_hi_lo_residual_stream(dev, shape):
+    """The hi / lo form of the residual stream (m3_gemm_ex, c_lo): x = hi + lo in two fp16 planes, updated IN PLACE by the
+    residual GEMMs together with the rows' statistics.  Against the fp32-stream launches on the same operands: hi is the
+    fp32 result rounded to fp16, hi + lo carries it to 2^-21, the statistics are those of the fp32 values; a chain of
+    updates stays that close (the stream is re-split after every update, errors do not pile up beyond the roundings)."""
+    m, c, k = shape
+    g = torch.Generator(device="cpu").manual_seed(m + c)
+    mk = lambda: (torch.randn(m, k, generator=g).half().to(dev), (torch.randn(c, k, generator=g) * 0.2).half().to(dev),
+                  torch.randn(c, generator=g).to(dev))
+    a0, w0, b0 = mk()
+    hl = ops.ln_hl_buffers(m, c, dev)
+    ops.gemm_ex(a0, w0, b0, ops.EPI_F32, hl=hl)
+    x = ops.gemm(a0, w0, b0, ops.EPI_F32)                                     # the fp32-stream twin
+    assert torch.equal(hl[0], x.half())
+    assert float((ops.hl_to_f32(hl) - x).abs().max()) <= float(x.abs().max()) * 2.0 ** -21
+    for step in range(4):
+        a, w, b = mk()
+        ref = ops.gemm(a, w, b, ops.EPI_F32_ACCUM, out=torch.empty_like(x), resid=ops.hl_to_f32(hl))     # exact twin of this update
+        ops.gemm_ex(a, w, b, ops.EPI_F32_ACCUM, hl=hl)
+        ops.gemm(a, w, b, ops.EPI_F32_ACCUM, out=x, resid=x)
+        assert torch.equal(hl[0], ref.half())                                 # one rounding of (hi + lo) + product
+        assert float((ops.hl_to_f32(hl) - ref).abs().max()) <= float(ref.abs().max()) * 2.0 ** -21
+        xo = ref.double().cpu().view(m, c // 32, 32)
+        assert torch.allclose(hl[2][..., 0].double().cpu().T, xo.sum(-1), rtol=1e-5, atol=1e-3)
+        assert torch.allclose(hl[2][..., 1].double().cpu().T, (xo * xo).sum(-1), rtol=1e-5, atol=1e-3)
+    assert _rel(ops.hl_to_f32(hl), x) < 1e-6                                  # five updates later: still the fp32 stream

@@ -158,6 +158,29 @@ def pmc_traffic(prefixes, tag=""):
     return (sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / n if n else None), os.path.basename(files[-1])
 
 
+def graph_kernel_nodes(graph) -> int:
+    """Kernel nodes of a captured torch.cuda.CUDAGraph(keep_graph=True): hipGraphGetNodes + hipGraphNodeGetType through the HIP
+    runtime torch has loaded (launches per replay; -1 when the runtime does not export the calls)."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        raw = ctypes.c_void_p(graph.raw_cuda_graph())
+        n = ctypes.c_size_t(0)
+        if hip.hipGraphGetNodes(raw, None, ctypes.byref(n)) != 0:
+            return -1
+        nodes = (ctypes.c_void_p * n.value)()
+        if hip.hipGraphGetNodes(raw, nodes, ctypes.byref(n)) != 0:
+            return -1
+        kernels = 0
+        for i in range(n.value):
+            t = ctypes.c_int(-1)
+            if hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t)) == 0 and t.value == 0:    # hipGraphNodeTypeKernel
+                kernels += 1
+        return kernels
+    except Exception:                                       # noqa: BLE001 - a diagnostic, never fatal
+        return -1
+
+
 def gemm_roofline(prof, tag=""):
     """`roofline` object from ops.PROFILE records (kind, flops, e0, e1, bytes) of one instrumented eager pass."""
     by_kind = {}
@@ -276,6 +299,7 @@ class PairsWorkload:
         self.graphs = None
         self.marks, self.state = [], {}
         self.gather, self.gathered = None, None
+        self.graph_launches = None
 
     def _make_scene(self, base):
         """What the matcher and the Gauss-Newton solve run on: P smooth two-view scenes of
@@ -338,7 +362,7 @@ class PairsWorkload:
         torch.cuda.synchronize()
         if not self.args.no_graph:
             try:
-                graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
+                graphs = [torch.cuda.CUDAGraph(keep_graph=True) for _ in range(3)]
                 with torch.cuda.graph(graphs[0]):
                     o1, o2 = self.leg_infer()
                 with torch.cuda.graph(graphs[1]):
@@ -347,6 +371,7 @@ class PairsWorkload:
                     gn = self.leg_gn(idx, valid)
                 torch.cuda.synchronize()
                 self.graphs = graphs
+                self.graph_launches = [graph_kernel_nodes(g) for g in graphs]
             except Exception as e:                                   # noqa: BLE001 - reported, never silent
                 print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
                 self.graphs = None
@@ -464,12 +489,16 @@ class PairsWorkload:
             "data": "synthetic: 512x512 textured pairs through the network (seeded random-init weights, no checkpoint available "
                     "offline); matcher + Gauss-Newton on smooth synthetic two-view scenes of the same size (SURVEY 8d configs 2-3)",
             "config": {"workload": f"{P} keyframe pairs/GPU at {self.h}x{self.w} (BASELINE configs[3] per-GPU shard): "
-                                   f"two-view MASt3R ViT-L infer ({args.precision} trunk, fp16 heads, fp32 accumulate) + "
+                                   f"two-view MASt3R ViT-L infer ({args.precision} trunk, fp16 heads, fp32 accumulate"
+                                   + (", LayerNorms folded into the GEMMs, hi+lo fp16 residual stream" if getattr(self.net, "ln_fold", False) else "") + ") + "
                                    + ("fast reciprocal-NN match (4096-seed grid, fp16 descriptors, MFMA search) " if sparse else "iter_proj/refine match ")
                                    + "+ 10-iter GN tracking" + ("" if ctx.dist is None else " + RCCL all-gather of results"),
                        "pairs_per_gpu": P, "global_pairs": world * P, "image": [self.h, self.w], "gn_iters": iters, "matcher": args.matcher,
                        "parallelism": f"pair-sharded x{world}",
                        "launch": ("3 hipGraph replays per step (infer | match | GN)" + ("" if ctx.dist is None else " + RCCL all-gather of the previous step overlapped on the communicator stream")) if self.graphs is not None else "eager"},
+            "launches_per_step": None if not self.graph_launches else
+                dict(zip(("infer", "match", "gn"), self.graph_launches), total=sum(self.graph_launches),
+                     note="kernel nodes of the three captured hipGraphs (hipGraphGetNodes)"),
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "stage_ms_note": "device time between stream events recorded around the three graph replays of every TIMED step (mean); sum ~ ms_per_step",
             "match_valid_frac": round(match_valid_frac, 4),
@@ -695,11 +724,13 @@ class PairsWorkload:
                 step1()
             torch.cuda.synchronize()
             run1 = step1
+            launches1 = None
             if self.graphs is not None:
-                g1 = torch.cuda.CUDAGraph()
+                g1 = torch.cuda.CUDAGraph(keep_graph=True)
                 with torch.cuda.graph(g1):
                     keep = step1()          # noqa: F841 - the graph's static outputs
                 run1 = g1.replay
+                launches1 = graph_kernel_nodes(g1)
             run1(); torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(10):
@@ -741,7 +772,7 @@ class PairsWorkload:
             fl = sum(p[1] for p in prof1)
             sec = sum(p[2].elapsed_time(p[3]) for p in prof1) * 1e-3
             result["batch1"] = {"workload": "BASELINE configs[1]: 1 pair/step at 512x512, same pipeline", "pairs_per_s": 1e3 / ms1,
-                                "ms_per_pair": ms1,
+                                "ms_per_pair": ms1, "launches_per_pair": launches1,
                                 "ms_per_frame_with_cached_keyframe_tokens": ms1c,
                                 "cached_note": "the per-frame tracking call: the keyframe's encoder tokens are cached (Frame.feat), one image is "
                                                "encoded, then decoders + heads + match + 10 GN iterations",

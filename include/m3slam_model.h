@@ -277,6 +277,11 @@ int m3_relu_bf16(const void *x, void *y, int64_t n, void *stream);              
 int m3_add_bf16(const void *a, const void *b, void *y, int64_t n, void *stream);     /* n % 8 == 0 */
 int m3_add_dt(const void *a, const void *b, void *y, int64_t n, int dtype, void *stream);
 int m3_concat2_bf16(const void *a, const void *b, void *out, int64_t M, int Ca, int Cb, void *stream);
+/* Packed snapshot of a step's result tensors into ONE send buffer (the all-gather's operand): segment i copies
+ * nbytes from src to dst + dst_off (16-byte aligned; mode 0), or writes nbytes / 4 int32 values narrowed from int64 (mode 1).
+ * segs is a HOST array of nseg <= 8 entries; one launch. */
+typedef struct m3_pack_seg { const void *src; int64_t dst_off; int64_t nbytes; int32_t mode; int32_t reserved; } m3_pack_seg;
+int m3_pack_fields(void *dst, const m3_pack_seg *segs, int nseg, void *stream);
 /* k = s transposed-conv GEMM output [B*h*w, s*s*C] -> NHWC [B,h*s,w*s,Cpad] (first C channels). */
 int m3_unshuffle_bf16(const void *in, void *out, int B, int h, int w, int s, int C, int Cpad, void *stream);
 /* bilinear x2, align_corners = True, NHWC bf16. */

@@ -136,9 +136,9 @@ k_gemm(const GemmArgs gin) {
 #pragma unroll
     for (int t0 = 0; t0 < STAGES - 1; ++t0)
         if (t0 < nk) stage(t0, t0);
-    // LayerNorm fold (kernel-uniform): two threads per row fetch the row's mean / rstd now - under the first loads - and carry
-    // them through the K loop in two registers; the table is written behind the waves' epilogue scratch after the loop
-    float2 ln_mr = make_float2(0.f, 0.f);
+    // LayerNorm fold (kernel-uniform): four threads per row pair fetch the rows' mean / rstd now - under the first loads - and carry
+    // them through the K loop in four registers; the table is written behind the waves' epilogue scratch after the loop
+    float4 ln_mr = make_float4(0.f, 0.f, 0.f, 0.f);
     if (MODE == 0 && g.ln_stats) ln_mr = ln_row_stats<BM>(g, m0, tid);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & (STAGES - 1);
@@ -274,7 +274,7 @@ k_gemm(const GemmArgs gin) {
         float2 *lnt = nullptr;
         if (MODE == 0 && g.ln_stats) {                       // the stages are dead after the loop's last barrier
             lnt = reinterpret_cast<float2 *>(lds + 4 * (NT == 4 ? 9216 : 4608));
-            if (tid < 2 * BM && (tid & 1) == 0) lnt[tid >> 1] = ln_mr;
+            ln_table_store<BM>(lnt, ln_mr, tid);
             __syncthreads();
         }
         // ---- epilogue: row-contiguous stores through a per-wave LDS scratch (gemm_common.h) --------

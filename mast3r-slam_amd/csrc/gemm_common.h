@@ -244,9 +244,16 @@ __device__ __forceinline__ RopeFreq rope_freqs(const GemmArgs &g, int lane) {
     for (int k = 0; k < 4; ++k) f.rev[k] = exp2f(-(float)(fi + k) * (g.rope_log2_base * (1.0f / 16.0f))) * 0.15915494309189535f;
     return f;
 }
+// token grid position (y, x) of row m: ONE 8-byte load, issued by the caller for all rows of a pass before any of them is used
+// (read inside rope_load, per (row, block), each 4-byte load was waited for where it stood: eight dependent round trips per
+// pass - most of what the fused rotation cost per tile, found in round 5 by reading the ISA)
+__device__ __forceinline__ int2 rope_pos_of(const GemmArgs &g, int m) {
+    const int mm = m < g.M ? m : g.M - 1;
+    return *reinterpret_cast<const int2 *>(g.rope_pos + (size_t)(mm % g.tokens_per_image) * 2);
+}
 template <int NJ>
 __device__ __forceinline__ void rope_load(const GemmArgs &g, RopeCoef (&cf)[NJ / 2], int m, int n_base, int lane,
-                                          const RopeFreq &fr) {
+                                          const RopeFreq &fr, int2 pyx = int2{0, 0}) {
     const int mm = m < g.M ? m : g.M - 1;
     const int tok = mm % g.tokens_per_image;
     const int fi = (lane >> 4) * 4;
@@ -255,7 +262,7 @@ __device__ __forceinline__ void rope_load(const GemmArgs &g, RopeCoef (&cf)[NJ /
         if (n_base + 32 * blk >= g.rope_cols) continue;                 // wave-uniform: v columns are not rotated
         const int axis = ((n_base + 32 * blk) >> 5) & 1;                 // 0: y, 1: x
         if (g.rope_pos) {                                                // kernel-uniform
-            const float pos = (float)g.rope_pos[tok * 2 + axis];
+            const float pos = (float)(axis ? pyx.y : pyx.x);
             cf[blk].c = make_float4(__builtin_amdgcn_cosf(pos * fr.rev[0]), __builtin_amdgcn_cosf(pos * fr.rev[1]),
                                     __builtin_amdgcn_cosf(pos * fr.rev[2]), __builtin_amdgcn_cosf(pos * fr.rev[3]));
             cf[blk].s = make_float4(__builtin_amdgcn_sinf(pos * fr.rev[0]), __builtin_amdgcn_sinf(pos * fr.rev[1]),
@@ -303,7 +310,7 @@ __device__ __forceinline__ void rope_strip(const GemmArgs &g, f32x4 *t, int m, i
         bj[j] = (g.bias && n_base + j * 16 + fi < g.N) ? *reinterpret_cast<const float4 *>(g.bias + n_base + j * 16 + fi)
                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
     RopeCoef cf[NJ / 2];
-    rope_load<NJ>(g, cf, m, n_base, lane, rope_freqs(g, lane));
+    rope_load<NJ>(g, cf, m, n_base, lane, rope_freqs(g, lane), g.rope_pos ? rope_pos_of(g, m) : int2{0, 0});
     rope_apply<NJ>(g, t, cf, bj, n_base);
 }
 
@@ -321,37 +328,54 @@ __device__ __forceinline__ unsigned dpp_xor1(unsigned v) {
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
 }
 
-// LayerNorm fold, consumer side: mean and 1 / sqrt(var + eps) of the tile's rows -> LDS table float2[ROWS] (written before the
-// kernel's first workgroup barrier, read in the epilogue).  Two threads per row: each adds half of the row's 32-column slots
-// in index order, then low + high - the one summation order of every kernel and tile shape, so a row's statistics do not
-// depend on which kernel multiplies it.  ln_slots is a multiple of 4 (host check); rows past M read the last row.
+// LayerNorm fold, consumer side: mean and 1 / sqrt(var + eps) of the tile's rows.  FOUR threads per PAIR of rows: the
+// statistics are slot-major ([ln_slots][M][2] floats), so the (sum, sum of squares) of two neighbouring rows are one 16-byte
+// load; thread (pair p, quarter c) adds the slots [c S/4, (c + 1) S/4) of rows 2p, 2p + 1 in index order, then the four
+// quarters are added as (q0 + q1) + (q2 + q3) on the DPP path - ONE order in every kernel and tile shape, so a row's
+// statistics do not depend on which kernel multiplies it.  (A first version read 8 bytes per lane, two threads per row:
+// twice the load instructions at half the bytes each - the table cost 2.2 us per tile.)  ln_slots % 4 == 0 and M even
+// (host checks); rows past M read the last pair.  Returns (mean, rstd) of row 2p in .x .y and of row 2p + 1 in .z .w,
+// in all four lanes of the quad; threads >= 2 ROWS return zeros.
 template <int ROWS>
-__device__ __forceinline__ float2 ln_row_stats(const GemmArgs &g, int m0, int tid) {     // (mean, rstd) of row tid >> 1
-    if (tid >= 2 * ROWS) return make_float2(0.f, 0.f);
-    const int row = tid >> 1, half = tid & 1, hs = g.ln_slots >> 1;
-    int m = m0 + row;
-    m = m < g.M ? m : g.M - 1;
-    // statistics are stored slot-major, [ln_slots][M][2]: the rows of a tile are contiguous within a slot (coalesced on both sides)
-    const float2 *p = reinterpret_cast<const float2 *>(g.ln_stats) + (size_t)half * hs * g.M + m;
-    float s = 0.f, q = 0.f;
-    for (int i0 = 0; i0 < hs; i0 += 16) {                    // up to 16 loads in flight
-        float2 v[16];
+__device__ __forceinline__ float4 ln_row_stats(const GemmArgs &g, int m0, int tid) {
+    if (tid >= 2 * ROWS) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const int pair = tid >> 2, quarter = tid & 3, qs = g.ln_slots >> 2;
+    int m = m0 + 2 * pair;
+    m = m < g.M - 1 ? m : g.M - 2;
+    const float4 *p = reinterpret_cast<const float4 *>(g.ln_stats + ((size_t)quarter * qs * g.M + m) * 2);
+    const size_t slot_stride = (size_t)g.M / 2;              // float4 units between consecutive slots
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+    for (int i0 = 0; i0 < qs; i0 += 8) {                     // 8 loads in flight; UNCONDITIONAL loads from clamped addresses,
+        float4 v[8];                                         // the bound applied to the value (a bound on the load makes hipcc
+#pragma unroll                                               // branch around each one and wait for it where it stands)
+        for (int i = 0; i < 8; ++i) v[i] = p[(size_t)(i0 + i < qs ? i0 + i : qs - 1) * slot_stride];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = (i0 + i < hs) ? p[(size_t)(i0 + i) * g.M] : make_float2(0.f, 0.f);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { s += v[i].x; q += v[i].y; }
+        for (int i = 0; i < 8; ++i) {
+            const bool on = i0 + i < qs;
+            s0 += on ? v[i].x : 0.f; q0 += on ? v[i].y : 0.f; s1 += on ? v[i].z : 0.f; q1 += on ? v[i].w : 0.f;
+        }
     }
-    s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, true));
-    q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0xB1, 0xF, 0xF, true));
+    auto quad_sum = [](float v) {
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // lane ^ 1
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // lane ^ 2
+        return v;
+    };
+    s0 = quad_sum(s0); q0 = quad_sum(q0); s1 = quad_sum(s1); q1 = quad_sum(q1);
     const float inv = 1.0f / (float)(g.ln_slots * 32);
-    const float mean = s * inv;
-    const float var = fmaxf(q * inv - mean * mean, 0.f);
-    return make_float2(mean, rsqrtf(var + g.ln_eps));
+    const float mean0 = s0 * inv, mean1 = s1 * inv;
+    const float var0 = fmaxf(q0 * inv - mean0 * mean0, 0.f), var1 = fmaxf(q1 * inv - mean1 * mean1, 0.f);
+    return make_float4(mean0, rsqrtf(var0 + g.ln_eps), mean1, rsqrtf(var1 + g.ln_eps));
+}
+template <int ROWS>
+__device__ __forceinline__ void ln_table_store(float2 *tab, const float4 &mr, int tid) {
+    if (tid < 2 * ROWS && (tid & 3) == 0) {
+        tab[2 * (tid >> 2)] = make_float2(mr.x, mr.y);
+        tab[2 * (tid >> 2) + 1] = make_float2(mr.z, mr.w);
+    }
 }
 template <int ROWS>
 __device__ __forceinline__ void ln_row_table(const GemmArgs &g, float2 *tab, int m0, int tid) {
-    const float2 mr = ln_row_stats<ROWS>(g, m0, tid);
-    if (tid < 2 * ROWS && (tid & 1) == 0) tab[tid >> 1] = mr;
+    ln_table_store<ROWS>(tab, ln_row_stats<ROWS>(g, m0, tid), tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -392,11 +416,23 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
         }
         return;
     }
+    // Bias of this lane's columns: UNCONDITIONAL loads from clamped addresses under one kernel-uniform test, the column bound
+    // applied to the values.  Written as `(bias && n < N) ? load : 0` hipcc branched around every load and waited for each in
+    // turn (s_and_saveexec / global_load / s_waitcnt vmcnt(0), four times): four dependent L2 round trips in front of every
+    // tile's epilogue since round 2 (found in round 5 by reading the ISA for the LayerNorm-fold column sums, same pattern).
     float4 bj[NJ];
+    if (g.bias) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int n = n_base + j * 16 + gq * 4;
-        bj[j] = (g.bias && n < g.N) ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n_base + j * 16 + gq * 4;
+            bj[j] = *reinterpret_cast<const float4 *>(g.bias + (n < g.N ? n : g.N - 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (n_base + j * 16 + gq * 4 >= g.N) bj[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bj[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (F32LDS) {
         // fp32 output of 64-column sub-tiles: unpadded 256-byte rows, 16-byte chunk c of row r at chunk c ^ (r & 7) - the
@@ -417,22 +453,31 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
         // LayerNorm-fold statistics of the sub-tile, staged behind the transpose scratch: [NJ / 2 slots][16 NI rows] float2
         float2 *wst = reinterpret_cast<float2 *>(wlds + ((PR * RS + 15) & ~15));
         uint4 q[RESID_AHEAD ? 2 : 1][RESID ? NIT : 1];
+        // (the kernel-uniform stream-form test stays OUTSIDE the load loop: inside it, hipcc branched around every load and waited
+        //  for each where it stood - 64 dependent round trips per wave in the residual epilogue)
         auto load_resid = [&](int pass, uint4 (&dst)[RESID ? NIT : 1]) {
             if constexpr (RESID) {
+                size_t off[NIT];
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     const int c = it * 64 + lane, rl = c / CPR, ch = c - rl * CPR;
                     int m = m_base + pass * PR + rl, n = n_base + ch * (F32OUT ? 4 : 8);
                     m = m < g.M ? m : g.M - 1;
                     n = n < g.N ? n : 0;
-                    const size_t off = (size_t)m * g.ldc + n;
-                    if (F32OUT && g.C_lo) {                         // kernel-uniform: hi / lo stream, 4 + 4 values of 16 bits
-                        const uint2 hi = *reinterpret_cast<const uint2 *>(reinterpret_cast<const bf16_t *>(g.R) + off);
-                        const uint2 lo = *reinterpret_cast<const uint2 *>(reinterpret_cast<const bf16_t *>(g.R_lo) + off);
+                    off[it] = (size_t)m * g.ldc + n;
+                }
+                if (F32OUT && g.C_lo) {                             // hi / lo stream: 4 + 4 values of 16 bits
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const uint2 hi = *reinterpret_cast<const uint2 *>(reinterpret_cast<const bf16_t *>(g.R) + off[it]);
+                        const uint2 lo = *reinterpret_cast<const uint2 *>(reinterpret_cast<const bf16_t *>(g.R_lo) + off[it]);
                         dst[it] = uint4{hi.x, hi.y, lo.x, lo.y};
-                    } else
-                    dst[it] = F32OUT ? *reinterpret_cast<const uint4 *>(reinterpret_cast<const float *>(g.R) + off)
-                                     : *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16_t *>(g.R) + off);
+                    }
+                } else {
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it)
+                        dst[it] = F32OUT ? *reinterpret_cast<const uint4 *>(reinterpret_cast<const float *>(g.R) + off[it])
+                                         : *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16_t *>(g.R) + off[it]);
                 }
             }
         };
@@ -548,9 +593,9 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
             // both live the 128 x 128 kernel's RoPE instantiation lost its second workgroup per CU)
             float4 csj[NJ];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
+            for (int j = 0; j < NJ; ++j) {                        // unconditional, clamped (columns past N are never stored)
                 const int n = n_base + j * 16 + gq * 4;
-                csj[j] = n < g.N ? *reinterpret_cast<const float4 *>(g.ln_colsum + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                csj[j] = *reinterpret_cast<const float4 *>(g.ln_colsum + (n < g.N ? n : g.N - 4));
             }
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
@@ -567,8 +612,16 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
         for (int pass = 0; pass < NI / TP; ++pass) {
             RopeCoef cf[EPI == EPI_BF16_ROPE ? TP : 1][NJ / 2];
             if constexpr (EPI == EPI_BF16_ROPE) {                 // all coefficient reads of the pass in flight at once
+                int2 pyx[TP];
 #pragma unroll
-                for (int ii = 0; ii < TP; ++ii) rope_load<NJ>(g, cf[ii], m_base + (pass * TP + ii) * 16 + r, n_base, lane, fr);
+                for (int ii = 0; ii < TP; ++ii) pyx[ii] = int2{0, 0};
+                if (g.rope_pos) {                                 // kernel-uniform; the loads below are unconditional
+#pragma unroll
+                    for (int ii = 0; ii < TP; ++ii) pyx[ii] = rope_pos_of(g, m_base + (pass * TP + ii) * 16 + r);
+                }
+#pragma unroll
+                for (int ii = 0; ii < TP; ++ii)
+                    rope_load<NJ>(g, cf[ii], m_base + (pass * TP + ii) * 16 + r, n_base, lane, fr, pyx[ii]);
             }
 #pragma unroll
             for (int ii = 0; ii < TP; ++ii) {

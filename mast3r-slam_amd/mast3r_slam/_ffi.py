@@ -87,6 +87,11 @@ class GemmDesc(C.Structure):
                 ("rope_base", C.c_float), ("q_scale", C.c_float), ("ln_eps", C.c_float)]
 
 
+class PackSeg(C.Structure):
+    """m3_pack_seg of include/m3slam_model.h."""
+    _fields_ = [("src", C.c_void_p), ("dst_off", C.c_int64), ("nbytes", C.c_int64), ("mode", C.c_int32), ("reserved", C.c_int32)]
+
+
 def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 

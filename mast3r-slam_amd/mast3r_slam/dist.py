@@ -73,6 +73,7 @@ class PackedGather:
         dtypes = list(dtypes) if dtypes is not None else [t.dtype for t in like]
         self.meta = [(tuple(t.shape), dt) for t, dt in zip(like, dtypes)]
         spans, total = _layout(self.meta)
+        self.spans = spans
         dev = like[0].device
         self.nccl = dist.get_backend(group) == "nccl"
         self.device = dev
@@ -89,10 +90,32 @@ class PackedGather:
         self.nbytes = total
         self.work = None
 
+    def _snapshot(self, tensors):
+        """tensors -> the packed send buffer.  On the ROCm device: ONE launch of the library's pack kernel (m3_pack_fields: 16 B
+        per lane, int64 -> int32 narrowing for the index field); seven device-to-device copies through the runtime took
+        0.6 ms of copy-kernel time per 8-pair step.  Elsewhere (CPU tensors: the gloo tests) plain copy_."""
+        if self.device.type != "cuda":
+            for v, t in zip(self.send_views, tensors):
+                v.copy_(t)
+            return
+        import ctypes as C
+        from . import _ffi
+        segs = (_ffi.PackSeg * len(tensors))()
+        keep = []
+        for i, ((off, nbytes), (shape, dt), t) in enumerate(zip(self.spans, self.meta, tensors)):
+            if tuple(t.shape) != shape or not t.is_cuda:
+                raise ValueError(f"field {i}: expected a device tensor of shape {shape}, got {tuple(t.shape)} on {t.device}")
+            t = t.contiguous()
+            narrow = t.dtype == torch.int64 and dt == torch.int32
+            if not narrow and t.dtype != dt:
+                t = t.to(dt)                                    # rare: any other conversion goes through torch
+            keep.append(t)
+            segs[i].src, segs[i].dst_off, segs[i].nbytes, segs[i].mode = t.data_ptr(), off, nbytes, 1 if narrow else 0
+        _ffi.call("m3_pack_fields", self.send.data_ptr(), C.addressof(segs), len(tensors), _ffi.stream_ptr())
+
     def post(self, tensors):
         self.wait()
-        for v, t in zip(self.send_views, tensors):
-            v.copy_(t)
+        self._snapshot(tensors)
         if self.nccl:
             self.work = dist.all_gather_into_tensor(self.recv.view(-1), self.send, group=self.group, async_op=True)
         else:

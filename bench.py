@@ -701,7 +701,20 @@ class PairsWorkload:
                 run2()
             e1.record(); torch.cuda.synchronize()
             ms2 = e0.elapsed_time(e1) / 5
+            # the same per-launch measurement of the dense GEMM launches on this trunk (queued behind two graph replays)
+            from mast3r_slam import ops as ops2
+            for _ in range(2):
+                run2()
+            ops2.PROFILE = []
+            net2.reconstruct_batch(self.im1, self.im2)
+            torch.cuda.synchronize()
+            prof2, ops2.PROFILE = ops2.PROFILE, None
+            roof2 = gemm_roofline(prof2)
             result[f"{other}_trunk"] = {"infer_ms": round(ms2, 3), f"{args.precision}_trunk_infer_ms": result["stage_ms"]["infer"],
+                                        "dense_gemm_roofline": {"achieved": roof2["achieved"], "frac": roof2["frac"], "avg_launch_us": roof2["avg_launch_us"],
+                                                                "launches": roof2["launches"],
+                                                                "note": "k_gemm256 dense launches of THIS trunk (no LayerNorm fold on the bf16 trunk: its "
+                                                                        "launches do only the GEMM + epilogue work, the LayerNorms run as 85 separate kernels)"},
                                         "ms_per_step_with_this_infer_leg": round(ms2 + result["stage_ms"]["match"] + result["stage_ms"]["gn"], 3),
                                         "note": "precision='fp16' (load_mast3r's default): fp16 GEMM / q / k operands, bf16 softmax probabilities "
                                                 "and v (M3_DT_F16_PVBF16); precision='bf16': bf16 trunk operands (BASELINE configs[1]); fp16 heads "

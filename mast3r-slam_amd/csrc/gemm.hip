@@ -133,13 +133,21 @@ k_gemm(const GemmArgs gin) {
     const int slices = CAN_SLICE ? g.slices : 1;
     int slice = 0, slice_end = slices > 1 ? (int)((long long)nk * 1 / slices) : nk;
 
-#pragma unroll
-    for (int t0 = 0; t0 < STAGES - 1; ++t0)
-        if (t0 < nk) stage(t0, t0);
-    // LayerNorm fold (kernel-uniform): four threads per row pair fetch the rows' mean / rstd now - under the first loads - and carry
-    // them through the K loop in four registers; the table is written behind the waves' epilogue scratch after the loop
+    // LayerNorm fold (kernel-uniform): four threads per row pair fetch the rows' mean / rstd FIRST - the tile's loads go out
+    // behind them - and carry them through the K loop in four registers; the table is written behind the waves' epilogue
+    // scratch after the loop
     float4 ln_mr = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (MODE == 0 && g.ln_stats) ln_mr = ln_row_stats<BM>(g, m0, tid);
+    if (MODE == 0 && g.ln_stats) {
+        const LnLoads L = ln_row_issue<BM>(g, m0, tid);
+#pragma unroll
+        for (int t0 = 0; t0 < STAGES - 1; ++t0)
+            if (t0 < nk) stage(t0, t0);
+        ln_mr = ln_row_finish<BM>(g, L, m0, tid);
+    } else {
+#pragma unroll
+        for (int t0 = 0; t0 < STAGES - 1; ++t0)
+            if (t0 < nk) stage(t0, t0);
+    }
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & (STAGES - 1);
         // refill the stage the previous iteration finished with (its trailing barrier orders the fragment reads before this)
@@ -580,10 +588,10 @@ int m3_gemm_ex(const m3_gemm_desc *d, void *stream) {
     }
     if (d->ln_stats) {                     // LayerNorm fold, consumer
         M3_REQUIRE(!f32out && epi != EPI_BF16_ADD && d->ln_colsum && d->ln_slots * 32 == d->K && d->ln_slots % 4 == 0 &&
-                   d->ln_eps > 0.0f && (reinterpret_cast<size_t>(d->ln_stats) & 7) == 0 &&
+                   d->ln_eps > 0.0f && d->M % 2 == 0 && (reinterpret_cast<size_t>(d->ln_stats) & 15) == 0 &&
                    (reinterpret_cast<size_t>(d->ln_colsum) & 15) == 0 && (reinterpret_cast<size_t>(d->C) & 15) == 0 &&
                    d->ldc % 8 == 0 && d->N % 8 == 0);
-        if (groups == 2) M3_REQUIRE(d->ln_colsum1 && (reinterpret_cast<size_t>(d->ln_colsum1) & 15) == 0 && d->ln_gstride % 2 == 0);
+        if (groups == 2) M3_REQUIRE(d->ln_colsum1 && (reinterpret_cast<size_t>(d->ln_colsum1) & 15) == 0 && d->ln_gstride % 4 == 0);
     }
     GemmArgs a{};
     a.A = (const bf16_t *)d->A; a.W = (const bf16_t *)d->W; a.W2 = (const bf16_t *)d->W1; a.bias = d->bias; a.bias2 = d->bias1;

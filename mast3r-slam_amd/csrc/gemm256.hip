@@ -168,12 +168,15 @@ k_gemm256(const GemmArgs gin) {
 
     // prologue: tile 0 into stage 0, visible to everyone; LayerNorm fold: the rows' mean / rstd table goes into the 2 KiB
     // behind the stages while those first loads fly (dense launches only)
-    stage(0, 0);
-    float2 *lnt = nullptr;
-    if (MODE == 0 && g.ln_stats) {                           // kernel-uniform
-        lnt = reinterpret_cast<float2 *>(lds + 2 * kStageBytes);
-        ln_row_table<BM>(g, lnt, m0, tid);
+    if (MODE == 0 && g.ln_stats) {                           // kernel-uniform; the statistics loads go out FIRST, the tile's
+        float2 *lnt = reinterpret_cast<float2 *>(lds + 2 * kStageBytes);   // LDS-DMA behind them: the table arithmetic then
+        const LnLoads L = ln_row_issue<BM>(g, m0, tid);                    // runs while the first K-tile is still in flight
+        stage(0, 0);
+        ln_table_store<BM>(lnt, ln_row_finish<BM>(g, L, m0, tid), tid);
+    } else {
+        stage(0, 0);
     }
+    float2 *lnt = (MODE == 0 && g.ln_stats) ? reinterpret_cast<float2 *>(lds + 2 * kStageBytes) : nullptr;
     phase_end_wait();
 
     if (group == 0) {

@@ -335,24 +335,46 @@ __device__ __forceinline__ unsigned dpp_xor1(unsigned v) {
 // statistics do not depend on which kernel multiplies it.  (A first version read 8 bytes per lane, two threads per row:
 // twice the load instructions at half the bytes each - the table cost 2.2 us per tile.)  ln_slots % 4 == 0 and M even
 // (host checks); rows past M read the last pair.  Returns (mean, rstd) of row 2p in .x .y and of row 2p + 1 in .z .w,
-// in all four lanes of the quad; threads >= 2 ROWS return zeros.
+// in all four lanes of the quad; threads >= 2 ROWS repeat pair 0's work (uniform control flow; ln_table_store ignores them).
+struct LnLoads { float4 v[8]; };
+// first half: the loads of the first 8 slots of the thread's quarter go out (and stay in flight: a kernel puts its first
+// K-tile's loads between the two halves, so the statistics' latency and arithmetic run under the tile's)
 template <int ROWS>
-__device__ __forceinline__ float4 ln_row_stats(const GemmArgs &g, int m0, int tid) {
-    if (tid >= 2 * ROWS) return make_float4(0.f, 0.f, 0.f, 0.f);
-    const int pair = tid >> 2, quarter = tid & 3, qs = g.ln_slots >> 2;
+__device__ __forceinline__ LnLoads ln_row_issue(const GemmArgs &g, int m0, int tid) {
+    LnLoads L;
+    const int pair = (tid < 2 * ROWS ? tid : 0) >> 2, quarter = tid & 3, qs = g.ln_slots >> 2;
     int m = m0 + 2 * pair;
     m = m < g.M - 1 ? m : g.M - 2;
     const float4 *p = reinterpret_cast<const float4 *>(g.ln_stats + ((size_t)quarter * qs * g.M + m) * 2);
     const size_t slot_stride = (size_t)g.M / 2;              // float4 units between consecutive slots
+#pragma unroll                                               // UNCONDITIONAL loads from clamped addresses, the bound applied to
+    for (int i = 0; i < 8; ++i)                              // the value (a bound on the load makes hipcc branch around each one
+        L.v[i] = p[(size_t)(i < qs ? i : qs - 1) * slot_stride];      // and wait for it where it stands)
+    return L;
+}
+template <int ROWS>
+__device__ __forceinline__ float4 ln_row_finish(const GemmArgs &g, const LnLoads &L, int m0, int tid) {
+    const int pair = (tid < 2 * ROWS ? tid : 0) >> 2, quarter = tid & 3, qs = g.ln_slots >> 2;
     float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-    for (int i0 = 0; i0 < qs; i0 += 8) {                     // 8 loads in flight; UNCONDITIONAL loads from clamped addresses,
-        float4 v[8];                                         // the bound applied to the value (a bound on the load makes hipcc
-#pragma unroll                                               // branch around each one and wait for it where it stands)
-        for (int i = 0; i < 8; ++i) v[i] = p[(size_t)(i0 + i < qs ? i0 + i : qs - 1) * slot_stride];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const bool on = i0 + i < qs;
-            s0 += on ? v[i].x : 0.f; q0 += on ? v[i].y : 0.f; s1 += on ? v[i].z : 0.f; q1 += on ? v[i].w : 0.f;
+    for (int i = 0; i < 8; ++i) {
+        const bool on = i < qs;
+        s0 += on ? L.v[i].x : 0.f; q0 += on ? L.v[i].y : 0.f; s1 += on ? L.v[i].z : 0.f; q1 += on ? L.v[i].w : 0.f;
+    }
+    if (qs > 8) {                                            // kernel-uniform; wider rows than 1024 columns: the rest in place
+        int m = m0 + 2 * pair;
+        m = m < g.M - 1 ? m : g.M - 2;
+        const float4 *p = reinterpret_cast<const float4 *>(g.ln_stats + ((size_t)quarter * qs * g.M + m) * 2);
+        const size_t slot_stride = (size_t)g.M / 2;
+        for (int i0 = 8; i0 < qs; i0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = p[(size_t)(i0 + i < qs ? i0 + i : qs - 1) * slot_stride];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool on = i0 + i < qs;
+                s0 += on ? v[i].x : 0.f; q0 += on ? v[i].y : 0.f; s1 += on ? v[i].z : 0.f; q1 += on ? v[i].w : 0.f;
+            }
         }
     }
     auto quad_sum = [](float v) {
@@ -365,6 +387,10 @@ __device__ __forceinline__ float4 ln_row_stats(const GemmArgs &g, int m0, int ti
     const float mean0 = s0 * inv, mean1 = s1 * inv;
     const float var0 = fmaxf(q0 * inv - mean0 * mean0, 0.f), var1 = fmaxf(q1 * inv - mean1 * mean1, 0.f);
     return make_float4(mean0, rsqrtf(var0 + g.ln_eps), mean1, rsqrtf(var1 + g.ln_eps));
+}
+template <int ROWS>
+__device__ __forceinline__ float4 ln_row_stats(const GemmArgs &g, int m0, int tid) {
+    return ln_row_finish<ROWS>(g, ln_row_issue<ROWS>(g, m0, tid), m0, tid);
 }
 template <int ROWS>
 __device__ __forceinline__ void ln_table_store(float2 *tab, const float4 &mr, int tid) {

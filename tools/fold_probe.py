@@ -33,6 +33,7 @@ for M in (16384, 2048):
     runs = {
         "layernorm kernel": lambda: ops.layernorm(x, gam, bet, dtype=torch.float16),
         "fc1+gelu plain": lambda: ops.gemm(xn, w1, b1, ops.EPI_BF16_GELU),
+        "fc1+gelu plain, A = hi plane": lambda: ops.gemm(hl[0], w1, b1, ops.EPI_BF16_GELU),
         "fc1+gelu folded": lambda: ops.gemm_ex(hl[0], w1, b1, ops.EPI_BF16_GELU, fold_in=(hl[2], cs1)),
         "qkv+rope plain": lambda: ops.gemm_rope(xn, wq, bq, pos, 2048, q_cols=1024, q_scale=0.18),
         "qkv+rope folded": lambda: ops.gemm_ex(hl[0], wq, bq, ops.EPI_BF16_ROPE, rope=(pos, 2048, 1024, 0.18), fold_in=(hl[2], csq)),

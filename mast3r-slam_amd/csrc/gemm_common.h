@@ -336,6 +336,14 @@ __device__ __forceinline__ unsigned dpp_xor1(unsigned v) {
 // twice the load instructions at half the bytes each - the table cost 2.2 us per tile.)  ln_slots % 4 == 0 and M even
 // (host checks); rows past M read the last pair.  Returns (mean, rstd) of row 2p in .x .y and of row 2p + 1 in .z .w,
 // in all four lanes of the quad; threads >= 2 ROWS repeat pair 0's work (uniform control flow; ln_table_store ignores them).
+// (mean, 1 / sqrt(var + eps)) of a row from its sum and sum of squares over 32 * slots columns, in ONE spelled-out operation
+// sequence, so each kernel that builds a row table gets the same bits
+__device__ __forceinline__ float2 ln_mean_rstd(float s, float q, int slots, float eps) {
+    const float inv = 1.0f / (float)(slots * 32);
+    const float mean = s * inv;
+    const float var = fmaxf(__builtin_fmaf(-mean, mean, q * inv), 0.f);      // the fma spelled out: hipcc contracts a * b - c * d
+    return make_float2(mean, rsqrtf(var + eps));                             // as it likes per call site (__fmul_rn does not stop it)
+}
 struct LnLoads { float4 v[8]; };
 // first half: the loads of the first 8 slots of the thread's quarter go out (and stay in flight: a kernel puts its first
 // K-tile's loads between the two halves, so the statistics' latency and arithmetic run under the tile's)
@@ -383,10 +391,8 @@ __device__ __forceinline__ float4 ln_row_finish(const GemmArgs &g, const LnLoads
         return v;
     };
     s0 = quad_sum(s0); q0 = quad_sum(q0); s1 = quad_sum(s1); q1 = quad_sum(q1);
-    const float inv = 1.0f / (float)(g.ln_slots * 32);
-    const float mean0 = s0 * inv, mean1 = s1 * inv;
-    const float var0 = fmaxf(q0 * inv - mean0 * mean0, 0.f), var1 = fmaxf(q1 * inv - mean1 * mean1, 0.f);
-    return make_float4(mean0, rsqrtf(var0 + g.ln_eps), mean1, rsqrtf(var1 + g.ln_eps));
+    const float2 a = ln_mean_rstd(s0, q0, g.ln_slots, g.ln_eps), b = ln_mean_rstd(s1, q1, g.ln_slots, g.ln_eps);
+    return make_float4(a.x, a.y, b.x, b.y);
 }
 template <int ROWS>
 __device__ __forceinline__ float4 ln_row_stats(const GemmArgs &g, int m0, int tid) {

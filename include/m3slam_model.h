@@ -132,6 +132,10 @@ typedef struct m3_gemm_desc {
     int32_t M, N, K, ldc, epilogue, dtype, groups;
     int32_t tokens_per_image, rope_cols, q_cols, ln_slots;
     float rope_base, q_scale, ln_eps;
+    int32_t rope_max_pos;              /* RoPE: > 0 promises that every entry of rope_pos is in [0, rope_max_pos) and rope_max_pos <= 64  */
+                                       /* (a 1024-pixel side): each workgroup then builds the rope_max_pos x 16 cos / sin table once in   */
+                                       /* LDS instead of eight v_sin / v_cos per lane, row and 32-column block (same values bit for bit). */
+                                       /* 0 (or > 64): computed per element.  A position outside the promise takes the last table row.    */
 } m3_gemm_desc;
 int m3_gemm_ex(const m3_gemm_desc *desc, void *stream);
 
@@ -257,6 +261,12 @@ int m3_layernorm_bf16_grouped2(const float *x, const float *gamma0, const float 
 int m3_layernorm_grouped2_dt(const float *x, const float *gamma0, const float *beta0, const float *gamma1,
                              const float *beta1, void *y, int M, int C, int in_row_shift, float eps,
                              int dtype, void *stream);
+/* LayerNorm of a residual stream kept as two fp16 planes (x = float(hi) + float(lo); m3_gemm_desc.c16 / c_lo): rows
+ * [0, split) use (gamma0, beta0), rows [split, rows) use (gamma1, beta1).  Equals m3_layernorm_dt on hi + lo bit for bit.
+ * Replaces the reference's enc_norm / dec_norm module calls on the fp16 trunk (the encoder / decoder forward the reference
+ * calls at mast3r_utils.py:278-294). */
+int m3_layernorm_hl_dt(const void *hi, const void *lo, const float *gamma0, const float *beta0, const float *gamma1,
+                       const float *beta1, void *y, int rows, int C, int split, float eps, int dtype, void *stream);
 /* Decoder block entry: two LayerNorms of the SAME rows in one pass.  x f32 [2,M,C] (two branches);
  * y_own[g][r] = LN(x[g][r]; ga_g, ba_g) (norm1) and y_cross[1-g][r] = LN(x[g][r]; gb_(1-g), bb_(1-g)) (norm_y: the
  * tokens of branch g as the other branch's cross-attention memory).  Bit-identical to m3_layernorm_grouped2_dt called

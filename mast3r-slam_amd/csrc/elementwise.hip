@@ -27,22 +27,40 @@ template <int DT> __device__ __forceinline__ bf16_t from_f32(float f) { return (
 
 // ---------------------------------------------------------------- LayerNorm: one wave per row
 // x f32 [M,C] -> y bf16 [M,C]; two-pass statistics in fp32 from registers (row read once).
-template <int VPL /* float4 per lane */, int DT>
+// HL: the input is a residual stream kept as two fp16 planes, x = float(hi) + float(lo) (LayerNorm fold, gemm_common.h); `x` then
+// points at the hi plane and `lo` at the lo plane.  Same arithmetic behind the loads, so the result equals the fp32-input kernel on
+// hi.float() + lo.float() bit for bit.
+template <int VPL /* float4 per lane */, int DT, bool HL = false>
 __global__ void __launch_bounds__(kThreads)
 k_layernorm(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
             const float *__restrict__ gamma2, const float *__restrict__ beta2, bf16_t *__restrict__ y, int M, int C,
-            int split, int in_shift, float eps) {
+            int split, int in_shift, float eps, const bf16_t *__restrict__ lo = nullptr) {
     const int row = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
     if (row >= M) return;
     const int lane = threadIdx.x & 63;
     if (row >= split) { gamma = gamma2; beta = beta2; }
     int in_row = row + in_shift;
     in_row = in_row >= M ? in_row - M : in_row;
-    const float4 *xr = reinterpret_cast<const float4 *>(x + (size_t)in_row * C);
     float4 v[VPL];
     float s = 0.f;
+    if constexpr (HL) {
+        const uint2 *hr = reinterpret_cast<const uint2 *>(reinterpret_cast<const bf16_t *>(x) + (size_t)in_row * C);
+        const uint2 *lr = reinterpret_cast<const uint2 *>(lo + (size_t)in_row * C);
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) { v[i] = xr[lane + 64 * i]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+        for (int i = 0; i < VPL; ++i) {
+            const uint2 h = hr[lane + 64 * i], l = lr[lane + 64 * i];
+            v[i] = make_float4(m3gemm::lo16<m3gemm::DT_F16>(h.x) + m3gemm::lo16<m3gemm::DT_F16>(l.x),
+                               m3gemm::hi16<m3gemm::DT_F16>(h.x) + m3gemm::hi16<m3gemm::DT_F16>(l.x),
+                               m3gemm::lo16<m3gemm::DT_F16>(h.y) + m3gemm::lo16<m3gemm::DT_F16>(l.y),
+                               m3gemm::hi16<m3gemm::DT_F16>(h.y) + m3gemm::hi16<m3gemm::DT_F16>(l.y));
+        }
+    } else {
+        const float4 *xr = reinterpret_cast<const float4 *>(x + (size_t)in_row * C);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) v[i] = xr[lane + 64 * i];
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     const float mean = s / (float)C;
@@ -444,6 +462,19 @@ int m3_layernorm_grouped2_dt(const float *x, const float *gamma0, const float *b
     if (dtype == DT_F16) { M3_LN_CASES(DT_F16) } else { M3_LN_CASES(DT_BF16) }
 #undef M3_LN
     M3_CHECK_LAUNCH("m3_layernorm_grouped2");
+    return M3_OK;
+}
+int m3_layernorm_hl_dt(const void *hi, const void *lo, const float *gamma0, const float *beta0, const float *gamma1,
+                       const float *beta1, void *y, int rows, int C, int split, float eps, int dtype, void *stream) {
+    M3_REQUIRE(hi && lo && gamma0 && beta0 && gamma1 && beta1 && y && rows > 0 && split >= 0 && C > 0 && C % 256 == 0 && C <= 2048);
+    M3_REQUIRE(((reinterpret_cast<size_t>(hi) | reinterpret_cast<size_t>(lo)) & 7) == 0);
+    M3_DT_OK(dtype);
+    dim3 grid(m3_cdiv(rows, kThreads / 64)), blk(kThreads);
+    hipStream_t st = (hipStream_t)stream;
+#define M3_LN(V, DTV) case V: hipLaunchKernelGGL((k_layernorm<V, DTV, true>), grid, blk, 0, st, (const float *)hi, gamma0, beta0, gamma1, beta1, (bf16_t *)y, rows, C, split, 0, eps, (const bf16_t *)lo); break
+    if (dtype == DT_F16) { M3_LN_CASES(DT_F16) } else { M3_LN_CASES(DT_BF16) }
+#undef M3_LN
+    M3_CHECK_LAUNCH("m3_layernorm_hl");
     return M3_OK;
 }
 int m3_layernorm_bf16_grouped2(const float *x, const float *gamma0, const float *beta0, const float *gamma1,

@@ -42,6 +42,7 @@ k_gemm(const GemmArgs gin) {
     // LDS stages (the loop below takes any power of two): two.  Four for T = 64 (three K-tiles in flight) were measured in
     // round 5 at one pair per step - no change, see M3_GEMM64_STAGES
     constexpr int STAGES = k_gemm_stages(T);
+    static_assert(4 * (NT == 4 ? 9216 : 4608) + BM * 8 + kRopeTableRows * 128 <= STAGES * kStageBytes, "row table + RoPE table behind the scratch");
     GemmArgs g = select_group<EPI>(gin, blockIdx.y);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -286,8 +287,19 @@ k_gemm(const GemmArgs gin) {
             __syncthreads();
         }
         // ---- epilogue: row-contiguous stores through a per-wave LDS scratch (gemm_common.h) --------
-        epilogue_rows<EPI, NT, NT, DT>(g, acc, lds + wave * (NT == 4 ? 9216 : 4608), m0 + wr * (T / 2), n0 + wc * (T / 2), lane, lnt,
-                                       wr * (T / 2));
+        const float *ropet = nullptr;
+        if constexpr (EPI == EPI_BF16_ROPE && MODE == 0) {
+            if (g.rope_pos && g.rope_pmax > 0) {             // kernel-uniform: cos / sin of every (position, frequency), once per
+                float *tab = reinterpret_cast<float *>(lds + 4 * (NT == 4 ? 9216 : 4608) + BM * 8);   // workgroup, behind scratch + row table
+                rope_table_build(g, tab, tid, kThreads);
+                __syncthreads();
+                ropet = tab;
+            }
+        }
+        // (the RoPE instantiation of the 128 x 128 tile: two row tiles per pass instead of four - half the coefficient sets live -
+        // keeps it at two workgroups per CU: 260 -> 2xx registers)
+        epilogue_rows<EPI, NT, NT, DT, (EPI == EPI_BF16_ROPE && T == 128) ? 2 : 4>(g, acc, lds + wave * (NT == 4 ? 9216 : 4608), m0 + wr * (T / 2),
+                                                                                  n0 + wc * (T / 2), lane, lnt, wr * (T / 2), ropet);
     }
 }
 
@@ -601,6 +613,7 @@ int m3_gemm_ex(const m3_gemm_desc *d, void *stream) {
     if (rope) {
         a.rope_pos = d->rope_pos; a.rope_log2_base = log2f(d->rope_base); a.tokens_per_image = d->tokens_per_image;
         a.rope_cols = d->rope_cols; a.q_cols = d->q_cols; a.q_scale = d->q_scale;
+        a.rope_pmax = (d->rope_max_pos > 0 && d->rope_max_pos <= kRopeTableRows) ? d->rope_max_pos : 0;
     }
     a.C16 = d->c16; a.stats_out = d->stats_out; a.stats_gstride = d->stats_gstride;
     a.R_lo = d->r_lo; a.C_lo = d->c_lo;

@@ -36,6 +36,7 @@ k_gemm256(const GemmArgs gin) {
     constexpr int NI = BM / WM / 16, NJ = BN / WN / 16;     // MFMA tiles per wave: 8 x 4 or 4 x 6
     constexpr int WISS = BN / 64;                           // 64-row global_load_lds issues of the W tile
     constexpr int kStageBytes = (BM + BN) * BK * 2;         // 64 KiB / 56 KiB
+    static_assert(8 * (64 * (32 * NJ + 16)) + kRopeTableRows * 128 <= 2 * kStageBytes, "RoPE table behind the epilogue scratch");
     const GemmArgs g = select_group<EPI>(gin, blockIdx.y);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -218,8 +219,17 @@ k_gemm256(const GemmArgs gin) {
 
     // epilogue: the operand stages are dead after the last barrier; each wave transposes its sub-tile
     // through a private LDS scratch (9 / 13 KiB) and stores full rows (gemm_common.h)
+    const float *ropet = nullptr;
+    if constexpr (EPI == EPI_BF16_ROPE && MODE == 0) {
+        if (g.rope_pos && g.rope_pmax > 0) {                 // kernel-uniform: the rotation's cos / sin table, once per workgroup, in
+            float *tab = reinterpret_cast<float *>(lds + 8 * (64 * (32 * NJ + 16)));     // the 56 / 8 KiB of dead stages behind the
+            rope_table_build(g, tab, tid, kThreads);                                      // eight waves' scratch
+            __syncthreads();
+            ropet = tab;
+        }
+    }
     epilogue_rows<EPI, NI, NJ, DT>(g, acc, lds + wave * (64 * (32 * NJ + 16)), m0 + wr * (16 * NI), n0 + wc * (16 * NJ), lane, lnt,
-                                   wr * (16 * NI));
+                                   wr * (16 * NI), ropet);
 }
 
 template <int MODE, int BN, int DT>

@@ -115,6 +115,8 @@ struct GemmArgs {
     const int *rope_pos;    // [tokens_per_image, 2 (y|x)] grid positions - cos/sin are then computed in the epilogue
     float rope_log2_base;   //   from frequencies base^(-i/16), i = 0..15 (v_sin_f32 / v_cos_f32, arguments in revolutions)
     int tokens_per_image, rope_cols;
+    int rope_pmax;          //   position mode: > 0 = every position is in [0, rope_pmax) (<= kRopeTableRows): the kernels then build
+                            //   the cos / sin of all rope_pmax x 16 (position, frequency) pairs ONCE per workgroup in LDS
     int q_cols;             // columns < q_cols (the q heads) are multiplied by q_scale after the rotation, before the
     float q_scale;          // 16-bit rounding: softmax scale * log2(e) folded into q (attention then needs no per-score FMA)
     // grouped launch (blockIdx.y = group): group 1 uses W2/bias2 and A/C/R advanced by the strides
@@ -244,6 +246,22 @@ __device__ __forceinline__ RopeFreq rope_freqs(const GemmArgs &g, int lane) {
     for (int k = 0; k < 4; ++k) f.rev[k] = exp2f(-(float)(fi + k) * (g.rope_log2_base * (1.0f / 16.0f))) * 0.15915494309189535f;
     return f;
 }
+// LDS table of the rotation coefficients, position mode: rows of 32 floats, row p = cos(p f_i), i = 0..15 | sin(p f_i), i = 0..15
+// - the SAME expressions as the per-lane computation in rope_load (same bits).  Per 32-column block and row a lane then reads
+// two 16-byte LDS words instead of issuing eight transcendentals: in the 256 x 256 tile a lane owns 32 rows x 2 blocks = 512
+// v_sin / v_cos (quarter rate: ~16 cycles each per wave), 6.8 us per tile with two waves per SIMD - all of what the fused
+// rotation cost per launch (12.6 us of the 16384 x 3072 x 1024 projection); and every wave column / N-tile recomputed the same
+// 64 values per token.  Built after the K loop in stage memory the epilogue scratch does not reach; the caller synchronises.
+constexpr int kRopeTableRows = 64;                  // positions 0..63: images up to 1024 x 1024 pixels (8 KiB)
+__device__ __forceinline__ void rope_table_build(const GemmArgs &g, float *tab, int tid, int nthreads) {
+    for (int e = tid; e < g.rope_pmax * 16; e += nthreads) {
+        const int p = e >> 4, f = e & 15;
+        const float rev = exp2f(-(float)f * (g.rope_log2_base * (1.0f / 16.0f))) * 0.15915494309189535f;
+        const float ang = (float)p * rev;
+        tab[p * 32 + f] = __builtin_amdgcn_cosf(ang);
+        tab[p * 32 + 16 + f] = __builtin_amdgcn_sinf(ang);
+    }
+}
 // token grid position (y, x) of row m: ONE 8-byte load, issued by the caller for all rows of a pass before any of them is used
 // (read inside rope_load, per (row, block), each 4-byte load was waited for where it stood: eight dependent round trips per
 // pass - most of what the fused rotation cost per tile, found in round 5 by reading the ISA)
@@ -253,7 +271,7 @@ __device__ __forceinline__ int2 rope_pos_of(const GemmArgs &g, int m) {
 }
 template <int NJ>
 __device__ __forceinline__ void rope_load(const GemmArgs &g, RopeCoef (&cf)[NJ / 2], int m, int n_base, int lane,
-                                          const RopeFreq &fr, int2 pyx = int2{0, 0}) {
+                                          const RopeFreq &fr, int2 pyx = int2{0, 0}, const float *ropet = nullptr) {
     const int mm = m < g.M ? m : g.M - 1;
     const int tok = mm % g.tokens_per_image;
     const int fi = (lane >> 4) * 4;
@@ -261,7 +279,13 @@ __device__ __forceinline__ void rope_load(const GemmArgs &g, RopeCoef (&cf)[NJ /
     for (int blk = 0; blk < NJ / 2; ++blk) {
         if (n_base + 32 * blk >= g.rope_cols) continue;                 // wave-uniform: v columns are not rotated
         const int axis = ((n_base + 32 * blk) >> 5) & 1;                 // 0: y, 1: x
-        if (g.rope_pos) {                                                // kernel-uniform
+        if (ropet) {                                                     // kernel-uniform: the workgroup's LDS table
+            int p = axis ? pyx.y : pyx.x;
+            p = p < g.rope_pmax ? p : g.rope_pmax - 1;                   // (a position outside the promised range: no stray read)
+            const float *row = ropet + p * 32 + fi;
+            cf[blk].c = *reinterpret_cast<const float4 *>(row);
+            cf[blk].s = *reinterpret_cast<const float4 *>(row + 16);
+        } else if (g.rope_pos) {                                         // kernel-uniform
             const float pos = (float)(axis ? pyx.y : pyx.x);
             cf[blk].c = make_float4(__builtin_amdgcn_cosf(pos * fr.rev[0]), __builtin_amdgcn_cosf(pos * fr.rev[1]),
                                     __builtin_amdgcn_cosf(pos * fr.rev[2]), __builtin_amdgcn_cosf(pos * fr.rev[3]));
@@ -432,7 +456,8 @@ __device__ __forceinline__ void ln_row_table(const GemmArgs &g, float2 *tab, int
 // ALIGNED = true: the host has checked the alignment conditions below, the element-wise fallback is not compiled in.
 template <int EPI, int NI, int NJ = 4, int DT = DT_BF16, int TPMAX = 4, bool RESID_AHEAD = true, bool ALIGNED = false>
 __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI][NJ], unsigned char *wlds,
-                                              int m_base, int n_base, int lane, const float2 *lnt = nullptr, int lrow = 0) {
+                                              int m_base, int n_base, int lane, const float2 *lnt = nullptr, int lrow = 0,
+                                              const float *ropet = nullptr) {
     constexpr bool F32OUT = (EPI == EPI_F32 || EPI == EPI_F32_ACCUM);
     constexpr bool F32LDS = F32OUT || EPI == EPI_BF16_ADD;        // keep one rounding for the bf16 residual add
     const int r = lane & 15, gq = lane >> 4;
@@ -618,7 +643,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
         constexpr int TP = NI < TPMAX ? NI : TPMAX;               // accumulator row tiles per pass (TPMAX: register budget)
         constexpr int PR = 16 * TP, CPR = NJ * 2;                 // rows per pass, 16-byte chunks (8 columns) per row
         RopeFreq fr{};
-        if constexpr (EPI == EPI_BF16_ROPE) { if (g.rope_pos) fr = rope_freqs(g, lane); }
+        if constexpr (EPI == EPI_BF16_ROPE) { if (g.rope_pos && !ropet) fr = rope_freqs(g, lane); }
         if (lnt) {
             // LayerNorm fold (kernel-uniform), before any bias: acc <- rstd[m] * (acc - mean[m] * colsum[n]).  Done for the whole
             // sub-tile up front so that the column sums are dead before the RoPE coefficients of the passes become live (with
@@ -653,7 +678,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
                 }
 #pragma unroll
                 for (int ii = 0; ii < TP; ++ii)
-                    rope_load<NJ>(g, cf[ii], m_base + (pass * TP + ii) * 16 + r, n_base, lane, fr, pyx[ii]);
+                    rope_load<NJ>(g, cf[ii], m_base + (pass * TP + ii) * 16 + r, n_base, lane, fr, pyx[ii], ropet);
             }
 #pragma unroll
             for (int ii = 0; ii < TP; ++ii) {

@@ -379,7 +379,8 @@ class Mast3rFull:
             if float(self.cfg["rope_base"]) != ops.ROPE_BASE:
                 raise ValueError(f"rope_base {self.cfg['rope_base']} is not supported by the fused epilogue ({ops.ROPE_BASE})")
             gy, gx = torch.meshgrid(torch.arange(gh), torch.arange(gw), indexing="ij")
-            self._rope_cache[key] = torch.stack([gy.reshape(-1), gx.reshape(-1)], -1).to(torch.int32).to(self.device).contiguous()
+            pos = torch.stack([gy.reshape(-1), gx.reshape(-1)], -1).to(torch.int32).to(self.device).contiguous()
+            self._rope_cache[key] = ops.rope_bound(pos, max(gh, gw))      # positions < max(gh, gw): the epilogues' LDS cos / sin table
         return self._rope_cache[key]
 
     def _as_images(self, img) -> torch.Tensor:
@@ -460,7 +461,7 @@ class Mast3rFull:
             ops.gemm_ex(a, P[p + ".attn.proj.w"], P[p + ".attn.proj.b"], ops.EPI_F32_ACCUM, hl=hl)
             hdn = ops.gemm_ex(x16, P[p + ".mlp.fc1.fw"], P[p + ".mlp.fc1.fb"], ops.EPI_BF16_GELU, fold_in=(st, P[p + ".mlp.fc1.fcs"]))
             ops.gemm_ex(hdn, P[p + ".mlp.fc2.w"], P[p + ".mlp.fc2.b"], ops.EPI_F32_ACCUM, hl=hl)
-        return ops.layernorm(ops.hl_to_f32(hl), P["enc_norm.g"], P["enc_norm.b"], dtype=dt)      # enc_norm stays a kernel
+        return ops.layernorm_hl(hl, P["enc_norm.g"], P["enc_norm.b"], dtype=dt)                  # enc_norm stays a kernel (reads the planes)
 
     def encode(self, img):
         """model.encode(img) (mast3r_utils.py:278): uint8 [H,W,3] -> tokens [T,1024] (16-bit tensor of the trunk type);
@@ -593,8 +594,7 @@ class Mast3rFull:
             layer = i + 1
             if layer in hooks:
                 if layer == c["dec_depth"]:
-                    tap = ops.layernorm_grouped2(ops.hl_to_f32(hl), P["dec_norm.g"], P["dec_norm.b"], P["dec_norm.g"], P["dec_norm.b"],
-                                                 dtype=hdt)
+                    tap = ops.layernorm_hl(hl, P["dec_norm.g"], P["dec_norm.b"], P["dec_norm.g"], P["dec_norm.b"], dtype=hdt)
                 elif hdt == dt:
                     tap = x16.clone()                      # the hi plane IS the stream rounded to the heads' type
                 else:

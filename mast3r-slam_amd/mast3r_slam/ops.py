@@ -11,6 +11,7 @@ import os
 import ctypes as C
 
 import torch
+from torch.utils.weak import WeakTensorKeyDictionary
 
 from . import _ffi
 
@@ -124,6 +125,26 @@ QK_PRESCALE = 0.125 * 1.4426950408889634     # softmax scale (head dim 64) * log
 ROPE_BASE = 100.0                            # CroCo "RoPE100"
 
 
+_ROPE_BOUND = WeakTensorKeyDictionary()       # keyed by tensor identity, dropped with the tensor
+
+
+def rope_bound(pos_yx, bound: int):
+    """Promise that every entry of the int32 position tensor `pos_yx` is in [0, bound): the RoPE epilogues given this tensor then
+    build their cos / sin table once per workgroup in LDS (m3_gemm_desc.rope_max_pos; same values, ~12 us less per 16384-row
+    projection).  Returns the tensor.  Without the promise (or bound > 64) the coefficients are computed per element."""
+    if pos_yx.dtype != torch.int32 or bound < 1:
+        raise ValueError("rope_bound: int32 positions and a positive bound")
+    _ROPE_BOUND[pos_yx] = int(bound)
+    return pos_yx
+
+
+def _rope_pmax(t) -> int:
+    if os.environ.get("M3_ROPE_TABLE", "1") == "0":            # A/B switch: per-element v_sin / v_cos (same results)
+        return 0
+    b = _ROPE_BOUND.get(t, 0) if isinstance(t, torch.Tensor) else 0
+    return b if 0 < b <= 64 else 0
+
+
 def _rope_table(t):
     """The `rope` operand of the fused epilogue: int32 [T,2] grid positions (y, x) - cos/sin computed in the kernel -
     or float32 [T,2,2,16] per-token cos/sin table (rope_token_table).  Returns (tensor, tokens_per_image, by_position)."""
@@ -146,6 +167,8 @@ def gemm_rope(a, w, bias, rope_tok, rope_cols: int, q_cols: int = 0, q_scale: fl
     dt = _pv_code(_same16(a, w), pv_bf16)
     m, k = a.shape
     n = w.shape[0]
+    if by_pos and float(base) == ROPE_BASE:                   # the descriptor entry point carries the position bound (rope_bound)
+        return gemm_ex(a, w, bias, EPI_BF16_ROPE, rope=(rope_tok, rope_cols, q_cols, q_scale), pv_bf16=pv_bf16)
     out = torch.empty((m, n), dtype=a.dtype, device=a.device)
     e0 = _prof_begin()
     if by_pos:
@@ -553,15 +576,13 @@ def gemm_grouped2(a, w0, w1, b0, b1, epi=EPI_BF16, out=None, resid=None, rope=No
     tpi, by_pos = 0, False
     if rtok is not None:
         rtok, tpi, by_pos = _rope_table(rtok)
-    e0 = _prof_begin()
     if by_pos:
         if epi != EPI_BF16_ROPE or resid is not None:
             raise ValueError("rope positions go with epi=EPI_BF16_ROPE and no residual")
-        _ffi.call("m3_gemm_grouped2_rope_pos_dt", _ffi.ptr(a), _ffi.ptr(w0), _ffi.ptr(w1), _ffi.ptr(b0), _ffi.ptr(b1), _ffi.ptr(out),
-                  m, n, k, ldc, m * k, m * ldc, _ffi.ptr(rtok), tpi, float(ROPE_BASE), rc, int(qc), float(qs), dt, _ffi.stream_ptr())
-    else:
-        _ffi.call("m3_gemm_grouped2_dt", _ffi.ptr(a), _ffi.ptr(w0), _ffi.ptr(w1), _ffi.ptr(b0), _ffi.ptr(b1), _ffi.ptr(out),
-                  _ffi.ptr(resid), m, n, k, ldc, m * k, m * ldc, epi, _ffi.ptr(rtok), tpi, rc, int(qc), float(qs), dt, _ffi.stream_ptr())
+        return gemm_ex(a, w0, b0, EPI_BF16_ROPE, out=out, w1=w1, bias1=b1, rope=(rtok, rc, qc, qs), pv_bf16=pv_bf16)
+    e0 = _prof_begin()
+    _ffi.call("m3_gemm_grouped2_dt", _ffi.ptr(a), _ffi.ptr(w0), _ffi.ptr(w1), _ffi.ptr(b0), _ffi.ptr(b1), _ffi.ptr(out),
+              _ffi.ptr(resid), m, n, k, ldc, m * k, m * ldc, epi, _ffi.ptr(rtok), tpi, rc, int(qc), float(qs), dt, _ffi.stream_ptr())
     _prof_end(e0, _gemm_kind(m, n, 2), 4.0 * m * n * k,
               2.0 * (2.0 * (m * k + n * k) + out.element_size() * m * n * (1 if resid is None else 2)))
     return out
@@ -591,6 +612,25 @@ def ln_hl_buffers(rows: int, cols: int, device, groups: int = 1):
 def hl_to_f32(hl):
     """fp32 view of a hi / lo stream (the two LayerNorms that still run as kernels - enc_norm, dec_norm - read it)."""
     return torch.add(hl[0].float(), hl[1])
+
+
+def layernorm_hl(hl, g0, b0, g1=None, b1=None, eps=1e-6, dtype=torch.float16):
+    """LayerNorm of a hi / lo stream (ln_hl_buffers) in one pass over the two planes: [M,C] -> [M,C], or [2,M,C] -> [2,M,C]
+    with (g1, b1) for the second group.  Bit-identical to layernorm(hl_to_f32(hl), ...)."""
+    hi, lo = hl[0], hl[1]
+    if hi.dtype != torch.float16 or lo.dtype != torch.float16 or hi.shape != lo.shape or not (hi.is_contiguous() and lo.is_contiguous()):
+        raise ValueError("bad hi / lo planes")
+    c = hi.shape[-1]
+    rows = hi.numel() // c
+    split = hi.shape[-2] if hi.dim() == 3 else rows
+    if hi.dim() == 3 and (hi.shape[0] != 2 or g1 is None or b1 is None):
+        raise ValueError("two groups need [2,M,C] planes and both parameter sets")
+    out = torch.empty(hi.shape, dtype=dtype, device=hi.device)
+    g1 = g0 if g1 is None else g1
+    b1 = b0 if b1 is None else b1
+    _ffi.call("m3_layernorm_hl_dt", _ffi.ptr(hi), _ffi.ptr(lo), _ffi.ptr(g0), _ffi.ptr(b0), _ffi.ptr(g1), _ffi.ptr(b1), _ffi.ptr(out),
+              rows, c, split, float(eps), DT_CODE[dtype], _ffi.stream_ptr())
+    return out
 
 
 def gemm_ex(a, w, bias=None, epi: int = EPI_BF16, out=None, resid=None, w1=None, bias1=None, rope=None, pv_bf16: bool = False,
@@ -666,6 +706,7 @@ def gemm_ex(a, w, bias=None, epi: int = EPI_BF16, out=None, resid=None, w1=None,
     d.c_gstride = m * ldc if grouped else 0
     if rope is not None:
         rtok, rc, qc, qs = (tuple(rope) + (0, 1.0))[:4]
+        d.rope_max_pos = _rope_pmax(rtok)
         rtok = _ffi.check(rtok, torch.int32, "rope positions", (None, 2))
         d.rope_pos, d.tokens_per_image, d.rope_base = rtok.data_ptr(), rtok.shape[0], float(ROPE_BASE)
         d.rope_cols, d.q_cols, d.q_scale = int(rc), int(qc), float(qs)

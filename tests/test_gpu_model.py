@@ -478,6 +478,49 @@ def test_gemm_with_fused_rope_epilogue(dev, m_n_k):
     assert float((out_p != out).float().mean()) < 0.02
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_rope_lds_table_returns_the_per_element_bits(dev, dtype):
+    """ops.rope_bound (m3_gemm_desc.rope_max_pos): with the positions' range promised, every workgroup builds the cos / sin of
+    all (position, frequency) pairs once in LDS; the rotation must return the bits of the per-element v_sin / v_cos form, in
+    every tile shape (64 / 128 / 192 / 256), for one and two groups, with and without bf16 v columns; a bound the table cannot
+    hold (> 64) and a missing promise fall back to the per-element form."""
+    gh, gw = 12, 20
+    t = gh * gw
+    m, k = 8 * t, 128
+    g = torch.Generator().manual_seed(31)
+    gy, gx = torch.meshgrid(torch.arange(gh), torch.arange(gw), indexing="ij")
+    mk_pos = lambda: torch.stack([gy.reshape(-1), gx.reshape(-1)], -1).to(torch.int32).to(dev).contiguous()
+    plain, bound, toobig = mk_pos(), ops.rope_bound(mk_pos(), max(gh, gw)), ops.rope_bound(mk_pos(), 65)
+    a = torch.randn(2, m, k, generator=g).to(dtype).to(dev)
+    prev = ops._ffi.lib().m3_gemm_set_tile(0)
+    try:
+        for tile in (64, 128, 192, 256):
+            ops._ffi.lib().m3_gemm_set_tile(tile)
+            for n, rc, qc in ((768, 512, 256), (1536, 1024, 512), (192, 192, 0)):
+                w = [(torch.randn(n, k, generator=g) * 0.1).to(dtype).to(dev) for _ in range(2)]
+                b = [torch.randn(n, generator=g).to(dev) for _ in range(2)]
+                for pv in ((False, True) if dtype == torch.float16 and rc < n else (False,)):
+                    one = lambda pos: ops.gemm_ex(a[0], w[0], b[0], ops.EPI_BF16_ROPE, rope=(pos, rc, qc, 0.25), pv_bf16=pv)
+                    two = lambda pos: ops.gemm_ex(a, w[0], b[0], ops.EPI_BF16_ROPE, w1=w[1], bias1=b[1], rope=(pos, rc, qc, 0.25), pv_bf16=pv)
+                    ref1, ref2 = one(plain), two(plain)
+                    assert torch.equal(one(bound), ref1) and torch.equal(two(bound), ref2)
+                    assert torch.equal(one(toobig), ref1)
+                    assert torch.equal(ops.gemm_rope(a[0], w[0], b[0], bound, rc, qc, 0.25, pv_bf16=pv), ref1)     # the older entry points
+                    assert torch.equal(ops.gemm_grouped2(a, w[0], w[1], b[0], b[1], ops.EPI_BF16_ROPE, rope=(bound, rc, qc, 0.25), pv_bf16=pv), ref2)
+    finally:
+        ops._ffi.lib().m3_gemm_set_tile(prev)
+    # and the table form against the fp32 reference rotation
+    pos = OM.patch_positions(gh * 16, gw * 16)
+    cos, sin = OM.rope_tables(max(gh, gw) + 1)
+    n, rc = 768, 512
+    w0 = (torch.randn(n, k, generator=g) * 0.1).to(dtype)
+    ref = a[0].float().cpu() @ w0.float().T
+    rot = OM.rope2d(ref[:, :rc].reshape(m // t, t, rc // 64, 64).transpose(1, 2), pos, cos, sin)
+    ref = torch.cat([rot.transpose(1, 2).reshape(m, rc), ref[:, rc:]], 1)
+    out = ops.gemm_ex(a[0], w0.to(dev), None, ops.EPI_BF16_ROPE, rope=(bound, rc))
+    assert _rel(out, ref) < (3e-3 if dtype == torch.bfloat16 else 4e-4)
+
+
 def test_frame_tracker_end_to_end(tiny, dev):
     """The reference's per-frame flow (slam.py:159-214): mono-init a keyframe, then FrameTracker.track a new
     frame against it through the injected operator (tracker.py:51-175).  Random weights give meaningless
@@ -1004,3 +1047,29 @@ def test_hi_lo_residual_stream(dev, shape):
         assert torch.allclose(hl[2][..., 0].double().cpu().T, xo.sum(-1), rtol=1e-5, atol=1e-3)
         assert torch.allclose(hl[2][..., 1].double().cpu().T, (xo * xo).sum(-1), rtol=1e-5, atol=1e-3)
     assert _rel(ops.hl_to_f32(hl), x) < 1e-6                                  # five updates later: still the fp32 stream
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_layernorm_reads_the_hi_lo_planes(dev, groups, dtype):
+    """m3_layernorm_hl_dt (enc_norm / dec_norm on the folded fp16 trunk) == the fp32-input LayerNorm kernel on hi + lo, bit for
+    bit, for one group and for the decoder's two groups with their own parameters; against torch within the 16-bit rounding."""
+    m, c = 1000, 768
+    g = torch.Generator(device="cpu").manual_seed(4 + groups)
+    shape = (m, c) if groups == 1 else (2, m, c)
+    x = torch.randn(shape, generator=g) * 3.0 + 0.5
+    hi = x.half()
+    lo = (x - hi.float()).half()
+    hl = (hi.to(dev), lo.to(dev))
+    par = [(torch.randn(c, generator=g).to(dev), torch.randn(c, generator=g).to(dev)) for _ in range(2)]
+    if groups == 1:
+        got = ops.layernorm_hl(hl, *par[0], dtype=dtype)
+        ref = ops.layernorm(ops.hl_to_f32(hl), *par[0], dtype=dtype)
+    else:
+        got = ops.layernorm_hl(hl, *par[0], *par[1], dtype=dtype)
+        ref = ops.layernorm_grouped2(ops.hl_to_f32(hl), *par[0], *par[1], dtype=dtype)
+    assert got.dtype == dtype and torch.equal(got, ref)
+    xs = ops.hl_to_f32(hl).double().cpu().reshape(groups, m, c)
+    for gi in range(groups):
+        t = torch.nn.functional.layer_norm(xs[gi], (c,), par[gi][0].double().cpu(), par[gi][1].double().cpu(), 1e-6)
+        assert _rel(got.reshape(groups, m, c)[gi], t) < (3e-3 if dtype == torch.bfloat16 else 4e-4)

@@ -132,12 +132,18 @@ typedef struct m3_gemm_desc {
     int32_t M, N, K, ldc, epilogue, dtype, groups;
     int32_t tokens_per_image, rope_cols, q_cols, ln_slots;
     float rope_base, q_scale, ln_eps;
+    int32_t stats_slots;               /* producer: slots of the stats_out buffer = m3_ln_slot_count(M, N, groups) (checked)               */
     int32_t rope_max_pos;              /* RoPE: > 0 promises that every entry of rope_pos is in [0, rope_max_pos) and rope_max_pos <= 64  */
                                        /* (a 1024-pixel side): each workgroup then builds the rope_max_pos x 16 cos / sin table once in   */
                                        /* LDS instead of eight v_sin / v_cos per lane, row and 32-column block (same values bit for bit). */
                                        /* 0 (or > 64): computed per element.  A position outside the promise takes the last table row.    */
 } m3_gemm_desc;
 int m3_gemm_ex(const m3_gemm_desc *desc, void *stream);
+/* Statistics slots a producer launch of a [M, N] stream (groups 1 or 2) writes per row: stats_out is [slots][M][2] floats per
+ * group.  N / 32 (32-column leaves) or, where the launch runs 256-row tiles whose width is the top node of the statistics'
+ * sum tree (256 columns for N % 256 == 0, else 192 for N % 192 == 0), one slot per tile: N / 256 or N / 192.  A consumer is
+ * given the same count in ln_slots (its K = N).  0: no statistics for this width. */
+int m3_ln_slot_count(int M, int N, int groups);
 
 /* 3x3 convolution, padding 1, stride 1 or 2, as an implicit GEMM: X bf16 NHWC [B,H,W,Cin],
  * W bf16 [Cout,3,3,Cin], Y NHWC [B,OH,OW,Cout].  Cin % 64 == 0, Cout % 4 == 0.  zero16: 16

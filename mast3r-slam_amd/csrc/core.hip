@@ -13,7 +13,7 @@ extern "C" {
 // 2000 (round 3): m3_chol_solve's workspace is m3_chol_ws_doubles(dim) (was 1 + dim); m3_track_* info carries the
 // solver-failure flag; the RoPE GEMM entry points take (rope_tok, tokens_per_image, rope_cols) since 1001 -> callers built
 // against a 1xxx header must be rebuilt (tests assert the exact value).
-int m3_abi_version(void) { return 2006; }
+int m3_abi_version(void) { return 2007; }
 
 const char *m3_status_string(int status) {
     switch (status) {

@@ -574,6 +574,22 @@ int m3_gemm_bf16_grouped2(const void *A, const void *W0, const void *W1, const f
                                tokens_per_image, rope_cols, 0, 1.0f, DT_BF16, stream);
 }
 
+// widest node of the statistics' canonical tree for a stream of C columns (gemm_common.h): 256, 192 or 0 (no fold for this width)
+static int ln_top_width(int C) {
+    const int w = C % 256 == 0 ? 256 : (C % 192 == 0 ? 192 : 0);
+    return (w && C / w <= 4) ? w : 0;
+}
+// does the launch of a [M, N] producer finish its tiles' statistics into ONE slot per tile (256-row kernel whose tile width is the
+// stream's top node)?  Same decision in m3_ln_slot_count (the host sizes the buffer with it) and in m3_gemm_ex.
+static bool ln_coarse(int M, int N, int groups) {
+    const int tile = pick_tile(M, N, groups), top = ln_top_width(N);
+    return top != 0 && tile == top;
+}
+int m3_ln_slot_count(int M, int N, int groups) {
+    if (M <= 0 || N <= 0 || N % 32) return 0;
+    return ln_coarse(M, N, groups > 1 ? 2 : 1) ? N / ln_top_width(N) : N / 32;
+}
+
 int m3_gemm_ex(const m3_gemm_desc *d, void *stream) {
     M3_REQUIRE(d && d->A && d->W && (d->C || d->c_lo) && d->M > 0 && d->N > 0 && d->K > 0);
     const int epi = d->epilogue, groups = d->groups > 1 ? 2 : 1;
@@ -597,9 +613,12 @@ int m3_gemm_ex(const m3_gemm_desc *d, void *stream) {
                    (!d->c16 || (reinterpret_cast<size_t>(d->c16) & 15) == 0) &&
                    (!d->stats_out || (reinterpret_cast<size_t>(d->stats_out) & 15) == 0));
         if (groups == 2) M3_REQUIRE(d->c_gstride % 8 == 0 && d->stats_gstride % 4 == 0);
+        if (d->stats_out) M3_REQUIRE(d->stats_slots == m3_ln_slot_count(d->M, d->N, groups));     // the buffer the host sized with it
     }
     if (d->ln_stats) {                     // LayerNorm fold, consumer
-        M3_REQUIRE(!f32out && epi != EPI_BF16_ADD && d->ln_colsum && d->ln_slots * 32 == d->K && d->ln_slots % 4 == 0 &&
+        const int top = ln_top_width(d->K);                 // the statistics arrive as 32-column leaves or as finished top nodes
+        M3_REQUIRE(top != 0 && (d->ln_slots == d->K / 32 || d->ln_slots == d->K / top));
+        M3_REQUIRE(!f32out && epi != EPI_BF16_ADD && d->ln_colsum &&
                    d->ln_eps > 0.0f && d->M % 2 == 0 && (reinterpret_cast<size_t>(d->ln_stats) & 15) == 0 &&
                    (reinterpret_cast<size_t>(d->ln_colsum) & 15) == 0 && (reinterpret_cast<size_t>(d->C) & 15) == 0 &&
                    d->ldc % 8 == 0 && d->N % 8 == 0);
@@ -619,6 +638,12 @@ int m3_gemm_ex(const m3_gemm_desc *d, void *stream) {
     a.R_lo = d->r_lo; a.C_lo = d->c_lo;
     a.ln_stats = d->ln_stats; a.ln_colsum = d->ln_colsum; a.ln_colsum2 = d->ln_colsum1; a.ln_slots = d->ln_slots;
     a.ln_eps = d->ln_eps; a.ln_gstride = d->ln_gstride;
+    if (d->ln_stats) {
+        const int top = ln_top_width(d->K);
+        a.ln_tops = d->K / top;
+        a.ln_gsz = d->ln_slots == d->K / top ? 1 : top / 32;
+    }
+    a.stats_coarse = d->stats_out && ln_coarse(d->M, d->N, groups);
     const int tile = pick_tile(d->M, d->N, groups);
     if (tile >= 192) return launch_dense_big(a, epi, tile, (hipStream_t)stream);
     if (tile == 64) return launch<0, 64>(a, epi, (hipStream_t)stream);

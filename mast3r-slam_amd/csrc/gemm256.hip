@@ -230,6 +230,12 @@ k_gemm256(const GemmArgs gin) {
     }
     epilogue_rows<EPI, NI, NJ, DT>(g, acc, lds + wave * (64 * (32 * NJ + 16)), m0 + wr * (16 * NI), n0 + wc * (16 * NJ), lane, lnt,
                                    wr * (16 * NI), ropet);
+    if constexpr (MODE == 0 && (EPI == EPI_F32 || EPI == EPI_F32_ACCUM)) {
+        if (g.stats_out && g.stats_coarse) {                 // kernel-uniform: the tile is one top node of the statistics' tree
+            __syncthreads();
+            stats_tile_finalize<NI, NJ, WN>(g, lds, 64 * (32 * NJ + 16), stats_stage_offset<NJ>(), m0, tn, tid);
+        }
+    }
 }
 
 template <int MODE, int BN, int DT>

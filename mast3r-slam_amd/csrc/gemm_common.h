@@ -115,6 +115,7 @@ struct GemmArgs {
     const int *rope_pos;    // [tokens_per_image, 2 (y|x)] grid positions - cos/sin are then computed in the epilogue
     float rope_log2_base;   //   from frequencies base^(-i/16), i = 0..15 (v_sin_f32 / v_cos_f32, arguments in revolutions)
     int tokens_per_image, rope_cols;
+    int ln_gsz, ln_tops;    // consumer: statistics slots stored per top node (8 or 6 leaves of 32 columns, or 1 = coarse) and top nodes (<= 4)
     int rope_pmax;          //   position mode: > 0 = every position is in [0, rope_pmax) (<= kRopeTableRows): the kernels then build
                             //   the cos / sin of all rope_pmax x 16 (position, frequency) pairs ONCE per workgroup in LDS
     int q_cols;             // columns < q_cols (the q heads) are multiplied by q_scale after the rotation, before the
@@ -141,6 +142,9 @@ struct GemmArgs {
     // type (same ldc) and, per row and 32-column slot, (sum x', sum x'^2) into stats_out [M][N/32][2] - from the fp32 values
     void *C16;
     float *stats_out;
+    int stats_coarse;       // producer, 256-row kernel only: 1 = ONE statistics slot per tile (slot width = the tile's BN = the stream
+                            // width's top node, 256 or 192 columns): the workgroup adds its waves' 32-column leaves in the canonical
+                            // tree (stats_tile_finalize) - a consumer tile then reads 2 KiB per slot of 256 / 192 columns, not of 32
     // hi / lo form of the stream (C_lo set; fp16 launches): the stream is kept as TWO 16-bit planes, x = hi + lo with hi = x
     // rounded to fp16 and lo = the rounded remainder (22 significant bits; |x| < 65504).  hi IS the consumer's operand, so the
     // residual launch moves 4 + 4 bytes per element as with an fp32 stream and no separate copy exists: R = hi in, R_lo = lo in,
@@ -352,75 +356,105 @@ __device__ __forceinline__ unsigned dpp_xor1(unsigned v) {
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
 }
 
-// LayerNorm fold, consumer side: mean and 1 / sqrt(var + eps) of the tile's rows.  FOUR threads per PAIR of rows: the
-// statistics are slot-major ([ln_slots][M][2] floats), so the (sum, sum of squares) of two neighbouring rows are one 16-byte
-// load; thread (pair p, quarter c) adds the slots [c S/4, (c + 1) S/4) of rows 2p, 2p + 1 in index order, then the four
-// quarters are added as (q0 + q1) + (q2 + q3) on the DPP path - ONE order in every kernel and tile shape, so a row's
-// statistics do not depend on which kernel multiplies it.  (A first version read 8 bytes per lane, two threads per row:
-// twice the load instructions at half the bytes each - the table cost 2.2 us per tile.)  ln_slots % 4 == 0 and M even
-// (host checks); rows past M read the last pair.  Returns (mean, rstd) of row 2p in .x .y and of row 2p + 1 in .z .w,
-// in all four lanes of the quad; threads >= 2 ROWS repeat pair 0's work (uniform control flow; ln_table_store ignores them).
-// (mean, 1 / sqrt(var + eps)) of a row from its sum and sum of squares over 32 * slots columns, in ONE spelled-out operation
+// The statistics' canonical sum.  A row's (sum, sum of squares) over its C columns is defined as ONE expression tree, whatever
+// kernel and tile shape produce or consume the pieces - so a row's statistics (and with them the network's output) do not depend
+// on the batch a pair is computed in:
+//   leaves      32 columns (8 lanes x 4 columns, dpp_sum8 in the producer's epilogue)
+//   top nodes   256 columns (C % 256 == 0) or 192 (C % 192 == 0): ((l0 + l1) + (l2 + l3)) + ((l4 + l5) + (l6 + l7)), the last
+//               pair absent (zero) for 192
+//   total       ((t0 + t1) + t2) + t3 over the <= 4 top nodes (absent ones zero; x + 0 = x keeps the bits)
+// Producers store leaves (slot-major [C / 32][M][2]) or, where a workgroup's tile IS a top node (256-row kernel, BN = 256 / 192),
+// the finished top nodes ([C / 256 or C / 192][M][2]: 1/8 or 1/6 of the bytes - a consumer pays for statistics bytes what it pays
+// for operand bytes, profiles/r05_fold_probe.md).
+__device__ __forceinline__ float ln_tree8(const float (&x)[8]) {
+    return ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+}
+// LayerNorm fold, consumer side: mean and 1 / sqrt(var + eps) of the tile's rows.  FOUR threads per PAIR of rows (the (sum, sum
+// of squares) of two neighbouring rows of a slot are one 16-byte load): thread (pair p, q) builds top node q of rows 2p, 2p + 1
+// from its ln_gsz stored slots (8 / 6 leaves, or the node itself), the quad then folds the nodes in index order on the DPP path,
+// every lane the same expression.  M even (host check); rows past M read the last pair.  Returns (mean, rstd) of row 2p in .x .y
+// and of row 2p + 1 in .z .w, in all four lanes of the quad; threads >= 2 ROWS repeat pair 0's work (ln_table_store ignores them).
+struct LnLoads { float4 v[8]; };
+// (mean, 1 / sqrt(var + eps)) of a row from its sum and sum of squares over `cols` columns, in ONE spelled-out operation
 // sequence, so each kernel that builds a row table gets the same bits
-__device__ __forceinline__ float2 ln_mean_rstd(float s, float q, int slots, float eps) {
-    const float inv = 1.0f / (float)(slots * 32);
+__device__ __forceinline__ float2 ln_mean_rstd(float s, float q, int cols, float eps) {
+    const float inv = 1.0f / (float)cols;
     const float mean = s * inv;
     const float var = fmaxf(__builtin_fmaf(-mean, mean, q * inv), 0.f);      // the fma spelled out: hipcc contracts a * b - c * d
     return make_float2(mean, rsqrtf(var + eps));                             // as it likes per call site (__fmul_rn does not stop it)
 }
-struct LnLoads { float4 v[8]; };
-// first half: the loads of the first 8 slots of the thread's quarter go out (and stay in flight: a kernel puts its first
-// K-tile's loads between the two halves, so the statistics' latency and arithmetic run under the tile's)
+// first half: the thread's loads go out (and stay in flight: a kernel puts its first K-tile's loads between the two halves)
 template <int ROWS>
 __device__ __forceinline__ LnLoads ln_row_issue(const GemmArgs &g, int m0, int tid) {
     LnLoads L;
-    const int pair = (tid < 2 * ROWS ? tid : 0) >> 2, quarter = tid & 3, qs = g.ln_slots >> 2;
+    const int pair = (tid < 2 * ROWS ? tid : 0) >> 2, q = tid & 3;
+    const int node = q < g.ln_tops ? q : g.ln_tops - 1;
     int m = m0 + 2 * pair;
     m = m < g.M - 1 ? m : g.M - 2;
-    const float4 *p = reinterpret_cast<const float4 *>(g.ln_stats + ((size_t)quarter * qs * g.M + m) * 2);
+    const float4 *p = reinterpret_cast<const float4 *>(g.ln_stats + ((size_t)node * g.ln_gsz * g.M + m) * 2);
     const size_t slot_stride = (size_t)g.M / 2;              // float4 units between consecutive slots
-#pragma unroll                                               // UNCONDITIONAL loads from clamped addresses, the bound applied to
-    for (int i = 0; i < 8; ++i)                              // the value (a bound on the load makes hipcc branch around each one
-        L.v[i] = p[(size_t)(i < qs ? i : qs - 1) * slot_stride];      // and wait for it where it stands)
+    L.v[0] = p[0];
+    if (g.ln_gsz > 1) {                                      // kernel-uniform.  UNCONDITIONAL loads from clamped addresses, the bound
+#pragma unroll                                               // applied to the value (a bound on the load makes hipcc branch around
+        for (int i = 1; i < 8; ++i) L.v[i] = p[(size_t)(i < g.ln_gsz ? i : g.ln_gsz - 1) * slot_stride];    // each one and wait for it)
+    } else {
+#pragma unroll
+        for (int i = 1; i < 8; ++i) L.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     return L;
 }
 template <int ROWS>
 __device__ __forceinline__ float4 ln_row_finish(const GemmArgs &g, const LnLoads &L, int m0, int tid) {
-    const int pair = (tid < 2 * ROWS ? tid : 0) >> 2, quarter = tid & 3, qs = g.ln_slots >> 2;
-    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+    const bool live = (tid & 3) < g.ln_tops;
+    float c[4][8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const bool on = i < qs;
-        s0 += on ? L.v[i].x : 0.f; q0 += on ? L.v[i].y : 0.f; s1 += on ? L.v[i].z : 0.f; q1 += on ? L.v[i].w : 0.f;
+        const bool on = live && i < g.ln_gsz;
+        c[0][i] = on ? L.v[i].x : 0.f; c[1][i] = on ? L.v[i].y : 0.f; c[2][i] = on ? L.v[i].z : 0.f; c[3][i] = on ? L.v[i].w : 0.f;
     }
-    if (qs > 8) {                                            // kernel-uniform; wider rows than 1024 columns: the rest in place
-        int m = m0 + 2 * pair;
-        m = m < g.M - 1 ? m : g.M - 2;
-        const float4 *p = reinterpret_cast<const float4 *>(g.ln_stats + ((size_t)quarter * qs * g.M + m) * 2);
-        const size_t slot_stride = (size_t)g.M / 2;
-        for (int i0 = 8; i0 < qs; i0 += 8) {
-            float4 v[8];
+    float t[4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = p[(size_t)(i0 + i < qs ? i0 + i : qs - 1) * slot_stride];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const bool on = i0 + i < qs;
-                s0 += on ? v[i].x : 0.f; q0 += on ? v[i].y : 0.f; s1 += on ? v[i].z : 0.f; q1 += on ? v[i].w : 0.f;
-            }
-        }
+    for (int k = 0; k < 4; ++k) {
+        const float node = ln_tree8(c[k]);
+        const int b = __builtin_bit_cast(int, node);         // the quad's four top nodes, folded in index order by every lane
+        const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, b, 0x00, 0xF, 0xF, true));   // quad_perm [0,0,0,0]
+        const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, b, 0x55, 0xF, 0xF, true));   // [1,1,1,1]
+        const float t2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, b, 0xAA, 0xF, 0xF, true));   // [2,2,2,2]
+        const float t3 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, b, 0xFF, 0xF, 0xF, true));   // [3,3,3,3]
+        t[k] = ((t0 + t1) + t2) + t3;
     }
-    auto quad_sum = [](float v) {
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // lane ^ 1
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // lane ^ 2
-        return v;
-    };
-    s0 = quad_sum(s0); q0 = quad_sum(q0); s1 = quad_sum(s1); q1 = quad_sum(q1);
-    const float2 a = ln_mean_rstd(s0, q0, g.ln_slots, g.ln_eps), b = ln_mean_rstd(s1, q1, g.ln_slots, g.ln_eps);
-    return make_float4(a.x, a.y, b.x, b.y);
+    const int cols = g.K;
+    const float2 a = ln_mean_rstd(t[0], t[1], cols, g.ln_eps), b2 = ln_mean_rstd(t[2], t[3], cols, g.ln_eps);
+    return make_float4(a.x, a.y, b2.x, b2.y);
 }
 template <int ROWS>
 __device__ __forceinline__ float4 ln_row_stats(const GemmArgs &g, int m0, int tid) {
     return ln_row_finish<ROWS>(g, ln_row_issue<ROWS>(g, m0, tid), m0, tid);
+}
+// Producer, 256-row kernel with a coarse slot (g.stats_coarse): after the waves' epilogues (and a workgroup barrier) the 32-column
+// leaves of the whole tile sit in the waves' scratch, [leaf of the wave][row of the wave] float2 behind each transpose image;
+// thread t < 256 adds row t's BN / 32 leaves in the canonical tree and stores ONE slot (index = the tile's N index).
+// byte offset of the statistics staging inside a wave's epilogue scratch (behind the 16-row fp32 transpose image)
+template <int NJ> constexpr int stats_stage_offset() { return (16 * ((NJ == 4) ? 256 : NJ * 64 + 16) + 15) & ~15; }
+template <int NI, int NJ, int WN>
+__device__ __forceinline__ void stats_tile_finalize(const GemmArgs &g, const unsigned char *lds, int wave_stride, int wst_off,
+                                                    int m0, int tn, int tid) {
+    constexpr int WROWS = 16 * NI, LPW = NJ / 2, LEAVES = WN * LPW;     // rows per wave, leaves per wave, leaves per tile (8 or 6)
+    if (tid >= 256) return;
+    const int wr = tid / WROWS, rr = tid - wr * WROWS;
+    float s[8], q[8];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        if (l < LEAVES) {
+            const int wc = l / LPW, sl = l - wc * LPW;
+            const float2 v = *reinterpret_cast<const float2 *>(lds + (wr * WN + wc) * wave_stride + wst_off + (sl * WROWS + rr) * 8);
+            s[l] = v.x; q[l] = v.y;
+        } else {
+            s[l] = 0.f; q[l] = 0.f;
+        }
+    }
+    const int m = m0 + tid;
+    if (m < g.M) *reinterpret_cast<float2 *>(g.stats_out + ((size_t)tn * g.M + m) * 2) = make_float2(ln_tree8(s), ln_tree8(q));
 }
 template <int ROWS>
 __device__ __forceinline__ void ln_table_store(float2 *tab, const float4 &mr, int tid) {
@@ -508,6 +542,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
         // around the loads, and one pass AHEAD of its use - the first version loaded each chunk inside the
         // bounds test, i.e. one exposed L2/HBM round trip per chunk (32 per wave): 18.6 us of a 52 us launch.
         // LayerNorm-fold statistics of the sub-tile, staged behind the transpose scratch: [NJ / 2 slots][16 NI rows] float2
+        static_assert(!F32OUT || ((PR * RS + 15) & ~15) == stats_stage_offset<NJ>(), "stats_tile_finalize reads the staging where the epilogue wrote it");
         float2 *wst = reinterpret_cast<float2 *>(wlds + ((PR * RS + 15) & ~15));
         uint4 q[RESID_AHEAD ? 2 : 1][RESID ? NIT : 1];
         // (the kernel-uniform stream-form test stays OUTSIDE the load loop: inside it, hipcc branched around every load and waited
@@ -614,7 +649,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
             }
             asm volatile("" ::: "memory");
         }
-        if (F32OUT && g.stats_out) {
+        if (F32OUT && g.stats_out && !g.stats_coarse) {       // (coarse slot: the leaves stay in the scratch for stats_tile_finalize)
             // the sub-tile's statistics leave as runs of 16 NI rows x 8 B per slot (slot-major layout [N / 32][M][2]), 16 bytes
             // = two rows per lane: M and the sub-tile's first row are even (host check), so a pair is inside or outside together
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -84,7 +84,7 @@ class GemmDesc(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("ldc", C.c_int32), ("epilogue", C.c_int32),
                 ("dtype", C.c_int32), ("groups", C.c_int32), ("tokens_per_image", C.c_int32), ("rope_cols", C.c_int32),
                 ("q_cols", C.c_int32), ("ln_slots", C.c_int32),
-                ("rope_base", C.c_float), ("q_scale", C.c_float), ("ln_eps", C.c_float), ("rope_max_pos", C.c_int32)]
+                ("rope_base", C.c_float), ("q_scale", C.c_float), ("ln_eps", C.c_float), ("stats_slots", C.c_int32), ("rope_max_pos", C.c_int32)]
 
 
 class PackSeg(C.Structure):

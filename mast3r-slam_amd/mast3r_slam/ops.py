@@ -593,12 +593,23 @@ LN_EPS = 1e-6
 
 def ln_fold_buffers(rows: int, cols: int, dtype, device, groups: int = 1):
     """Buffers of the LayerNorm fold for a [rows, cols] (or [2, rows, cols]) fp32 stream: (x16, stats) - the 16-bit copy of the
-    stream and the partial statistics [cols / 32, rows, 2] (slot-major) that a producer GEMM (gemm_ex(..., fold_out=...)) fills."""
-    if cols % 128:
-        raise ValueError("LayerNorm fold: the stream width must be a multiple of 128")
+    stream and the partial statistics [slots, rows, 2] (slot-major; ln_slot_count) that a producer GEMM (gemm_ex(..., fold_out=...)) fills."""
+    slots = ln_slot_count(rows, cols, groups)
     lead = (2,) if groups == 2 else ()
     return (torch.empty(lead + (rows, cols), dtype=dtype, device=device),
-            torch.empty(lead + (cols // 32, rows, 2), dtype=torch.float32, device=device))
+            torch.empty(lead + (slots, rows, 2), dtype=torch.float32, device=device))
+
+
+def ln_slot_count(rows: int, cols: int, groups: int = 1) -> int:
+    """Statistics slots per row a producer launch of a [rows, cols] stream writes (m3_ln_slot_count): cols / 32 leaves, or
+    one slot per 256- / 192-column top node where the launch runs 256-row tiles of exactly that width (the consumer then reads
+    1/8 or 1/6 of the bytes).  The decision follows the tile the launch will be dispatched to."""
+    if cols % 192 and cols % 256 or cols // (256 if cols % 256 == 0 else 192) > 4:
+        raise ValueError("LayerNorm fold: the stream width must be 1..4 times 256 or 192 columns")
+    n = int(_ffi.lib().m3_ln_slot_count(int(rows), int(cols), int(groups)))
+    if n <= 0:
+        raise ValueError(f"no LayerNorm-fold statistics for a [{rows}, {cols}] stream")
+    return n
 
 
 def ln_hl_buffers(rows: int, cols: int, device, groups: int = 1):
@@ -671,17 +682,18 @@ def gemm_ex(a, w, bias=None, epi: int = EPI_BF16, out=None, resid=None, w1=None,
         for t_ in (hi, lo):
             if t_.dtype != torch.float16 or tuple(t_.shape) != lead + (m, n) or not t_.is_contiguous():
                 raise ValueError("bad hi / lo planes (ln_hl_buffers)")
-        if stats.dtype != torch.float32 or tuple(stats.shape) != lead + (n // 32, m, 2) or not stats.is_contiguous():
+        slots = ln_slot_count(m, n, 2 if grouped else 1)
+        if stats.dtype != torch.float32 or tuple(stats.shape) != lead + (slots, m, 2) or not stats.is_contiguous():
             raise ValueError("bad statistics buffer (ln_hl_buffers)")
         d = _ffi.GemmDesc()
         d.A, d.W, d.W1 = a.data_ptr(), w.data_ptr(), _ffi.ptr(w1)
         d.bias, d.bias1 = _ffi.ptr(bias), _ffi.ptr(bias1)
-        d.c16, d.c_lo, d.stats_out = hi.data_ptr(), lo.data_ptr(), stats.data_ptr()
+        d.c16, d.c_lo, d.stats_out, d.stats_slots = hi.data_ptr(), lo.data_ptr(), stats.data_ptr(), slots
         if epi == EPI_F32_ACCUM:
             d.R, d.r_lo = hi.data_ptr(), lo.data_ptr()
         d.M, d.N, d.K, d.ldc, d.epilogue, d.dtype, d.groups = m, n, k, n, epi, dt, 2 if grouped else 1
         d.a_gstride, d.c_gstride = (m * k, m * n) if grouped else (0, 0)
-        d.stats_gstride = m * (n // 32) * 2 if grouped else 0
+        d.stats_gstride = m * slots * 2 if grouped else 0
         e0 = _prof_begin()
         _ffi.call("m3_gemm_ex", C.addressof(d), _ffi.stream_ptr())
         g_ = 2 if grouped else 1
@@ -712,23 +724,26 @@ def gemm_ex(a, w, bias=None, epi: int = EPI_BF16, out=None, resid=None, w1=None,
         d.rope_cols, d.q_cols, d.q_scale = int(rc), int(qc), float(qs)
     if fold_out is not None:
         x16, stats = fold_out
+        slots = ln_slot_count(m, n, 2 if grouped else 1)
         if (x16.dtype != a.dtype or tuple(x16.shape) != tuple(out.shape) or not x16.is_contiguous() or stats.dtype != torch.float32
-                or tuple(stats.shape) != lead + (n // 32, m, 2) or not stats.is_contiguous() or ldc != n):
+                or tuple(stats.shape) != lead + (slots, m, 2) or not stats.is_contiguous() or ldc != n):
             raise ValueError("bad fold_out buffers (ln_fold_buffers)")
-        d.c16, d.stats_out = x16.data_ptr(), stats.data_ptr()
-        d.stats_gstride = m * (n // 32) * 2 if grouped else 0
+        d.c16, d.stats_out, d.stats_slots = x16.data_ptr(), stats.data_ptr(), slots
+        d.stats_gstride = m * slots * 2 if grouped else 0
     if fold_in is not None:
         stats, cs0 = fold_in[0], fold_in[1]
         cs1 = fold_in[2] if len(fold_in) > 2 else None
-        if stats.dtype != torch.float32 or tuple(stats.shape) != lead + (k // 32, m, 2) or not stats.is_contiguous():
+        if (stats.dtype != torch.float32 or stats.dim() != len(lead) + 3 or tuple(stats.shape[:len(lead)]) != lead
+                or tuple(stats.shape[-2:]) != (m, 2) or not stats.is_contiguous()):
             raise ValueError("bad fold_in statistics")
+        slots = stats.shape[-3]                                  # k / 32 leaves or the producer's finished top nodes (checked in C)
         cs0 = _ffi.check(cs0, torch.float32, "colsum", (n,))
         if grouped:
             cs1 = _ffi.check(cs1, torch.float32, "colsum1", (n,))
-        per = m * (k // 32) * 2
+        per = m * slots * 2
         d.ln_stats = (stats[1] if (grouped and a_swap) else stats).data_ptr()
         d.ln_colsum, d.ln_colsum1 = cs0.data_ptr(), _ffi.ptr(cs1)
-        d.ln_slots, d.ln_eps = k // 32, float(LN_EPS)
+        d.ln_slots, d.ln_eps = slots, float(LN_EPS)
         d.ln_gstride = (-per if a_swap else per) if grouped else 0
     e0 = _prof_begin()
     _ffi.call("m3_gemm_ex", C.addressof(d), _ffi.stream_ptr())

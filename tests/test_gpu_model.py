@@ -952,9 +952,11 @@ def test_layernorm_fold_producer_and_consumer(dev, shape):
     assert torch.equal(out, plain)                                           # the fp32 stream is what the plain launch writes
     x16, st = fo
     assert torch.equal(x16, out.half())                                      # the copy is the stream rounded once
-    xo = out.double().cpu().view(m, c // 32, 32)
-    assert torch.allclose(st[..., 0].double().cpu().T, xo.sum(-1), rtol=1e-5, atol=1e-3)          # slot-major [c / 32, m, 2]
-    assert torch.allclose(st[..., 1].double().cpu().T, (xo * xo).sum(-1), rtol=1e-5, atol=1e-3)
+    slots = st.shape[0]                                                       # c / 32 leaves, or one slot per 256- / 192-column tile
+    assert slots == ops.ln_slot_count(m, c) and slots in (c // 32, c // 256 if c % 256 == 0 else c // 192)
+    xo = out.double().cpu().view(m, slots, c // slots)
+    assert torch.allclose(st[..., 0].double().cpu().T, xo.sum(-1), rtol=1e-5, atol=1e-3)          # slot-major [slots, m, 2]
+    assert torch.allclose(st[..., 1].double().cpu().T, (xo * xo).sum(-1), rtol=1e-5, atol=2e-3)
     # consumer, three epilogues
     ref_d = F.layer_norm(out.double().cpu(), (c,), gam.double(), bet.double(), ops.LN_EPS) @ W.double().T + b.double()
     y = ops.gemm_ex(x16, wf.to(dev), fb.to(dev), ops.EPI_BF16, fold_in=(st, cs.to(dev)))
@@ -972,14 +974,17 @@ def test_layernorm_fold_producer_and_consumer(dev, shape):
             assert _rel(yr, plain_r) < 3e-3
 
 
-def test_layernorm_fold_is_tile_shape_invariant(dev):
-    """Statistics are kept per 32-column slot and added in one order by every kernel, so producer outputs AND consumer
-    outputs are bitwise the same whichever tile shape a launch is dispatched to (64 / 128 / 192 / 256)."""
-    m, c, n = 4096, 768, 1536
+@pytest.mark.parametrize("c", [768, 1024])
+def test_layernorm_fold_is_tile_shape_invariant(dev, c):
+    """A row's statistics are ONE expression tree (32-column leaves -> 256- / 192-column top nodes -> total) whichever kernel
+    produces or consumes the pieces, so the stream, its copy AND the consumer's output are bitwise the same whichever tile shape
+    a launch is dispatched to (64 / 128 / 192 / 256) - including the shapes whose producer stores finished top nodes (one slot
+    per tile) instead of leaves."""
+    m, n = 4096, 1536
     x, gam, bet, W, b, ref, wf, cs, fb = _fold_problem(m, c, n, seed=3)
     g = torch.Generator(device="cpu").manual_seed(9)
     a = torch.randn(m, 256, generator=g).half().to(dev); wp = (torch.randn(c, 256, generator=g) * 0.05).half().to(dev)
-    got = []
+    got, shapes = [], set()
     prev = ops._ffi.lib().m3_gemm_set_tile(0)
     try:
         for tile in (64, 128, 192, 256):
@@ -988,9 +993,11 @@ def test_layernorm_fold_is_tile_shape_invariant(dev):
             fo = ops.ln_fold_buffers(m, c, torch.float16, dev)
             ops.gemm_ex(a, wp, None, ops.EPI_F32_ACCUM, out=xs, resid=xs, fold_out=fo)
             y = ops.gemm_ex(fo[0], wf.to(dev), fb.to(dev), ops.EPI_BF16_GELU, fold_in=(fo[1], cs.to(dev)))
-            got.append((xs, fo[0], fo[1], y))
+            got.append((xs, fo[0], y))
+            shapes.add(fo[1].shape[0])
     finally:
         ops._ffi.lib().m3_gemm_set_tile(prev)
+    assert shapes == {c // 32, c // (256 if c % 256 == 0 else 192)}           # leaves, and top nodes from the tile as wide as one
     for other in got[1:]:
         for p, q in zip(got[0], other):
             assert torch.equal(p, q)
@@ -1010,7 +1017,8 @@ def test_layernorm_fold_two_groups_and_swapped_memory(dev):
     for gi in range(2):                                                       # each group = the single-group launch on its half
         x1 = x[gi].clone(); f1 = ops.ln_fold_buffers(m, c, torch.float16, dev)
         ops.gemm_ex(a[gi].contiguous(), wp[gi], None, ops.EPI_F32_ACCUM, out=x1, resid=x1, fold_out=f1)
-        assert torch.equal(xs[gi], x1) and torch.equal(fo[0][gi], f1[0]) and torch.equal(fo[1][gi], f1[1])
+        assert torch.equal(xs[gi], x1) and torch.equal(fo[0][gi], f1[0])
+        assert fo[1][gi].shape != f1[1].shape or torch.equal(fo[1][gi], f1[1])      # (the two launches may store different tree levels)
     wf = [P0[6].to(dev), P1[6].to(dev)]; cs = [P0[7].to(dev), P1[7].to(dev)]; fb = [P0[8].to(dev), P1[8].to(dev)]
     for swap in (False, True):
         y = ops.gemm_ex(fo[0], wf[0], fb[0], ops.EPI_BF16, w1=wf[1], bias1=fb[1], fold_in=(fo[1], cs[0], cs[1]), a_swap=swap)
@@ -1043,9 +1051,10 @@ def test_hi_lo_residual_stream(dev, shape):
         ops.gemm(a, w, b, ops.EPI_F32_ACCUM, out=x, resid=x)
         assert torch.equal(hl[0], ref.half())                                 # one rounding of (hi + lo) + product
         assert float((ops.hl_to_f32(hl) - ref).abs().max()) <= float(ref.abs().max()) * 2.0 ** -21
-        xo = ref.double().cpu().view(m, c // 32, 32)
+        slots = hl[2].shape[0]
+        xo = ref.double().cpu().view(m, slots, c // slots)
         assert torch.allclose(hl[2][..., 0].double().cpu().T, xo.sum(-1), rtol=1e-5, atol=1e-3)
-        assert torch.allclose(hl[2][..., 1].double().cpu().T, (xo * xo).sum(-1), rtol=1e-5, atol=1e-3)
+        assert torch.allclose(hl[2][..., 1].double().cpu().T, (xo * xo).sum(-1), rtol=1e-5, atol=2e-3)
     assert _rel(ops.hl_to_f32(hl), x) < 1e-6                                  # five updates later: still the fp32 stream
 
 

@@ -140,9 +140,10 @@ typedef struct m3_gemm_desc {
 } m3_gemm_desc;
 int m3_gemm_ex(const m3_gemm_desc *desc, void *stream);
 /* Statistics slots a producer launch of a [M, N] stream (groups 1 or 2) writes per row: stats_out is [slots][M][2] floats per
- * group.  N / 32 (32-column leaves) or, where the launch runs 256-row tiles whose width is the top node of the statistics'
- * sum tree (256 columns for N % 256 == 0, else 192 for N % 192 == 0), one slot per tile: N / 256 or N / 192.  A consumer is
- * given the same count in ln_slots (its K = N).  0: no statistics for this width. */
+ * group.  A slot is a node of the rows' canonical sum tree (32-column leaves -> 64-column pairs -> 128-column halves -> top
+ * nodes of 192 columns for N % 192 == 0, else of 256 for N % 256 == 0; at most 4 top nodes) - the widest one the launch's tile
+ * width is a multiple of: N / 64, N / 128 or one slot per 256- / 192-wide tile.  A consumer is given the same count in ln_slots
+ * (its K = N) and finishes the tree; every combination gives a row the same bits.  0: no statistics for this width. */
 int m3_ln_slot_count(int M, int N, int groups);
 
 /* 3x3 convolution, padding 1, stride 1 or 2, as an implicit GEMM: X bf16 NHWC [B,H,W,Cin],

@@ -300,6 +300,12 @@ k_gemm(const GemmArgs gin) {
         // keeps it at two workgroups per CU: 260 -> 2xx registers)
         epilogue_rows<EPI, NT, NT, DT, (EPI == EPI_BF16_ROPE && T == 128) ? 2 : 4>(g, acc, lds + wave * (NT == 4 ? 9216 : 4608), m0 + wr * (T / 2),
                                                                                   n0 + wc * (T / 2), lane, lnt, wr * (T / 2), ropet);
+        if constexpr (MODE == 0 && (EPI == EPI_F32 || EPI == EPI_F32_ACCUM)) {
+            if (g.stats_out) {                               // kernel-uniform: the tile's statistics leaves -> slots of the sum tree
+                __syncthreads();
+                stats_tile_finalize<BM, NT, NT, 2>(g, lds, NT == 4 ? 9216 : 4608, stats_stage_offset<NT>(), m0, n0, tid);
+            }
+        }
     }
 }
 
@@ -576,18 +582,23 @@ int m3_gemm_bf16_grouped2(const void *A, const void *W0, const void *W1, const f
 
 // widest node of the statistics' canonical tree for a stream of C columns (gemm_common.h): 256, 192 or 0 (no fold for this width)
 static int ln_top_width(int C) {
-    const int w = C % 256 == 0 ? 256 : (C % 192 == 0 ? 192 : 0);
-    return (w && C / w <= 4) ? w : 0;
+    if (C % 192 == 0 && C / 192 <= 4) return 192;            // 768 = the decoder width: the 256-row kernel runs it in 192-wide tiles
+    if (C % 256 == 0 && C / 256 <= 4) return 256;
+    return 0;
 }
-// does the launch of a [M, N] producer finish its tiles' statistics into ONE slot per tile (256-row kernel whose tile width is the
-// stream's top node)?  Same decision in m3_ln_slot_count (the host sizes the buffer with it) and in m3_gemm_ex.
-static bool ln_coarse(int M, int N, int groups) {
+// columns per statistics slot a [M, N] producer launch stores: the widest node of the tree its tile width is a multiple of.  Same
+// decision in m3_ln_slot_count (the host sizes the buffer with it) and in m3_gemm_ex.
+static int ln_store_width(int M, int N, int groups) {
     const int tile = pick_tile(M, N, groups), top = ln_top_width(N);
-    return top != 0 && tile == top;
+    if (top == 0) return 0;
+    if (tile == top) return top;                             // 256-row kernel, one slot per tile
+    if (top == 256 && tile == 128) return 128;
+    return 64;                                               // every tile width is a multiple of 64
 }
 int m3_ln_slot_count(int M, int N, int groups) {
-    if (M <= 0 || N <= 0 || N % 32) return 0;
-    return ln_coarse(M, N, groups > 1 ? 2 : 1) ? N / ln_top_width(N) : N / 32;
+    if (M <= 0 || N <= 0) return 0;
+    const int w = ln_store_width(M, N, groups > 1 ? 2 : 1);
+    return w ? N / w : 0;
 }
 
 int m3_gemm_ex(const m3_gemm_desc *d, void *stream) {
@@ -608,16 +619,16 @@ int m3_gemm_ex(const m3_gemm_desc *d, void *stream) {
                    d->rope_cols <= d->N && d->q_cols >= 0 && d->q_cols <= d->rope_cols && d->q_cols % 64 == 0);
     const bool f32out = epi == EPI_F32 || epi == EPI_F32_ACCUM;
     if (d->c16 || d->stats_out) {          // LayerNorm fold, producer: the row-contiguous epilogue must be the one that runs
-        M3_REQUIRE(f32out && (d->N % 32 == 0 || !d->stats_out) && d->M % 2 == 0 && d->ldc % 8 == 0 && (reinterpret_cast<size_t>(d->C) & 15) == 0 &&
+        M3_REQUIRE(f32out && (d->N % 64 == 0 || !d->stats_out) && d->M % 2 == 0 && d->ldc % 8 == 0 && (reinterpret_cast<size_t>(d->C) & 15) == 0 &&
                    (!d->R || (reinterpret_cast<size_t>(d->R) & 15) == 0) &&
                    (!d->c16 || (reinterpret_cast<size_t>(d->c16) & 15) == 0) &&
                    (!d->stats_out || (reinterpret_cast<size_t>(d->stats_out) & 15) == 0));
         if (groups == 2) M3_REQUIRE(d->c_gstride % 8 == 0 && d->stats_gstride % 4 == 0);
-        if (d->stats_out) M3_REQUIRE(d->stats_slots == m3_ln_slot_count(d->M, d->N, groups));     // the buffer the host sized with it
+        if (d->stats_out) M3_REQUIRE(d->stats_slots > 0 && d->stats_slots == m3_ln_slot_count(d->M, d->N, groups));   // the buffer the host sized with it
     }
     if (d->ln_stats) {                     // LayerNorm fold, consumer
-        const int top = ln_top_width(d->K);                 // the statistics arrive as 32-column leaves or as finished top nodes
-        M3_REQUIRE(top != 0 && (d->ln_slots == d->K / 32 || d->ln_slots == d->K / top));
+        const int top = ln_top_width(d->K);                 // the statistics arrive as pairs, halves or finished top nodes of the tree
+        M3_REQUIRE(top != 0 && (d->ln_slots == d->K / 64 || (top == 256 && d->ln_slots == d->K / 128) || d->ln_slots == d->K / top));
         M3_REQUIRE(!f32out && epi != EPI_BF16_ADD && d->ln_colsum &&
                    d->ln_eps > 0.0f && d->M % 2 == 0 && (reinterpret_cast<size_t>(d->ln_stats) & 15) == 0 &&
                    (reinterpret_cast<size_t>(d->ln_colsum) & 15) == 0 && (reinterpret_cast<size_t>(d->C) & 15) == 0 &&
@@ -641,9 +652,9 @@ int m3_gemm_ex(const m3_gemm_desc *d, void *stream) {
     if (d->ln_stats) {
         const int top = ln_top_width(d->K);
         a.ln_tops = d->K / top;
-        a.ln_gsz = d->ln_slots == d->K / top ? 1 : top / 32;
+        a.ln_gsz = d->ln_slots / a.ln_tops;                  // 1 .. 4 stored slots per top node
     }
-    a.stats_coarse = d->stats_out && ln_coarse(d->M, d->N, groups);
+    a.stats_w = d->stats_out ? ln_store_width(d->M, d->N, groups) : 0;
     const int tile = pick_tile(d->M, d->N, groups);
     if (tile >= 192) return launch_dense_big(a, epi, tile, (hipStream_t)stream);
     if (tile == 64) return launch<0, 64>(a, epi, (hipStream_t)stream);

@@ -231,9 +231,9 @@ k_gemm256(const GemmArgs gin) {
     epilogue_rows<EPI, NI, NJ, DT>(g, acc, lds + wave * (64 * (32 * NJ + 16)), m0 + wr * (16 * NI), n0 + wc * (16 * NJ), lane, lnt,
                                    wr * (16 * NI), ropet);
     if constexpr (MODE == 0 && (EPI == EPI_F32 || EPI == EPI_F32_ACCUM)) {
-        if (g.stats_out && g.stats_coarse) {                 // kernel-uniform: the tile is one top node of the statistics' tree
+        if (g.stats_out) {                                   // kernel-uniform: the tile's statistics leaves -> slots of the sum tree
             __syncthreads();
-            stats_tile_finalize<NI, NJ, WN>(g, lds, 64 * (32 * NJ + 16), stats_stage_offset<NJ>(), m0, tn, tid);
+            stats_tile_finalize<BM, NI, NJ, WN>(g, lds, 64 * (32 * NJ + 16), stats_stage_offset<NJ>(), m0, n0, tid);
         }
     }
 }

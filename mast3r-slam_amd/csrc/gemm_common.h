@@ -115,7 +115,7 @@ struct GemmArgs {
     const int *rope_pos;    // [tokens_per_image, 2 (y|x)] grid positions - cos/sin are then computed in the epilogue
     float rope_log2_base;   //   from frequencies base^(-i/16), i = 0..15 (v_sin_f32 / v_cos_f32, arguments in revolutions)
     int tokens_per_image, rope_cols;
-    int ln_gsz, ln_tops;    // consumer: statistics slots stored per top node (8 or 6 leaves of 32 columns, or 1 = coarse) and top nodes (<= 4)
+    int ln_gsz, ln_tops;    // consumer: stored slots per top node (1 .. 4) and top nodes (<= 4)
     int rope_pmax;          //   position mode: > 0 = every position is in [0, rope_pmax) (<= kRopeTableRows): the kernels then build
                             //   the cos / sin of all rope_pmax x 16 (position, frequency) pairs ONCE per workgroup in LDS
     int q_cols;             // columns < q_cols (the q heads) are multiplied by q_scale after the rotation, before the
@@ -139,12 +139,12 @@ struct GemmArgs {
                             //   stored as bf16 - the operand type of the fast attention loop's P.V product (M3_DT_F16_PVBF16)
     // ---- LayerNorm folded into the GEMMs on both sides of it (m3_gemm_ex; fp16 trunk) ----
     // producer (EPI_F32 / EPI_F32_ACCUM): besides the fp32 stream x' the launch writes C16 = x' rounded to the launch's 16-bit
-    // type (same ldc) and, per row and 32-column slot, (sum x', sum x'^2) into stats_out [M][N/32][2] - from the fp32 values
+    // type (same ldc) and, per row and statistics slot, (sum x', sum x'^2) into stats_out [N / stats_w][M][2] - from the fp32 values
     void *C16;
     float *stats_out;
-    int stats_coarse;       // producer, 256-row kernel only: 1 = ONE statistics slot per tile (slot width = the tile's BN = the stream
-                            // width's top node, 256 or 192 columns): the workgroup adds its waves' 32-column leaves in the canonical
-                            // tree (stats_tile_finalize) - a consumer tile then reads 2 KiB per slot of 256 / 192 columns, not of 32
+    int stats_w;            // producer: columns per stored statistics slot - 64, 128, 192 or 256: a node of the rows' canonical sum
+                            // tree that the launch's tile width is a multiple of (the workgroup adds its waves' 32-column leaves:
+                            // stats_tile_finalize).  One slot per tile where the tile is a top node (256-row kernel, BN = 256 / 192)
     // hi / lo form of the stream (C_lo set; fp16 launches): the stream is kept as TWO 16-bit planes, x = hi + lo with hi = x
     // rounded to fp16 and lo = the rounded remainder (22 significant bits; |x| < 65504).  hi IS the consumer's operand, so the
     // residual launch moves 4 + 4 bytes per element as with an fp32 stream and no separate copy exists: R = hi in, R_lo = lo in,
@@ -360,21 +360,24 @@ __device__ __forceinline__ unsigned dpp_xor1(unsigned v) {
 // kernel and tile shape produce or consume the pieces - so a row's statistics (and with them the network's output) do not depend
 // on the batch a pair is computed in:
 //   leaves      32 columns (8 lanes x 4 columns, dpp_sum8 in the producer's epilogue)
-//   top nodes   256 columns (C % 256 == 0) or 192 (C % 192 == 0): ((l0 + l1) + (l2 + l3)) + ((l4 + l5) + (l6 + l7)), the last
-//               pair absent (zero) for 192
+//   top nodes   192 columns (C % 192 == 0, e.g. 768) or else 256 (C % 256 == 0): ((l0 + l1) + (l2 + l3)) + ((l4 + l5) + (l6 + l7)), the last
+//               pair absent (zero) for 192; its left-aligned subtrees are the 64-column pairs p_j = l_2j + l_2j+1 and (for 256)
+//               the 128-column halves (p0 + p1), (p2 + p3)
 //   total       ((t0 + t1) + t2) + t3 over the <= 4 top nodes (absent ones zero; x + 0 = x keeps the bits)
-// Producers store leaves (slot-major [C / 32][M][2]) or, where a workgroup's tile IS a top node (256-row kernel, BN = 256 / 192),
-// the finished top nodes ([C / 256 or C / 192][M][2]: 1/8 or 1/6 of the bytes - a consumer pays for statistics bytes what it pays
-// for operand bytes, profiles/r05_fold_probe.md).
+// A producer stores the widest node its tile width is a multiple of - pairs (64-column tiles, and 128-wide tiles of a 192-family
+// stream), halves (128-wide tiles), whole top nodes (256-row kernel with BN = 256 / 192: one slot per tile) - slot-major
+// [C / w][M][2]; a consumer builds each top node as (u0 + u1) + (u2 + u3) from its stored slots (absent ones zero) - the same
+// expression whatever the level.  A consumer pays for statistics bytes what it pays for operand bytes
+// (profiles/r05_fold_probe.md): 2 KiB per 256-row tile and slot.
 __device__ __forceinline__ float ln_tree8(const float (&x)[8]) {
     return ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
 }
 // LayerNorm fold, consumer side: mean and 1 / sqrt(var + eps) of the tile's rows.  FOUR threads per PAIR of rows (the (sum, sum
 // of squares) of two neighbouring rows of a slot are one 16-byte load): thread (pair p, q) builds top node q of rows 2p, 2p + 1
-// from its ln_gsz stored slots (8 / 6 leaves, or the node itself), the quad then folds the nodes in index order on the DPP path,
-// every lane the same expression.  M even (host check); rows past M read the last pair.  Returns (mean, rstd) of row 2p in .x .y
-// and of row 2p + 1 in .z .w, in all four lanes of the quad; threads >= 2 ROWS repeat pair 0's work (ln_table_store ignores them).
-struct LnLoads { float4 v[8]; };
+// from its ln_gsz stored slots, the quad then folds the nodes in index order on the DPP path, every lane the same expression.
+// M even (host check); rows past M read the last pair.  Returns (mean, rstd) of row 2p in .x .y and of row 2p + 1 in .z .w, in
+// all four lanes of the quad; threads >= 2 ROWS repeat pair 0's work (ln_table_store ignores them).
+struct LnLoads { float4 v[4]; };
 // (mean, 1 / sqrt(var + eps)) of a row from its sum and sum of squares over `cols` columns, in ONE spelled-out operation
 // sequence, so each kernel that builds a row table gets the same bits
 __device__ __forceinline__ float2 ln_mean_rstd(float s, float q, int cols, float eps) {
@@ -383,7 +386,9 @@ __device__ __forceinline__ float2 ln_mean_rstd(float s, float q, int cols, float
     const float var = fmaxf(__builtin_fmaf(-mean, mean, q * inv), 0.f);      // the fma spelled out: hipcc contracts a * b - c * d
     return make_float2(mean, rsqrtf(var + eps));                             // as it likes per call site (__fmul_rn does not stop it)
 }
-// first half: the thread's loads go out (and stay in flight: a kernel puts its first K-tile's loads between the two halves)
+// first half: the thread's loads go out (and stay in flight: a kernel puts its first K-tile's loads between the two halves).
+// UNCONDITIONAL loads from clamped addresses, the bound applied to the value in the second half (a bound on the load makes hipcc
+// branch around each one and wait for it where it stands)
 template <int ROWS>
 __device__ __forceinline__ LnLoads ln_row_issue(const GemmArgs &g, int m0, int tid) {
     LnLoads L;
@@ -393,68 +398,66 @@ __device__ __forceinline__ LnLoads ln_row_issue(const GemmArgs &g, int m0, int t
     m = m < g.M - 1 ? m : g.M - 2;
     const float4 *p = reinterpret_cast<const float4 *>(g.ln_stats + ((size_t)node * g.ln_gsz * g.M + m) * 2);
     const size_t slot_stride = (size_t)g.M / 2;              // float4 units between consecutive slots
-    L.v[0] = p[0];
-    if (g.ln_gsz > 1) {                                      // kernel-uniform.  UNCONDITIONAL loads from clamped addresses, the bound
-#pragma unroll                                               // applied to the value (a bound on the load makes hipcc branch around
-        for (int i = 1; i < 8; ++i) L.v[i] = p[(size_t)(i < g.ln_gsz ? i : g.ln_gsz - 1) * slot_stride];    // each one and wait for it)
-    } else {
 #pragma unroll
-        for (int i = 1; i < 8; ++i) L.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int i = 0; i < 4; ++i) L.v[i] = p[(size_t)(i < g.ln_gsz ? i : g.ln_gsz - 1) * slot_stride];
     return L;
 }
 template <int ROWS>
 __device__ __forceinline__ float4 ln_row_finish(const GemmArgs &g, const LnLoads &L, int m0, int tid) {
     const bool live = (tid & 3) < g.ln_tops;
-    float c[4][8];
+    float4 u[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 4; ++i) {
         const bool on = live && i < g.ln_gsz;
-        c[0][i] = on ? L.v[i].x : 0.f; c[1][i] = on ? L.v[i].y : 0.f; c[2][i] = on ? L.v[i].z : 0.f; c[3][i] = on ? L.v[i].w : 0.f;
+        u[i] = make_float4(on ? L.v[i].x : 0.f, on ? L.v[i].y : 0.f, on ? L.v[i].z : 0.f, on ? L.v[i].w : 0.f);
     }
+    const float node[4] = {(u[0].x + u[1].x) + (u[2].x + u[3].x), (u[0].y + u[1].y) + (u[2].y + u[3].y),
+                           (u[0].z + u[1].z) + (u[2].z + u[3].z), (u[0].w + u[1].w) + (u[2].w + u[3].w)};
     float t[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float node = ln_tree8(c[k]);
-        const int b = __builtin_bit_cast(int, node);         // the quad's four top nodes, folded in index order by every lane
+        const int b = __builtin_bit_cast(int, node[k]);      // the quad's four top nodes, folded in index order by every lane
         const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, b, 0x00, 0xF, 0xF, true));   // quad_perm [0,0,0,0]
         const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, b, 0x55, 0xF, 0xF, true));   // [1,1,1,1]
         const float t2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, b, 0xAA, 0xF, 0xF, true));   // [2,2,2,2]
         const float t3 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, b, 0xFF, 0xF, 0xF, true));   // [3,3,3,3]
         t[k] = ((t0 + t1) + t2) + t3;
     }
-    const int cols = g.K;
-    const float2 a = ln_mean_rstd(t[0], t[1], cols, g.ln_eps), b2 = ln_mean_rstd(t[2], t[3], cols, g.ln_eps);
+    const float2 a = ln_mean_rstd(t[0], t[1], g.K, g.ln_eps), b2 = ln_mean_rstd(t[2], t[3], g.K, g.ln_eps);
     return make_float4(a.x, a.y, b2.x, b2.y);
 }
 template <int ROWS>
 __device__ __forceinline__ float4 ln_row_stats(const GemmArgs &g, int m0, int tid) {
     return ln_row_finish<ROWS>(g, ln_row_issue<ROWS>(g, m0, tid), m0, tid);
 }
-// Producer, 256-row kernel with a coarse slot (g.stats_coarse): after the waves' epilogues (and a workgroup barrier) the 32-column
-// leaves of the whole tile sit in the waves' scratch, [leaf of the wave][row of the wave] float2 behind each transpose image;
-// thread t < 256 adds row t's BN / 32 leaves in the canonical tree and stores ONE slot (index = the tile's N index).
 // byte offset of the statistics staging inside a wave's epilogue scratch (behind the 16-row fp32 transpose image)
 template <int NJ> constexpr int stats_stage_offset() { return (16 * ((NJ == 4) ? 256 : NJ * 64 + 16) + 15) & ~15; }
-template <int NI, int NJ, int WN>
+// Producer: after the waves' epilogues (and a workgroup barrier) the 32-column leaves of the whole tile sit in the waves' scratch,
+// [leaf of the wave][row of the wave] float2 behind each transpose image.  Thread t < TROWS takes row t: for every slot of
+// g.stats_w columns inside the tile it adds the slot's leaves in the canonical tree (left-aligned, absent leaves zero) and stores
+// it; consecutive threads store consecutive rows of a slot (8 B each).
+template <int TROWS, int NI, int NJ, int WN>
 __device__ __forceinline__ void stats_tile_finalize(const GemmArgs &g, const unsigned char *lds, int wave_stride, int wst_off,
-                                                    int m0, int tn, int tid) {
-    constexpr int WROWS = 16 * NI, LPW = NJ / 2, LEAVES = WN * LPW;     // rows per wave, leaves per wave, leaves per tile (8 or 6)
-    if (tid >= 256) return;
+                                                    int m0, int n0, int tid) {
+    constexpr int WROWS = 16 * NI, LPW = NJ / 2, LEAVES = WN * LPW;     // rows per wave, leaves per wave, leaves per tile
+    if (tid >= TROWS) return;
     const int wr = tid / WROWS, rr = tid - wr * WROWS;
-    float s[8], q[8];
+    const int lpu = g.stats_w >> 5;                          // leaves per slot: 2, 4, 6 or 8
+    const int m = m0 + tid;
+    for (int k = 0; k * lpu < LEAVES; ++k) {
+        float s[8], q[8];
 #pragma unroll
-    for (int l = 0; l < 8; ++l) {
-        if (l < LEAVES) {
+        for (int i = 0; i < 8; ++i) {
+            const bool on = i < lpu;
+            const int l = k * lpu + (on ? i : 0);
             const int wc = l / LPW, sl = l - wc * LPW;
             const float2 v = *reinterpret_cast<const float2 *>(lds + (wr * WN + wc) * wave_stride + wst_off + (sl * WROWS + rr) * 8);
-            s[l] = v.x; q[l] = v.y;
-        } else {
-            s[l] = 0.f; q[l] = 0.f;
+            s[i] = on ? v.x : 0.f; q[i] = on ? v.y : 0.f;
         }
+        const int n = n0 + k * g.stats_w;
+        if (m < g.M && n < g.N)
+            *reinterpret_cast<float2 *>(g.stats_out + ((size_t)(n / g.stats_w) * g.M + m) * 2) = make_float2(ln_tree8(s), ln_tree8(q));
     }
-    const int m = m0 + tid;
-    if (m < g.M) *reinterpret_cast<float2 *>(g.stats_out + ((size_t)tn * g.M + m) * 2) = make_float2(ln_tree8(s), ln_tree8(q));
 }
 template <int ROWS>
 __device__ __forceinline__ void ln_table_store(float2 *tab, const float4 &mr, int tid) {
@@ -649,19 +652,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs &g, f32x4 (&acc)[NI
             }
             asm volatile("" ::: "memory");
         }
-        if (F32OUT && g.stats_out && !g.stats_coarse) {       // (coarse slot: the leaves stay in the scratch for stats_tile_finalize)
-            // the sub-tile's statistics leave as runs of 16 NI rows x 8 B per slot (slot-major layout [N / 32][M][2]), 16 bytes
-            // = two rows per lane: M and the sub-tile's first row are even (host check), so a pair is inside or outside together
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            constexpr int ROWS = 16 * NI;
-#pragma unroll
-            for (int sl = 0; sl < NJ / 2; ++sl) {
-                const int n = n_base + sl * 32, m = m_base + 2 * lane;
-                if (2 * lane < ROWS && m < g.M && n < g.N)
-                    *reinterpret_cast<float4 *>(g.stats_out + ((size_t)(n >> 5) * g.M + m) * 2) =
-                        *reinterpret_cast<const float4 *>(wst + sl * ROWS + 2 * lane);
-            }
-        }
+        // (the sub-tile's statistics leaves stay in the scratch: the kernel's stats_tile_finalize turns the tile's leaves into slots)
     } else {
         // 64-column sub-tiles (NJ = 4: 128-byte rows) use an UNPADDED scratch: the 16-byte chunk c of row r is stored at
         // chunk c ^ ((r >> 1) & 7), and odd rows store the two 8-byte halves of a chunk swapped.

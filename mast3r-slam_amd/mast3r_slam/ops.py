@@ -601,11 +601,9 @@ def ln_fold_buffers(rows: int, cols: int, dtype, device, groups: int = 1):
 
 
 def ln_slot_count(rows: int, cols: int, groups: int = 1) -> int:
-    """Statistics slots per row a producer launch of a [rows, cols] stream writes (m3_ln_slot_count): cols / 32 leaves, or
-    one slot per 256- / 192-column top node where the launch runs 256-row tiles of exactly that width (the consumer then reads
-    1/8 or 1/6 of the bytes).  The decision follows the tile the launch will be dispatched to."""
-    if cols % 192 and cols % 256 or cols // (256 if cols % 256 == 0 else 192) > 4:
-        raise ValueError("LayerNorm fold: the stream width must be 1..4 times 256 or 192 columns")
+    """Statistics slots per row a producer launch of a [rows, cols] stream writes (m3_ln_slot_count): nodes of the rows'
+    canonical sum tree, cols / 64 pairs, cols / 128 halves or one slot per 256- / 192-column top node - the widest the tile
+    the launch will be dispatched to allows."""
     n = int(_ffi.lib().m3_ln_slot_count(int(rows), int(cols), int(groups)))
     if n <= 0:
         raise ValueError(f"no LayerNorm-fold statistics for a [{rows}, {cols}] stream")
@@ -736,7 +734,7 @@ def gemm_ex(a, w, bias=None, epi: int = EPI_BF16, out=None, resid=None, w1=None,
         if (stats.dtype != torch.float32 or stats.dim() != len(lead) + 3 or tuple(stats.shape[:len(lead)]) != lead
                 or tuple(stats.shape[-2:]) != (m, 2) or not stats.is_contiguous()):
             raise ValueError("bad fold_in statistics")
-        slots = stats.shape[-3]                                  # k / 32 leaves or the producer's finished top nodes (checked in C)
+        slots = stats.shape[-3]                                  # the producer's tree level (checked in C)
         cs0 = _ffi.check(cs0, torch.float32, "colsum", (n,))
         if grouped:
             cs1 = _ffi.check(cs1, torch.float32, "colsum1", (n,))

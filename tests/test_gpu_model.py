@@ -952,8 +952,8 @@ def test_layernorm_fold_producer_and_consumer(dev, shape):
     assert torch.equal(out, plain)                                           # the fp32 stream is what the plain launch writes
     x16, st = fo
     assert torch.equal(x16, out.half())                                      # the copy is the stream rounded once
-    slots = st.shape[0]                                                       # c / 32 leaves, or one slot per 256- / 192-column tile
-    assert slots == ops.ln_slot_count(m, c) and slots in (c // 32, c // 256 if c % 256 == 0 else c // 192)
+    slots = st.shape[0]                                                       # 64-column pairs, 128-column halves or one slot per 256- / 192-column tile
+    assert slots == ops.ln_slot_count(m, c) and slots in (c // 64, c // 128, c // 192 if c % 192 == 0 else c // 256)
     xo = out.double().cpu().view(m, slots, c // slots)
     assert torch.allclose(st[..., 0].double().cpu().T, xo.sum(-1), rtol=1e-5, atol=1e-3)          # slot-major [slots, m, 2]
     assert torch.allclose(st[..., 1].double().cpu().T, (xo * xo).sum(-1), rtol=1e-5, atol=2e-3)
@@ -976,10 +976,9 @@ def test_layernorm_fold_producer_and_consumer(dev, shape):
 
 @pytest.mark.parametrize("c", [768, 1024])
 def test_layernorm_fold_is_tile_shape_invariant(dev, c):
-    """A row's statistics are ONE expression tree (32-column leaves -> 256- / 192-column top nodes -> total) whichever kernel
-    produces or consumes the pieces, so the stream, its copy AND the consumer's output are bitwise the same whichever tile shape
-    a launch is dispatched to (64 / 128 / 192 / 256) - including the shapes whose producer stores finished top nodes (one slot
-    per tile) instead of leaves."""
+    """A row's statistics are ONE expression tree (32-column leaves -> pairs -> halves -> 256- / 192-column top nodes -> total)
+    whichever kernel produces or consumes the pieces, so the stream, its copy AND the consumer's output are bitwise the same
+    whichever tile shape a launch is dispatched to (64 / 128 / 192 / 256), each of which stores a different level of the tree."""
     m, n = 4096, 1536
     x, gam, bet, W, b, ref, wf, cs, fb = _fold_problem(m, c, n, seed=3)
     g = torch.Generator(device="cpu").manual_seed(9)
@@ -997,7 +996,7 @@ def test_layernorm_fold_is_tile_shape_invariant(dev, c):
             shapes.add(fo[1].shape[0])
     finally:
         ops._ffi.lib().m3_gemm_set_tile(prev)
-    assert shapes == {c // 32, c // (256 if c % 256 == 0 else 192)}           # leaves, and top nodes from the tile as wide as one
+    assert shapes == ({12, 4} if c == 768 else {16, 8, 4})                    # pairs / halves / top nodes, by what the tile width allows
     for other in got[1:]:
         for p, q in zip(got[0], other):
             assert torch.equal(p, q)

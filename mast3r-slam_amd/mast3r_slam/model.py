@@ -426,8 +426,8 @@ class Mast3rFull:
             ops.patchify16(imgs_u8, dt, out=patches[:b * t])
             ops.patchify16(imgs2_u8, dt, out=patches[b * t:])
             b = 2 * b
-        if self.ln_fold:
-            return self._encode_fold(patches, b, t, rtok), (gh, gw)
+        if self.ln_fold and patches.shape[0] % 2 == 0:           # (the fold works on row PAIRS: an odd row count - one image with an
+            return self._encode_fold(patches, b, t, rtok), (gh, gw)   #  odd token grid, e.g. 21 x 21 - takes the LayerNorm kernels)
         x = ops.gemm(patches, P["patch.w"], P["patch.b"], ops.EPI_F32)                        # fp32 residual stream
         for i in range(c["enc_depth"]):
             p = f"enc_blocks.{i}"
@@ -491,7 +491,7 @@ class Mast3rFull:
             fcat = torch.as_strided(f1, (2, m, f1.shape[1]), (m * f1.shape[1], f1.shape[1], 1))   # adjacent halves of the encoder batch
         else:
             fcat = torch.stack([f1, f2])                                                 # [2,M,1024]
-        if self.ln_fold:
+        if self.ln_fold and m % 2 == 0:
             return self._decode_fold(fcat, f1, f2, npairs, t, rtok)
         x = ops.gemm_grouped2(fcat, P["decoder_embed.w"], P["decoder_embed.w"], P["decoder_embed.b"],
                               P["decoder_embed.b"], ops.EPI_F32)                         # fp32 residual streams [2,M,D]

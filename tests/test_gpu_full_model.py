@@ -214,6 +214,25 @@ def test_token_counts_that_are_not_multiples_of_128(tiny, dev, shape):
     assert torch.equal(q1["pts3d"], e1["pts3d"])
 
 
+def test_odd_token_grid_one_image_and_one_pair(tiny, dev):
+    """336 x 336 -> a 21 x 21 grid, 441 tokens: model.encode of ONE image is a 441-row stream and one pair decodes two 441-row
+    groups - odd row counts, which the LayerNorm fold (row pairs) hands to the LayerNorm kernels.  Same contract and the same
+    1e-3 against the oracle as every other shape."""
+    cfg, w, net = tiny
+    h = wd = 336
+    im1, im2 = _pair(h, wd, 5)
+    tok = net.encode(im1[0])
+    assert tok.shape == (441, cfg["enc_dim"]) and torch.isfinite(tok.float()).all()
+    both = net.encode(np.concatenate([im1, im2]))                      # 882 rows: the folded path on the fp16 trunk
+    assert _rel(tok, both[0]) < 3e-3
+    o1, o2 = net.reconstruct_batch(im1, im2)
+    with torch.no_grad():
+        r1, r2 = OM.reconstruct(w, torch.from_numpy(im1), torch.from_numpy(im2), cfg)
+    for o, r in ((o1, r1), (o2, r2)):
+        assert o["pts3d"].shape == (1, h, wd, 3)
+        assert _rel(o["pts3d"], r["pts3d"]) < 1e-3 and _rel(o["conf"], r["conf"]) < 1e-4
+
+
 def test_checkpoint_round_trip_and_precision_argument(tiny, dev, tmp_path):
     """load_mast3r(model_type, variant, resolution, precision) + from_pretrained(weights_path)
     (mast3r_utils.py:47-80, :67-76): a saved state dict - bare, wrapped as the public checkpoint

@@ -14,7 +14,7 @@ T = 1024
 pos = torch.stack(torch.meshgrid(torch.arange(32), torch.arange(32), indexing="ij"), -1).reshape(-1, 2).to(dev)
 inv = 1.0 / (100.0 ** (torch.arange(0, 32, 2, dtype=torch.float32) / 32.0))
 ang = torch.arange(33, dtype=torch.float32)[:, None] * inv[None]
-rtok = pos.to(torch.int32).contiguous()      # position mode (what the model uses); the f32 table of ops.rope_token_table(pos,
+rtok = ops.rope_bound(pos.to(torch.int32).contiguous(), 32)      # position mode with the range promised (what the model uses); the f32 table of ops.rope_token_table(pos,
                                              # torch.stack([ang.cos(), ang.sin()], -1).to(dev)) selects the table mode
 
 def mk(m, n, k, dt, groups):
